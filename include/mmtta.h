@@ -1,0 +1,252 @@
+/*
+ * mmtta.h - C ABI of libmmtta.so, the MI355X (gfx950) kernels of the per-volume adaptation
+ * hot path of zhm1205/Multimodal_TTA.
+ *
+ * Boundary rules ("C-ABI layer"):
+ *   - plain C: pointers, sizes, POD structs; no torch / C++ types in any signature;
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed
+ *     inside, all scratch memory is passed in as a workspace;
+ *   - every call is asynchronous on the hipStream_t passed as `void* stream` (0 = default
+ *     stream) and safe to capture into a hipGraph (no sync, no malloc, no host readback);
+ *   - return value: 0 on success, negative mmtta_status otherwise; never throws.
+ *
+ * The reference has no native layer.  Each entry point names the torch / MONAI call it
+ * stands in for and the reference file:line that reaches it.  "Reference" paths are relative
+ * to the upstream repository root.
+ *
+ * Internal activation layout: channels-last NDHWC ("CL"), element stride 1 along C, described
+ * by mmtta_tensor.  Boundary tensors (input volume, returned logits, labels) are NCDHW.
+ */
+#ifndef MMTTA_H
+#define MMTTA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMTTA_ABI_VERSION 1
+
+typedef enum {
+  MMTTA_OK = 0,
+  MMTTA_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, bad enum) */
+  MMTTA_ERR_UNSUPPORTED = -2, /* valid request this build has no kernel for (stated in message) */
+  MMTTA_ERR_LAUNCH = -3,      /* hipLaunch / hipGetLastError failure */
+  MMTTA_ERR_WORKSPACE = -4    /* workspace too small */
+} mmtta_status;
+
+typedef enum { MMTTA_F32 = 0, MMTTA_BF16 = 1 } mmtta_dtype;
+
+/* A 5-D view.  Strides are in ELEMENTS.  Kernels that need channels-last require sc == 1. */
+typedef struct {
+  void* ptr;
+  int32_t n, c, d, h, w;
+  int64_t sn, sc, sd, sh, sw;
+  int32_t dtype; /* mmtta_dtype */
+  int32_t _pad;
+} mmtta_tensor;
+
+/* Per-(n,c) normalisation applied to a tensor WHEN IT IS READ ("norm on load"):
+ *   v = (x - mean[n*C+c]) * rstd[n*C+c] * (gamma ? gamma[c] : 1) + (beta ? beta[c] : 0);
+ *   if (relu) v = max(v, 0);
+ * mean == NULL means "no transform".  This is MONAI's ADN (Norm -> Dropout(p=0) -> ReLU) of the
+ * producing Convolution, folded into the consumer (reference:
+ * src/models/unet_multimodal_midfusion.py:45-55 via monai Convolution/ADN). */
+typedef struct {
+  const float* mean;  /* [N*C] or NULL */
+  const float* rstd;  /* [N*C] */
+  const float* gamma; /* [C] or NULL */
+  const float* beta;  /* [C] or NULL */
+  int32_t relu;
+  int32_t _pad;
+} mmtta_norm_on_load;
+
+const char* mmtta_last_error(void);   /* thread-local text for the last non-zero status */
+int mmtta_abi_version(void);
+
+/* ------------------------------------------------------------------ layout (boundary) ---- */
+/* NCDHW fp32 <-> channels-last.  Stands in for nothing in the reference: it is the price of
+ * the internal layout, paid once per volume on the way in (reference tensor contract:
+ * src/datasets/brats.py:343-347, image float32 [C,D,H,W]) and once on the way out
+ * (src/evaluation/seg_eval.py:300, logits [B,R,D,H,W]).  Any strides are accepted. */
+int mmtta_copy_strided(const mmtta_tensor* src, const mmtta_tensor* dst, void* stream);
+
+/* ------------------------------------------------------------------ convolution ---------- */
+typedef enum {
+  MMTTA_CONV_FWD = 0,    /* torch.nn.Conv3d forward,       y = conv(x, W) + b                */
+  MMTTA_CONV_DGRAD = 1,  /* its input gradient,            dx = conv_transpose(dy, W)        */
+  MMTTA_CONVT_FWD = 2,   /* torch.nn.ConvTranspose3d fwd   (k3 s2 p1 op1), W is [Cin,Cout,k] */
+  MMTTA_CONVT_DGRAD = 3  /* its input gradient,            dx = conv(dy, W), stride 2        */
+} mmtta_conv_op;
+
+typedef struct {
+  int32_t op;      /* mmtta_conv_op */
+  int32_t ksize;   /* 1 or 3 (padding (k-1)/2, dilation 1, groups 1) */
+  int32_t stride;  /* 1 or 2 (ConvTranspose: 2 only) */
+  int32_t cin;     /* channels of the module's INPUT  (Conv3d.in_channels)  */
+  int32_t cout;    /* channels of the module's OUTPUT (Conv3d.out_channels) */
+  int32_t dtype;   /* arithmetic: MMTTA_F32 (fp32 MFMA, exact fp32) or MMTTA_BF16 */
+} mmtta_conv_desc;
+
+/* Size in bytes of the packed weight image for (desc.op): the MFMA-ready copy
+ * [tap][K][N] (K = reduction channels, N = produced channels, both zero padded). */
+int64_t mmtta_conv_packed_bytes(const mmtta_conv_desc* desc);
+
+/* Repack master weights (torch layout, fp32: Conv3d [Cout,Cin,k,k,k]; ConvTranspose3d
+ * [Cin,Cout,k,k,k]) into the image used by mmtta_conv_run for desc.op.
+ * Runs once per optimizer step. */
+int mmtta_conv_pack_weights(const mmtta_conv_desc* desc, const float* w_master, void* packed, void* stream);
+
+/* Launch geometry chosen for a problem; filled by mmtta_conv_plan. */
+typedef struct {
+  int32_t tiles;         /* M tiles (over n and space) per launch                           */
+  int32_t launches;      /* 1, or 8 parity classes for stride-2 transposed forms             */
+  int32_t ksplit;        /* >1: partial sums go through the workspace                        */
+  int32_t stats_rows;    /* rows of the [rows][2][C] partial-statistics slab this op writes  */
+  int64_t workspace_bytes;
+} mmtta_conv_plan_t;
+
+/* `x` is the tensor the op READS, `y` the tensor it PRODUCES (for *_DGRAD: x = dy, y = dx). */
+int mmtta_conv_plan(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_tensor* y,
+                    mmtta_conv_plan_t* plan);
+
+/* Optional epilogue of mmtta_conv_run: y = acc + bias + T(add), T = norm-on-load of `add`.
+ * Fuses MONAI ResidualUnit's `cx + res` (reference: unet_multimodal_midfusion.py:45-55,
+ * 121-131 through monai ResidualUnit.forward) into the residual convolution. */
+typedef struct {
+  const mmtta_tensor* add;          /* NULL: nothing added; same shape as y, channels-last */
+  mmtta_norm_on_load add_norm;      /* transform of `add` (mean NULL: added as is)         */
+} mmtta_conv_epilogue;
+
+/* One convolution-shaped op as an implicit GEMM on the matrix cores.
+ *   Replaces: torch.nn.Conv3d / ConvTranspose3d forward and autograd's input-gradient,
+ *   reached from reference src/models/unet.py:68-69 (monai UNet) and
+ *   src/models/unet_multimodal_midfusion.py:204-267; backward from
+ *   src/core/trainers/seg_trainer.py:142 (loss.backward()).
+ *   x        tensor read (channels-last), with an optional norm-on-load
+ *   packed   image from mmtta_conv_pack_weights for the same desc
+ *   bias     [produced channels] fp32 or NULL
+ *   y        tensor written (channels-last); accumulate != 0: y += result
+ *   stats    NULL or fp32 [plan.stats_rows][2][C_produced]: per-tile sum / sum of squares of the
+ *            values written (input of mmtta_norm_stats_finalize)
+ *   workspace  plan.workspace_bytes bytes or NULL when 0 */
+int mmtta_conv_run(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                   const void* packed, const float* bias, const mmtta_conv_epilogue* epi,
+                   const mmtta_tensor* y, int accumulate, float* stats, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
+/* Weight (and bias) gradient.
+ *   Replaces: autograd's weight-gradient of Conv3d / ConvTranspose3d
+ *   (reference src/core/trainers/seg_trainer.py:142).
+ *   desc.op  MMTTA_CONV_FWD or MMTTA_CONVT_FWD (which module the gradient is for)
+ *   x, x_norm the module's forward input (with the transform it was read with)
+ *   dy       gradient of the module's output
+ *   dw       fp32, torch layout of the module's weight; accumulate != 0: dw += result
+ *   db       fp32 [cout] or NULL */
+int64_t mmtta_conv_wgrad_workspace_bytes(const mmtta_conv_desc* desc, const mmtta_tensor* x,
+                                         const mmtta_tensor* dy);
+int mmtta_conv_wgrad(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                     const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ normalisation -------- */
+typedef enum {
+  MMTTA_NORM_INSTANCE = 0, /* torch.nn.InstanceNorm3d(affine=False): statistics per (n,c)      */
+  MMTTA_NORM_BATCH = 1,    /* torch.nn.BatchNorm3d: statistics per c over (n,d,h,w)            */
+  MMTTA_NORM_GROUP = 2     /* torch.nn.GroupNorm: statistics per (n, group of C/groups chans)  */
+} mmtta_norm_kind;
+
+/* Turn per-tile partial sums into the per-(n,c) mean / rstd that consumers read.
+ *   Replaces: the statistics half of F.instance_norm / F.batch_norm / F.group_norm (biased
+ *   variance, eps inside the sqrt), reached from monai ADN "N".
+ *   part     fp32 [rows][2][C] from mmtta_conv_run (rows = rows_per_n * N, n-major)
+ *   scratch  fp64 [N*C*2] (fp64 totals between the two stages)
+ *   count    voxels per (n,c) = D*H*W
+ *   running_mean/var, momentum: BatchNorm only.  training != 0: batch statistics are used and
+ *            the running buffers get the EMA update (unbiased variance), the "norm-stat
+ *            update" of the adaptation step; training == 0: running statistics are used.
+ *   mean, rstd   fp32 [N*C] outputs */
+int mmtta_norm_stats_finalize(int kind, int groups, const float* part, int rows_per_n, int n, int c,
+                              int64_t count, float eps, int training, float* running_mean,
+                              float* running_var, float momentum, float* mean, float* rstd,
+                              double* scratch, void* stream);
+
+/* Rows per batch item of the partial slabs written by mmtta_channel_stats and
+ * mmtta_norm_bwd_reduce for a tensor of this shape (deterministic two-stage reductions). */
+int mmtta_reduce_rows_per_n(const mmtta_tensor* t);
+
+/* Per-(n,c) partial sum / sum-of-squares of a tensor that no convolution epilogue produced.
+ * part: fp32 [N * mmtta_reduce_rows_per_n(x)][2][C]. */
+int mmtta_channel_stats(const mmtta_tensor* x, float* part, void* stream);
+
+/* out = Ta(a) + Tb(b)  (b may be NULL), Ta/Tb = norm-on-load.  Materialises
+ * relu(norm(y)) [+ residual]: monai ResidualUnit.forward's add with an Identity residual. */
+int mmtta_combine(const mmtta_tensor* a, const mmtta_norm_on_load* ta, const mmtta_tensor* b,
+                  const mmtta_norm_on_load* tb, const mmtta_tensor* out, void* stream);
+
+/* Backward of norm(+ReLU), pass 1: per-(n,c) reductions
+ *   s1[n,c] = sum dz, s2[n,c] = sum dz * xhat,  dz = dout * [post > 0] (relu) or dout,
+ *   xhat = (y - mean) * rstd,  post = gamma*xhat + beta.
+ *   part: fp32 [N * mmtta_reduce_rows_per_n(y)][2][C].  Replaces the reduction half of
+ *   native_*_norm_backward. */
+int mmtta_norm_bwd_reduce(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
+                          float* part, void* stream);
+
+/* Pass 2 coefficients: from part -> m1, m2 [N*C] (group means of gamma*dz and gamma*dz*xhat) and,
+ * if gamma is trained, dgamma / dbeta [C] (accumulate != 0: +=).  training == 0 (BatchNorm on
+ * running statistics): m1 = m2 = 0. */
+int mmtta_norm_bwd_finalize(int kind, int groups, const float* part, int rows_per_n, int n, int c, int64_t count,
+                            const float* gamma, int training, float* m1, float* m2, float* dgamma,
+                            float* dbeta, int accumulate, double* scratch /* fp64 [N*C*2] */, void* stream);
+
+/* Pass 3: dy = rstd * (gamma*dz - m1 - xhat*m2); dy may alias dout. */
+int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
+                         const float* m1, const float* m2, const mmtta_tensor* dy, void* stream);
+
+/* ------------------------------------------------------------------ resampling / glue ---- */
+/* nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True) and its adjoint
+ * (reference: src/models/unet_multimodal_midfusion.py:114-120,134 via monai UpSample). */
+int mmtta_upsample2x_fwd(const mmtta_tensor* x, const mmtta_tensor* y, void* stream);
+int mmtta_upsample2x_bwd(const mmtta_tensor* dy, const mmtta_tensor* dx, int accumulate, void* stream);
+
+/* out = sum_i w[i] * in[i], i < count <= 8 (accumulate != 0: out += ...).  The M-way modality
+ * means torch.stack(...).mean (reference: unet_multimodal_midfusion.py:221,229,247), the
+ * f_shared + residual add (:96) and their adjoints. */
+int mmtta_lincomb(int count, const mmtta_tensor* const* in, const float* w, const mmtta_tensor* out,
+                  int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ loss ----------------- */
+/* Entropy-minimisation objective and its gradient in one pass (BUILD-DEFINED: the reference
+ * has no TTA loss; it takes the place of DiceCELoss in the step
+ * skeleton of reference src/core/trainers/seg_trainer.py:141-142).
+ *   softmax == 0: mean over (n,r,voxel) of H_bern(z) = softplus(z) - z*sigmoid(z)
+ *   softmax != 0: mean over (n,voxel)   of H_cat(z)  = logsumexp_r z - sum_r p_r z_r
+ *   logits, dlogits  channels-last, same shape; dlogits = dLoss/dlogits
+ *   partial  fp64 [mmtta_entropy_partials(...)] scratch; loss  fp32 [1] */
+int64_t mmtta_entropy_partials(const mmtta_tensor* logits);
+int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits,
+                       double* partial, float* loss, void* stream);
+
+/* ------------------------------------------------------------------ optimizer ------------ */
+/* torch.optim.Adam (amsgrad=False, coupled L2) over a flat parameter arena, two segments:
+ * [0, n_decay) with weight_decay, [n_decay, n) without - the decay / no-decay groups of
+ * reference src/core/experiment_manager.py:199-237; hyper-parameters
+ * configs/training/default.yaml:30-39.  `step` is a device int32 incremented by this call
+ * (t starts at 1), so a captured graph replays correctly.  SURVEY.md Appendix E K8. */
+int mmtta_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int32_t* step, void* stream);
+
+/* ------------------------------------------------------------------ evaluation tail ------ */
+/* sigmoid -> (>= threshold) -> uint8 mask; GT (> 0.5); per (n,r) integer counts
+ * inter = sum p&g, psum = sum p, gsum = sum g.  Replaces reference
+ * src/evaluation/seg_eval.py:304-306 and the three reductions of :55-60.
+ *   logits  channels-last fp32;  label  any strides, fp32 {0,1};
+ *   counts  int64 [N][R][3], zeroed by this call;  mask  uint8 NCDHW [N,R,D,H,W] or NULL */
+int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label, float threshold,
+                           int64_t* counts, uint8_t* mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMTTA_H */

@@ -1,0 +1,91 @@
+// Shared helpers for the gfx950 kernels of libmmtta.so.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mmtta.h"
+
+namespace mmtta {
+
+constexpr int WAVE = 64;
+
+void set_error(const char* fmt, ...);
+
+#define MMTTA_CHECK(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::mmtta::set_error(__VA_ARGS__);    \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+inline int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return MMTTA_ERR_LAUNCH;
+  }
+  return MMTTA_OK;
+}
+
+inline bool is_cl(const mmtta_tensor* t) { return t->sc == 1 || t->c == 1; }
+
+// Device-side copy of a tensor view (float data).
+struct TV {
+  float* p;
+  int n, c, d, h, w;
+  long long sn, sc, sd, sh, sw;
+};
+
+inline TV tv(const mmtta_tensor* t) {
+  TV v;
+  v.p = (float*)t->ptr;
+  v.n = t->n; v.c = t->c; v.d = t->d; v.h = t->h; v.w = t->w;
+  v.sn = t->sn; v.sc = t->sc; v.sd = t->sd; v.sh = t->sh; v.sw = t->sw;
+  return v;
+}
+
+// Device-side norm-on-load descriptor.
+struct NL {
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+  int relu;
+};
+
+inline NL nl(const mmtta_norm_on_load* t) {
+  NL r;
+  if (t == nullptr) { r.mean = r.rstd = r.gamma = r.beta = nullptr; r.relu = 0; return r; }
+  r.mean = t->mean; r.rstd = t->rstd; r.gamma = t->gamma; r.beta = t->beta; r.relu = t->relu;
+  return r;
+}
+
+// scale/shift of channel c of batch item n for a norm-on-load (identity when mean == nullptr)
+__device__ __forceinline__ void nl_coeff(const NL& t, int n, int C, int c, float& sc, float& sh) {
+  if (t.mean == nullptr) { sc = 1.f; sh = 0.f; return; }
+  float mu = t.mean[n * C + c], rs = t.rstd[n * C + c];
+  float g = t.gamma ? t.gamma[c] : 1.f;
+  float b = t.beta ? t.beta[c] : 0.f;
+  sc = rs * g;
+  sh = b - mu * sc;
+}
+
+__device__ __forceinline__ float nl_apply(float x, float sc, float sh, int relu) {
+  float v = fmaf(x, sc, sh);
+  return relu ? fmaxf(v, 0.f) : v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace mmtta

@@ -1,0 +1,616 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores (gfx950), channels-last activations.
+//
+// One kernel family serves Conv3d forward, its input gradient, ConvTranspose3d forward and its
+// input gradient (reference call sites: src/models/unet.py:68-69 via monai UNet,
+// src/models/unet_multimodal_midfusion.py:204-267; backward from
+// src/core/trainers/seg_trainer.py:142).  All four are the same "gather GEMM":
+//
+//     out[g*so + o][n] = sum_{tap} sum_{k} T(in[g*si + d_tap][k]) * Wp[slab_tap][k][n]
+//
+// g runs over an output sub-grid.  Conv: so=1, si=stride, d = k-pad.  Input gradient of a stride-1
+// conv: d = pad-k.  The stride-2 transposed forms are split into 8 output parity classes (so=2),
+// each a small dense conv over 1..8 taps - no zero-stuffing, no atomics, no wasted MACs.
+//
+// Work decomposition (wave = 64 lanes, 4 waves per workgroup, one workgroup = one spatial box):
+//   * the input box of the tile (tile + halo, KCI channels at a time) is staged ONCE in LDS and
+//     re-used by every tap (27x re-use for k=3) - global reads are ~1.5-2.4x the input instead
+//     of 27x; norm+ReLU of the producer is applied while staging (norm on load), padding voxels
+//     are written as exact zeros;
+//   * each wave owns MB 32-row blocks x one 32-column block: v_mfma_f32_32x32x2_f32 (exact fp32,
+//     one operand element per lane, so the LDS image needs no fragment layout) with the
+//     weight fragment fetched straight from the packed image (L1/L2 resident) one tap ahead;
+//   * LDS voxel stride KCI+1 words: the 32 rows of an A fragment fall on distinct banks;
+//   * epilogue: bias, optional fused residual add, store (128-B segments), per-tile
+//     sum / sum-of-squares for the following InstanceNorm (deterministic partial slab, no atomics);
+//   * small spatial extents (8^3 bottleneck) get split-K over channel blocks through a workspace
+//     so that >= 256 workgroups exist.
+#include "common.h"
+
+namespace mmtta {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Taps {
+  int n;
+  signed char dz[27], dy[27], dx[27];
+  unsigned char slab[27];
+  int zmin, ymin, xmin;
+  int zext, yext, xext;
+};
+
+struct GArgs {
+  const float* in; long long isn, isd, ish, isw; int Ci, Di, Hi, Wi;
+  NL tin;
+  float* out; long long osn, osd, osh, osw; int Co, Do, Ho, Wo;
+  int Dg, Hg, Wg;
+  int so, oz, oy, ox;
+  int si;
+  const float* wp; int Kp, Np;
+  const float* bias;
+  const float* add; long long asn, asd, ash, asw; NL tadd;
+  int accumulate;
+  float* stats; int stats_rows_per_n, stats_row_off;
+  float* ws; int ksplit, stages_per_split, nstages;
+  int tz, ty, tx;
+  int vec4;
+  Taps taps;
+};
+
+template <int TZ, int TY, int TX>
+__device__ __forceinline__ void row_to_local(int v, int& zl, int& yl, int& xl) {
+  xl = v % TX;
+  yl = (v / TX) % TY;
+  zl = v / (TX * TY);
+}
+
+template <int NB, int MB, int TZ, int TY, int TX, int KCI>
+__global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
+  extern __shared__ float lds[];
+  constexpr int VS = KCI + 1;
+  constexpr int MT = TZ * TY * TX;
+  constexpr int MG = 4 / NB;
+  static_assert(MT == 32 * MB * MG, "tile rows must equal 32*MB*(4/NB)");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = wave % NB, mg = wave / NB;
+  const int h = lane >> 5, r = lane & 31;
+
+  int t = blockIdx.x;
+  const int txi = t % a.tx; t /= a.tx;
+  const int tyi = t % a.ty; t /= a.ty;
+  const int tzi = t % a.tz;
+  const int n = t / a.tz;
+  const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;
+  const int BZ = (TZ - 1) * a.si + a.taps.zext + 1;
+  const int BY = (TY - 1) * a.si + a.taps.yext + 1;
+  const int BX = (TX - 1) * a.si + a.taps.xext + 1;
+  const int boxvox = BZ * BY * BX;
+  const int iz0 = gz0 * a.si + a.taps.zmin, iy0 = gy0 * a.si + a.taps.ymin, ix0 = gx0 * a.si + a.taps.xmin;
+
+  const int colbase = (blockIdx.y * NB + cb) * 32;
+  const bool colact = colbase < a.Np;
+
+  int rowvox[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    int zl, yl, xl;
+    row_to_local<TZ, TY, TX>((mg * MB + mb) * 32 + r, zl, yl, xl);
+    rowvox[mb] = ((zl * a.si) * BY + yl * a.si) * BX + xl * a.si;
+  }
+
+  f32x16 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
+
+  const int ks0 = blockIdx.z * a.stages_per_split;
+  const int ks1 = min(a.nstages, ks0 + a.stages_per_split);
+  const float* inb = a.in + (long long)n * a.isn;
+
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int c0 = ks * KCI;
+    // ---------------- stage the input box (KCI channels) into LDS ----------------
+    if (a.vec4) {
+      constexpr int CV = KCI / 4;
+      const int cv = tid % CV;           // 256 % CV == 0: fixed channel group per thread
+      const int c = c0 + cv * 4;
+      float sc[4], sh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c + j < a.Ci) nl_coeff(a.tin, n, a.Ci, c + j, sc[j], sh[j]);
+        else { sc[j] = 0.f; sh[j] = 0.f; }
+      }
+      for (int bv = tid / CV; bv < boxvox; bv += 256 / CV) {
+        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
+                        (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
+        if (ok) {
+          const float4 x = *reinterpret_cast<const float4*>(inb + iz * a.isd + iy * a.ish + ix * a.isw + c);
+          v.x = nl_apply(x.x, sc[0], sh[0], a.tin.relu);
+          v.y = (c + 1 < a.Ci) ? nl_apply(x.y, sc[1], sh[1], a.tin.relu) : 0.f;
+          v.z = (c + 2 < a.Ci) ? nl_apply(x.z, sc[2], sh[2], a.tin.relu) : 0.f;
+          v.w = (c + 3 < a.Ci) ? nl_apply(x.w, sc[3], sh[3], a.tin.relu) : 0.f;
+        }
+        float* d = lds + bv * VS + cv * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    } else {
+      const int cc = tid % KCI;          // 256 % KCI == 0
+      const int c = c0 + cc;
+      float sc = 0.f, sh = 0.f;
+      if (c < a.Ci) nl_coeff(a.tin, n, a.Ci, c, sc, sh);
+      for (int bv = tid / KCI; bv < boxvox; bv += 256 / KCI) {
+        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+        float v = 0.f;
+        if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi &&
+            c < a.Ci)
+          v = nl_apply(inb[iz * a.isd + iy * a.ish + ix * a.isw + c], sc, sh, a.tin.relu);
+        lds[bv * VS + cc] = v;
+      }
+    }
+    __syncthreads();
+
+    // ---------------- MFMA over taps x channel pairs ----------------
+    if (colact) {
+      const int kreal = min(KCI, a.Ci - c0);
+      const int kkn = (kreal + 1) >> 1;          // channel pairs that carry data
+      const float* wcol = a.wp + (long long)c0 * a.Np + colbase + r + (long long)h * a.Np;
+      const long long slabsz = (long long)a.Kp * a.Np;
+      float bcur[KCI / 2], bnxt[KCI / 2];
+      {
+        const float* wb = wcol + a.taps.slab[0] * slabsz;
+#pragma unroll
+        for (int kk = 0; kk < KCI / 2; ++kk) bcur[kk] = (kk < kkn) ? wb[(long long)(2 * kk) * a.Np] : 0.f;
+      }
+      for (int tp = 0; tp < a.taps.n; ++tp) {
+        if (tp + 1 < a.taps.n) {
+          const float* wb = wcol + a.taps.slab[tp + 1] * slabsz;
+#pragma unroll
+          for (int kk = 0; kk < KCI / 2; ++kk) bnxt[kk] = (kk < kkn) ? wb[(long long)(2 * kk) * a.Np] : 0.f;
+        }
+        const int toff = ((a.taps.dz[tp] - a.taps.zmin) * BY + (a.taps.dy[tp] - a.taps.ymin)) * BX +
+                         (a.taps.dx[tp] - a.taps.xmin);
+#pragma unroll
+        for (int kk = 0; kk < KCI / 2; ++kk) {
+          if (kk < kkn) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+              const float av = lds[(rowvox[mb] + toff) * VS + 2 * kk + h];
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bcur[kk], acc[mb], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KCI / 2; ++kk) bcur[kk] = bnxt[kk];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const int col = colbase + r;
+  const bool colok = colact && col < a.Co;
+  float s_sum = 0.f, s_sq = 0.f;
+  if (a.ksplit > 1) {
+    if (colact) {
+      float* wsb = a.ws + ((long long)blockIdx.z * gridDim.x + blockIdx.x) * MT * a.Np + col;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int v = (mg * MB + mb) * 32 + row;
+          wsb[(long long)v * a.Np] = acc[mb][i];
+        }
+    }
+    return;
+  }
+  float bias = 0.f, asc = 1.f, ash = 0.f;
+  if (colok) {
+    if (a.bias) bias = a.bias[col];
+    if (a.add) nl_coeff(a.tadd, n, a.Co, col, asc, ash);
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      int zl, yl, xl;
+      row_to_local<TZ, TY, TX>((mg * MB + mb) * 32 + row, zl, yl, xl);
+      const int gz = gz0 + zl, gy = gy0 + yl, gx = gx0 + xl;
+      if (colok && gz < a.Dg && gy < a.Hg && gx < a.Wg) {
+        const int oz = gz * a.so + a.oz, oy = gy * a.so + a.oy, ox = gx * a.so + a.ox;
+        if (oz < a.Do && oy < a.Ho && ox < a.Wo) {
+          float v = acc[mb][i] + bias;
+          if (a.add)
+            v += nl_apply(a.add[(long long)n * a.asn + oz * a.asd + oy * a.ash + ox * a.asw + col], asc, ash,
+                          a.tadd.relu);
+          float* op = a.out + (long long)n * a.osn + oz * a.osd + oy * a.osh + ox * a.osw + col;
+          if (a.accumulate) v += *op;
+          *op = v;
+          s_sum += v;
+          s_sq += v * v;
+        }
+      }
+    }
+  if (a.stats != nullptr) {
+    // lanes l and l+32 hold the same column; waves of different m-groups too.
+    s_sum += __shfl_xor(s_sum, 32, 64);
+    s_sq += __shfl_xor(s_sq, 32, 64);
+    float* red = lds;  // [4 waves][2][32]; safe: the K loop ended with a barrier
+    if (h == 0) {
+      red[(wave * 2 + 0) * 32 + r] = s_sum;
+      red[(wave * 2 + 1) * 32 + r] = s_sq;
+    }
+    __syncthreads();
+    if (mg == 0 && h == 0 && colok) {
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int g = 0; g < MG; ++g) {
+        ts += red[((g * NB + cb) * 2 + 0) * 32 + r];
+        tq += red[((g * NB + cb) * 2 + 1) * 32 + r];
+      }
+      const int tile_in_n = blockIdx.x % (a.tz * a.ty * a.tx);
+      const long long row = (long long)n * a.stats_rows_per_n + a.stats_row_off + tile_in_n;
+      a.stats[(row * 2 + 0) * a.Co + col] = ts;
+      a.stats[(row * 2 + 1) * a.Co + col] = tq;
+    }
+  }
+}
+
+// Reduce split-K slabs: sum over splits, then the same epilogue as above.
+// grid (tiles, ceil(Np/32)); 256 threads = 8 row groups x 32 columns.
+template <int TZ, int TY, int TX>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles) {
+  __shared__ float red[2][8][32];
+  constexpr int MT = TZ * TY * TX;
+  const int tid = threadIdx.x, r = tid & 31, rg = tid >> 5;
+  int t = blockIdx.x;
+  const int txi = t % a.tx; t /= a.tx;
+  const int tyi = t % a.ty; t /= a.ty;
+  const int tzi = t % a.tz;
+  const int n = t / a.tz;
+  const int col = blockIdx.y * 32 + r;
+  const bool colok = col < a.Co;
+  float bias = 0.f, asc = 1.f, ash = 0.f;
+  if (colok) {
+    if (a.bias) bias = a.bias[col];
+    if (a.add) nl_coeff(a.tadd, n, a.Co, col, asc, ash);
+  }
+  float s_sum = 0.f, s_sq = 0.f;
+  for (int v = rg; v < MT; v += 8) {
+    int zl, yl, xl;
+    row_to_local<TZ, TY, TX>(v, zl, yl, xl);
+    const int gz = tzi * TZ + zl, gy = tyi * TY + yl, gx = txi * TX + xl;
+    if (!(colok && gz < a.Dg && gy < a.Hg && gx < a.Wg)) continue;
+    const int oz = gz * a.so + a.oz, oy = gy * a.so + a.oy, ox = gx * a.so + a.ox;
+    if (!(oz < a.Do && oy < a.Ho && ox < a.Wo)) continue;
+    float sum = 0.f;
+    for (int kz = 0; kz < a.ksplit; ++kz)
+      sum += a.ws[(((long long)kz * tiles + blockIdx.x) * MT + v) * a.Np + col];
+    float val = sum + bias;
+    if (a.add)
+      val += nl_apply(a.add[(long long)n * a.asn + oz * a.asd + oy * a.ash + ox * a.asw + col], asc, ash,
+                      a.tadd.relu);
+    float* op = a.out + (long long)n * a.osn + oz * a.osd + oy * a.osh + ox * a.osw + col;
+    if (a.accumulate) val += *op;
+    *op = val;
+    s_sum += val;
+    s_sq += val * val;
+  }
+  if (a.stats != nullptr) {
+    red[0][rg][r] = s_sum;
+    red[1][rg][r] = s_sq;
+    __syncthreads();
+    if (rg == 0 && colok) {
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) { ts += red[0][g][r]; tq += red[1][g][r]; }
+      const int tile_in_n = blockIdx.x % (a.tz * a.ty * a.tx);
+      const long long row = (long long)n * a.stats_rows_per_n + a.stats_row_off + tile_in_n;
+      a.stats[(row * 2 + 0) * a.Co + col] = ts;
+      a.stats[(row * 2 + 1) * a.Co + col] = tq;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight packing
+// torch layout W[A][B][T] (A = dim0, B = dim1, T = k^3 taps) -> P[T][Kp][Np]
+// kn_is_ba: K = B, N = A (Conv3d forward, ConvTranspose3d input gradient)
+// else    : K = A, N = B (Conv3d input gradient, ConvTranspose3d forward)
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ p, int A, int B, int T,
+                                    int Kp, int Np, int kn_is_ba) {
+  const long long total = (long long)T * Kp * Np;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int nn = (int)(i % Np);
+    const int k = (int)((i / Np) % Kp);
+    const int tp = (int)(i / ((long long)Np * Kp));
+    const int K = kn_is_ba ? B : A, N = kn_is_ba ? A : B;
+    float v = 0.f;
+    if (k < K && nn < N) {
+      const int ai = kn_is_ba ? nn : k, bi = kn_is_ba ? k : nn;
+      v = w[((long long)ai * B + bi) * T + tp];
+    }
+    p[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------- host side
+struct Config { int NB, MB, TZ, TY, TX, KCI; };
+
+static inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+static void op_dims(const mmtta_conv_desc* d, int& K, int& N, int& si, bool& classes) {
+  switch (d->op) {
+    case MMTTA_CONV_FWD: K = d->cin; N = d->cout; si = d->stride; classes = false; break;
+    case MMTTA_CONV_DGRAD: K = d->cout; N = d->cin; si = 1; classes = d->stride == 2; break;
+    case MMTTA_CONVT_FWD: K = d->cin; N = d->cout; si = 1; classes = true; break;
+    default: K = d->cout; N = d->cin; si = 2; classes = false; break;  // CONVT_DGRAD
+  }
+}
+
+static Config pick_config(int Np, int si) {
+  if (si == 1) {
+    if (Np == 32) return {1, 4, 8, 8, 8, 8};
+    if (Np == 64) return {2, 4, 4, 8, 8, 16};
+    return {4, 4, 4, 4, 8, 32};
+  }
+  if (Np == 32) return {1, 1, 4, 4, 8, 8};
+  if (Np == 64) return {2, 2, 4, 4, 8, 8};
+  return {4, 4, 4, 4, 8, 8};
+}
+
+static int validate_desc(const mmtta_conv_desc* d) {
+  MMTTA_CHECK(d != nullptr, MMTTA_ERR_INVALID, "conv: null desc");
+  MMTTA_CHECK(d->op >= 0 && d->op <= 3, MMTTA_ERR_INVALID, "conv: bad op %d", d->op);
+  MMTTA_CHECK(d->ksize == 1 || d->ksize == 3, MMTTA_ERR_UNSUPPORTED, "conv: ksize %d (1 or 3)", d->ksize);
+  MMTTA_CHECK(d->stride == 1 || d->stride == 2, MMTTA_ERR_UNSUPPORTED, "conv: stride %d (1 or 2)", d->stride);
+  MMTTA_CHECK(!(d->ksize == 1 && d->stride != 1), MMTTA_ERR_UNSUPPORTED, "conv: 1x1x1 with stride 2");
+  MMTTA_CHECK(d->cin > 0 && d->cout > 0, MMTTA_ERR_INVALID, "conv: channels must be positive");
+  MMTTA_CHECK(d->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "conv: dtype %d (this build: fp32)", d->dtype);
+  if (d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONVT_DGRAD)
+    MMTTA_CHECK(d->ksize == 3 && d->stride == 2, MMTTA_ERR_UNSUPPORTED,
+                "conv_transpose: only k3 s2 p1 op1 (the monai UNet up layer)");
+  return MMTTA_OK;
+}
+
+struct Geometry {
+  int K, N, Kp, Np, si;
+  bool classes;
+  Config cfg;
+  int tz, ty, tx, tiles_per_n, tiles;
+  int nstages, ksplit, sps;
+  int launches;
+};
+
+static int expected_out_dim(const mmtta_conv_desc* d, int in) {
+  switch (d->op) {
+    case MMTTA_CONV_FWD: return d->stride == 1 ? in : (in + 1) / 2;
+    case MMTTA_CONVT_FWD: return in * 2;
+    case MMTTA_CONVT_DGRAD: return in / 2;
+    default: return -1;  // CONV_DGRAD: caller gives dx shape (in*1 or in*2 or in*2-1)
+  }
+}
+
+static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y, Geometry& g) {
+  int st = validate_desc(d);
+  if (st) return st;
+  MMTTA_CHECK(x && y && x->ptr && y->ptr, MMTTA_ERR_INVALID, "conv: null tensor");
+  MMTTA_CHECK(is_cl(x) && is_cl(y), MMTTA_ERR_UNSUPPORTED, "conv: tensors must be channels-last (sc == 1)");
+  op_dims(d, g.K, g.N, g.si, g.classes);
+  MMTTA_CHECK(x->c == g.K && y->c == g.N, MMTTA_ERR_INVALID, "conv: channel mismatch (x.c=%d want %d, y.c=%d want %d)",
+              x->c, g.K, y->c, g.N);
+  MMTTA_CHECK(x->n == y->n, MMTTA_ERR_INVALID, "conv: batch mismatch");
+  const int xd[3] = {x->d, x->h, x->w}, yd[3] = {y->d, y->h, y->w};
+  for (int i = 0; i < 3; ++i) {
+    int e = expected_out_dim(d, xd[i]);
+    if (e >= 0) {
+      MMTTA_CHECK(yd[i] == e, MMTTA_ERR_INVALID, "conv: spatial mismatch axis %d: in %d -> out %d, expected %d", i, xd[i],
+                  yd[i], e);
+      if (d->op == MMTTA_CONVT_DGRAD)
+        MMTTA_CHECK(xd[i] % 2 == 0, MMTTA_ERR_INVALID, "conv_transpose dgrad: dy extent must be even");
+    } else {
+      // CONV_DGRAD: x = dy (conv output extent), y = dx (conv input extent)
+      int want = d->stride == 1 ? yd[i] : (yd[i] + 1) / 2;
+      MMTTA_CHECK(xd[i] == want, MMTTA_ERR_INVALID, "conv dgrad: dy extent %d does not match dx extent %d", xd[i], yd[i]);
+    }
+  }
+  g.Kp = roundup(g.K, 32);
+  g.Np = roundup(g.N, 32);
+  g.cfg = pick_config(g.Np, g.si);
+  int Dg = y->d, Hg = y->h, Wg = y->w;
+  if (g.classes) { Dg = (y->d + 1) / 2; Hg = (y->h + 1) / 2; Wg = (y->w + 1) / 2; }
+  g.tz = (Dg + g.cfg.TZ - 1) / g.cfg.TZ;
+  g.ty = (Hg + g.cfg.TY - 1) / g.cfg.TY;
+  g.tx = (Wg + g.cfg.TX - 1) / g.cfg.TX;
+  g.tiles_per_n = g.tz * g.ty * g.tx;
+  g.tiles = g.tiles_per_n * x->n;
+  g.nstages = (g.K + g.cfg.KCI - 1) / g.cfg.KCI;
+  g.launches = g.classes ? 8 : 1;
+  const int ncolgroups = (g.Np + 32 * g.cfg.NB - 1) / (32 * g.cfg.NB);
+  const int wgs = g.tiles * ncolgroups;
+  g.ksplit = 1;
+  g.sps = g.nstages;
+  if (wgs < 128 && g.nstages > 1) {
+    int want = (256 + wgs - 1) / wgs;
+    if (want > g.nstages) want = g.nstages;
+    g.sps = (g.nstages + want - 1) / want;
+    g.ksplit = (g.nstages + g.sps - 1) / g.sps;
+  }
+  return MMTTA_OK;
+}
+
+static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t) {
+  // pz/py/px: output parity class for the transposed forms, ignored otherwise
+  int n = 0;
+  const bool classes = (d->op == MMTTA_CONVT_FWD) || (d->op == MMTTA_CONV_DGRAD && d->stride == 2);
+  if (d->ksize == 1) {
+    t.dz[0] = t.dy[0] = t.dx[0] = 0; t.slab[0] = 0; n = 1;
+  } else if (!classes) {
+    const int sgn = (d->op == MMTTA_CONV_DGRAD) ? -1 : 1;   // stride-1 input gradient mirrors the taps
+    for (int kz = 0; kz < 3; ++kz) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+      t.dz[n] = (signed char)(sgn * (kz - 1)); t.dy[n] = (signed char)(sgn * (ky - 1));
+      t.dx[n] = (signed char)(sgn * (kx - 1)); t.slab[n] = (unsigned char)((kz * 3 + ky) * 3 + kx); ++n;
+    }
+  } else {
+    // out index i = 2*o - 1 + k.  parity 0: k=1 reads o=g (d=0); parity 1: k=0 reads g+1, k=2 reads g.
+    int kzs[2], dzs[2], nz, kys[2], dys[2], ny, kxs[2], dxs[2], nx;
+    auto axis = [](int p, int* ks, int* ds) { if (p == 0) { ks[0] = 1; ds[0] = 0; return 1; }
+                                              ks[0] = 0; ds[0] = 1; ks[1] = 2; ds[1] = 0; return 2; };
+    nz = axis(pz, kzs, dzs); ny = axis(py, kys, dys); nx = axis(px, kxs, dxs);
+    for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c) {
+      t.dz[n] = (signed char)dzs[a]; t.dy[n] = (signed char)dys[b]; t.dx[n] = (signed char)dxs[c];
+      t.slab[n] = (unsigned char)((kzs[a] * 3 + kys[b]) * 3 + kxs[c]); ++n;
+    }
+  }
+  t.n = n;
+  int zmn = 9, zmx = -9, ymn = 9, ymx = -9, xmn = 9, xmx = -9;
+  for (int i = 0; i < n; ++i) {
+    zmn = t.dz[i] < zmn ? t.dz[i] : zmn; zmx = t.dz[i] > zmx ? t.dz[i] : zmx;
+    ymn = t.dy[i] < ymn ? t.dy[i] : ymn; ymx = t.dy[i] > ymx ? t.dy[i] : ymx;
+    xmn = t.dx[i] < xmn ? t.dx[i] : xmn; xmx = t.dx[i] > xmx ? t.dx[i] : xmx;
+  }
+  t.zmin = zmn; t.ymin = ymn; t.xmin = xmn;
+  t.zext = zmx - zmn; t.yext = ymx - ymn; t.xext = xmx - xmn;
+}
+
+template <int NB, int MB, int TZ, int TY, int TX, int KCI>
+static int launch_cfg(const GArgs& a, int tiles, hipStream_t s) {
+  const int BZ = (TZ - 1) * a.si + a.taps.zext + 1, BY = (TY - 1) * a.si + a.taps.yext + 1,
+            BX = (TX - 1) * a.si + a.taps.xext + 1;
+  size_t lds = (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
+  if (lds < 4 * 2 * 32 * sizeof(float)) lds = 4 * 2 * 32 * sizeof(float);
+  MMTTA_CHECK(lds <= 160 * 1024, MMTTA_ERR_UNSUPPORTED, "conv: LDS box of %zu bytes exceeds 160 KiB", lds);
+  auto kern = igemm_f32_kernel<NB, MB, TZ, TY, TX, KCI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(tiles, (a.Np + 32 * NB - 1) / (32 * NB), a.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  int st = launch_status("conv igemm");
+  if (st) return st;
+  if (a.ksplit > 1) {
+    dim3 g2(tiles, (a.Np + 31) / 32);
+    hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX>), g2, dim3(256), 0, s, a, tiles);
+    st = launch_status("conv split-K finalize");
+  }
+  return st;
+}
+
+static int launch_any(const Config& c, const GArgs& a, int tiles, hipStream_t s) {
+  if (a.si == 1) {
+    if (c.NB == 1) return launch_cfg<1, 4, 8, 8, 8, 8>(a, tiles, s);
+    if (c.NB == 2) return launch_cfg<2, 4, 4, 8, 8, 16>(a, tiles, s);
+    return launch_cfg<4, 4, 4, 4, 8, 32>(a, tiles, s);
+  }
+  if (c.NB == 1) return launch_cfg<1, 1, 4, 4, 8, 8>(a, tiles, s);
+  if (c.NB == 2) return launch_cfg<2, 2, 4, 4, 8, 8>(a, tiles, s);
+  return launch_cfg<4, 4, 4, 4, 8, 8>(a, tiles, s);
+}
+
+}  // namespace mmtta
+
+using namespace mmtta;
+
+extern "C" int64_t mmtta_conv_packed_bytes(const mmtta_conv_desc* d) {
+  if (validate_desc(d)) return -1;
+  int K, N, si; bool cl;
+  op_dims(d, K, N, si, cl);
+  const int T = d->ksize * d->ksize * d->ksize;
+  return (int64_t)T * roundup(K, 32) * roundup(N, 32) * (int64_t)sizeof(float);
+}
+
+extern "C" int mmtta_conv_pack_weights(const mmtta_conv_desc* d, const float* w, void* packed, void* stream) {
+  int st = validate_desc(d);
+  if (st) return st;
+  MMTTA_CHECK(w && packed, MMTTA_ERR_INVALID, "pack: null pointer");
+  int K, N, si; bool cl;
+  op_dims(d, K, N, si, cl);
+  const int T = d->ksize * d->ksize * d->ksize;
+  const bool convt = d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONVT_DGRAD;
+  const int A = convt ? d->cin : d->cout, B = convt ? d->cout : d->cin;
+  // K,N in terms of (A,B): CONV_FWD K=cin=B ; CONV_DGRAD K=cout=A ; CONVT_FWD K=cin=A ; CONVT_DGRAD K=cout=B
+  const int kn_is_ba = (d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_DGRAD) ? 1 : 0;
+  const int Kp = roundup(K, 32), Np = roundup(N, 32);
+  const long long total = (long long)T * Kp * Np;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, A, B, T,
+                     Kp, Np, kn_is_ba);
+  return launch_status("pack weights");
+}
+
+extern "C" int mmtta_conv_plan(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y,
+                               mmtta_conv_plan_t* plan) {
+  MMTTA_CHECK(plan != nullptr, MMTTA_ERR_INVALID, "conv plan: null plan");
+  Geometry g;
+  int st = geometry(d, x, y, g);
+  if (st) return st;
+  plan->tiles = g.tiles;
+  plan->launches = g.launches;
+  plan->ksplit = g.ksplit;
+  plan->stats_rows = g.launches * g.tiles;
+  plan->workspace_bytes =
+      g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * (int64_t)sizeof(float) : 0;
+  return MMTTA_OK;
+}
+
+extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                              const void* packed, const float* bias, const mmtta_conv_epilogue* epi,
+                              const mmtta_tensor* y, int accumulate, float* stats, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+  Geometry g;
+  int st = geometry(d, x, y, g);
+  if (st) return st;
+  MMTTA_CHECK(packed != nullptr, MMTTA_ERR_INVALID, "conv: null packed weights");
+  const int64_t need = g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * 4 : 0;
+  MMTTA_CHECK(need == 0 || (workspace != nullptr && workspace_bytes >= need), MMTTA_ERR_WORKSPACE,
+              "conv: workspace %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
+  GArgs a;
+  a.in = (const float*)x->ptr; a.isn = x->sn; a.isd = x->sd; a.ish = x->sh; a.isw = x->sw;
+  a.Ci = x->c; a.Di = x->d; a.Hi = x->h; a.Wi = x->w;
+  a.tin = nl(x_norm);
+  a.out = (float*)y->ptr; a.osn = y->sn; a.osd = y->sd; a.osh = y->sh; a.osw = y->sw;
+  a.Co = y->c; a.Do = y->d; a.Ho = y->h; a.Wo = y->w;
+  a.si = g.si;
+  a.wp = (const float*)packed; a.Kp = g.Kp; a.Np = g.Np;
+  a.bias = bias;
+  a.add = nullptr; a.asn = a.asd = a.ash = a.asw = 0; a.tadd = nl(nullptr);
+  if (epi && epi->add) {
+    const mmtta_tensor* ad = epi->add;
+    MMTTA_CHECK(ad->ptr && is_cl(ad) && ad->n == y->n && ad->c == y->c && ad->d == y->d && ad->h == y->h && ad->w == y->w,
+                MMTTA_ERR_INVALID, "conv: epilogue `add` must be channels-last with the shape of y");
+    a.add = (const float*)ad->ptr; a.asn = ad->sn; a.asd = ad->sd; a.ash = ad->sh; a.asw = ad->sw;
+    a.tadd = nl(&epi->add_norm);
+  }
+  a.accumulate = accumulate;
+  a.stats = stats; a.stats_rows_per_n = g.launches * g.tiles_per_n;
+  a.ws = (float*)workspace; a.ksplit = g.ksplit; a.stages_per_split = g.sps; a.nstages = g.nstages;
+  a.tz = g.tz; a.ty = g.ty; a.tx = g.tx;
+  const bool al = (((uintptr_t)x->ptr) % 16 == 0) && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0;
+  a.vec4 = al ? 1 : 0;
+  if (!g.classes) {
+    build_taps(d, 0, 0, 0, a.taps);
+    a.so = 1; a.oz = a.oy = a.ox = 0;
+    a.Dg = y->d; a.Hg = y->h; a.Wg = y->w;
+    a.stats_row_off = 0;
+    return launch_any(g.cfg, a, g.tiles, (hipStream_t)stream);
+  }
+  for (int cls = 0; cls < 8; ++cls) {
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    build_taps(d, pz, py, px, a.taps);
+    a.so = 2; a.oz = pz; a.oy = py; a.ox = px;
+    a.Dg = (y->d - pz + 1) / 2; a.Hg = (y->h - py + 1) / 2; a.Wg = (y->w - px + 1) / 2;
+    a.stats_row_off = cls * g.tiles_per_n;
+    st = launch_any(g.cfg, a, g.tiles, (hipStream_t)stream);
+    if (st) return st;
+  }
+  return MMTTA_OK;
+}

@@ -1,0 +1,243 @@
+// Entropy objective (+gradient), fused Adam over the flat parameter arena, and the
+// sigmoid -> threshold -> Dice counting tail (gfx950).  All three are single-pass HBM-bound
+// kernels; see include/mmtta.h for the reference lines each one stands in for.
+#include "common.h"
+
+namespace mmtta {
+
+// ------------------------------------------------------------------ entropy loss
+constexpr int ENT_MAX_BLOCKS = 2048;
+constexpr int ENT_MAX_R = 16;
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;  // valid on thread 0
+}
+
+__global__ __launch_bounds__(256) void entropy_bernoulli_kernel(TV z, TV dz, double* partial, float inv_count) {
+  __shared__ double sh[4];
+  const int C = z.c;
+  const long long total = (long long)z.n * z.d * z.h * z.w * C;
+  double acc = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long v = i / C;
+    const int x = (int)(v % z.w); v /= z.w;
+    const int y = (int)(v % z.h); v /= z.h;
+    const int zz = (int)(v % z.d);
+    const int n = (int)(v / z.d);
+    const float t = z.p[n * z.sn + zz * z.sd + y * z.sh + x * z.sw + c];
+    const float e = expf(-fabsf(t));
+    const float sig = t >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    const float softplus = fmaxf(t, 0.f) + log1pf(e);
+    acc += (double)(softplus - t * sig);
+    dz.p[n * dz.sn + zz * dz.sd + y * dz.sh + x * dz.sw + c] = -t * sig * (1.f - sig) * inv_count;
+  }
+  const double t = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void entropy_categorical_kernel(TV z, TV dz, double* partial, float inv_count) {
+  __shared__ double sh[4];
+  const int R = z.c;
+  const long long total = (long long)z.n * z.d * z.h * z.w;
+  double acc = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long v = i;
+    const int x = (int)(v % z.w); v /= z.w;
+    const int y = (int)(v % z.h); v /= z.h;
+    const int zz = (int)(v % z.d);
+    const int n = (int)(v / z.d);
+    const float* zp = z.p + n * z.sn + zz * z.sd + y * z.sh + x * z.sw;
+    float* gp = dz.p + n * dz.sn + zz * dz.sd + y * dz.sh + x * dz.sw;
+    float t[ENT_MAX_R];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < ENT_MAX_R; ++r)
+      if (r < R) { t[r] = zp[r]; m = fmaxf(m, t[r]); }
+    float se = 0.f;
+#pragma unroll
+    for (int r = 0; r < ENT_MAX_R; ++r)
+      if (r < R) se += expf(t[r] - m);
+    const float lse = m + logf(se);
+    float pz = 0.f;
+#pragma unroll
+    for (int r = 0; r < ENT_MAX_R; ++r)
+      if (r < R) pz += expf(t[r] - lse) * t[r];
+    const float H = lse - pz;
+    acc += (double)H;
+#pragma unroll
+    for (int r = 0; r < ENT_MAX_R; ++r)
+      if (r < R) {
+        const float logp = t[r] - lse;
+        gp[r] = -expf(logp) * (logp + H) * inv_count;
+      }
+  }
+  const double t = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(64) void entropy_finish_kernel(const double* partial, int nblocks, double inv_count,
+                                                            float* loss) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) s += partial[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) *loss = (float)(s * inv_count);
+}
+
+static int entropy_blocks(const mmtta_tensor* z) {
+  const long long total = (long long)z->n * z->d * z->h * z->w * z->c;
+  long long b = (total + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > ENT_MAX_BLOCKS) b = ENT_MAX_BLOCKS;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   long long n_decay, float lr, float beta1, float beta2, float eps,
+                                                   float wd, const int* __restrict__ step) {
+  __shared__ float s_step_size, s_bc2_sqrt;
+  if (threadIdx.x == 0) {
+    const double t = (double)(*step + 1);
+    const double bc1 = 1.0 - pow((double)beta1, t);
+    const double bc2 = 1.0 - pow((double)beta2, t);
+    s_step_size = (float)((double)lr / bc1);
+    s_bc2_sqrt = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
+  const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    float gi = g[i];
+    if (i < n_decay && wd != 0.f) gi = gi + wd * pi;
+    float mi = m[i], vi = v[i];
+    mi = mi + w1 * (gi - mi);
+    vi = vi * beta2 + (w2 * gi) * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+__global__ void step_inc_kernel(int* step) { *step += 1; }
+
+// ------------------------------------------------------------------ mask + Dice counts
+__global__ __launch_bounds__(256) void dice_counts_kernel(TV z, TV lab, float thr, unsigned long long* counts,
+                                                          unsigned char* mask, int blocks_per_n) {
+  __shared__ unsigned int sh[3][256];
+  const int R = z.c;
+  int rp = 1;
+  while (rp < R) rp <<= 1;        // R <= 256 enforced by the host
+  const int nvl = 256 / rp;
+  const int r = threadIdx.x % rp, vl = threadIdx.x / rp;
+  const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
+  const long long dhw = (long long)z.d * z.h * z.w;
+  unsigned int ci = 0, cp = 0, cg = 0;
+  if (r < R) {
+    for (long long v = (long long)bn * nvl + vl; v < dhw; v += (long long)blocks_per_n * nvl) {
+      long long t = v;
+      const int x = (int)(t % z.w); t /= z.w;
+      const int y = (int)(t % z.h);
+      const int zz = (int)(t / z.h);
+      const float lg = z.p[n * z.sn + zz * z.sd + y * z.sh + x * z.sw + r];
+      const float prob = 1.f / (1.f + expf(-lg));
+      const unsigned int pb = prob >= thr ? 1u : 0u;
+      const float lv = lab.p[n * lab.sn + (long long)r * lab.sc + zz * lab.sd + y * lab.sh + x * lab.sw];
+      const unsigned int gb = lv > 0.5f ? 1u : 0u;
+      ci += pb & gb; cp += pb; cg += gb;
+      if (mask) mask[((long long)n * R + r) * dhw + v] = (unsigned char)pb;
+    }
+  }
+  sh[0][threadIdx.x] = ci; sh[1][threadIdx.x] = cp; sh[2][threadIdx.x] = cg;
+  __syncthreads();
+  if (vl == 0 && r < R) {
+    unsigned long long ti = 0, tp = 0, tg = 0;
+    for (int j = 0; j < nvl; ++j) { ti += sh[0][j * rp + r]; tp += sh[1][j * rp + r]; tg += sh[2][j * rp + r]; }
+    unsigned long long* c = counts + ((long long)n * R + r) * 3;
+    atomicAdd(c + 0, ti); atomicAdd(c + 1, tp); atomicAdd(c + 2, tg);
+  }
+}
+
+}  // namespace mmtta
+
+using namespace mmtta;
+
+extern "C" int64_t mmtta_entropy_partials(const mmtta_tensor* logits) {
+  if (logits == nullptr) return -1;
+  return entropy_blocks(logits);
+}
+
+extern "C" int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits, double* partial,
+                                  float* loss, void* stream) {
+  MMTTA_CHECK(logits && dlogits && partial && loss && logits->ptr && dlogits->ptr, MMTTA_ERR_INVALID, "entropy: null argument");
+  MMTTA_CHECK(logits->n == dlogits->n && logits->c == dlogits->c && logits->d == dlogits->d && logits->h == dlogits->h &&
+                  logits->w == dlogits->w, MMTTA_ERR_INVALID, "entropy: shape mismatch");
+  MMTTA_CHECK(is_cl(logits) && is_cl(dlogits), MMTTA_ERR_UNSUPPORTED, "entropy: channels-last only");
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = entropy_blocks(logits);
+  const long long nvox = (long long)logits->n * logits->d * logits->h * logits->w;
+  if (!softmax) {
+    const double cnt = (double)nvox * logits->c;
+    hipLaunchKernelGGL(entropy_bernoulli_kernel, dim3(blocks), dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt));
+    int st = launch_status("entropy bernoulli");
+    if (st) return st;
+    hipLaunchKernelGGL(entropy_finish_kernel, dim3(1), dim3(64), 0, s, partial, blocks, 1.0 / cnt, loss);
+  } else {
+    MMTTA_CHECK(logits->c <= ENT_MAX_R, MMTTA_ERR_UNSUPPORTED, "entropy softmax: more than %d classes", ENT_MAX_R);
+    const double cnt = (double)nvox;
+    hipLaunchKernelGGL(entropy_categorical_kernel, dim3(blocks), dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt));
+    int st = launch_status("entropy categorical");
+    if (st) return st;
+    hipLaunchKernelGGL(entropy_finish_kernel, dim3(1), dim3(64), 0, s, partial, blocks, 1.0 / cnt, loss);
+  }
+  return launch_status("entropy finish");
+}
+
+extern "C" int mmtta_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int32_t* step, void* stream) {
+  MMTTA_CHECK(p && g && m && v && step && n >= 0 && n_decay >= 0 && n_decay <= n, MMTTA_ERR_INVALID, "adam: bad argument");
+  if (n == 0) return MMTTA_OK;
+  hipStream_t s = (hipStream_t)stream;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, (long long)n, (long long)n_decay, lr, beta1,
+                     beta2, eps, weight_decay, step);
+  int st = launch_status("adam");
+  if (st) return st;
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
+  return launch_status("adam step counter");
+}
+
+extern "C" int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label, float threshold, int64_t* counts,
+                                      uint8_t* mask, void* stream) {
+  MMTTA_CHECK(logits && label && counts && logits->ptr && label->ptr, MMTTA_ERR_INVALID, "dice: null argument");
+  MMTTA_CHECK(logits->n == label->n && logits->c == label->c && logits->d == label->d && logits->h == label->h &&
+                  logits->w == label->w, MMTTA_ERR_INVALID, "dice: logits/label shape mismatch");
+  MMTTA_CHECK(is_cl(logits), MMTTA_ERR_UNSUPPORTED, "dice: logits must be channels-last");
+  MMTTA_CHECK(logits->c <= 256, MMTTA_ERR_UNSUPPORTED, "dice: more than 256 regions");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)logits->n * logits->c * 3 * sizeof(int64_t), s);
+  MMTTA_CHECK(e == hipSuccess, MMTTA_ERR_LAUNCH, "dice: memset failed: %s", hipGetErrorString(e));
+  const long long dhw = (long long)logits->d * logits->h * logits->w;
+  int rp = 1;
+  while (rp < logits->c) rp <<= 1;
+  const int nvl = 256 / rp;
+  long long bpn = (dhw + (long long)nvl * 16 - 1) / ((long long)nvl * 16);
+  if (bpn < 1) bpn = 1;
+  if (bpn > 1024) bpn = 1024;
+  hipLaunchKernelGGL(dice_counts_kernel, dim3((unsigned)(bpn * logits->n)), dim3(256), 0, s, tv(logits), tv(label), threshold,
+                     (unsigned long long*)counts, mask, (int)bpn);
+  return launch_status("dice counts");
+}

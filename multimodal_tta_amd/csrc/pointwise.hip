@@ -1,0 +1,572 @@
+// HBM-bound kernels of the adaptation path (gfx950): layout copies, norm statistics and the
+// norm(+ReLU) backward, the residual "combine", trilinear x2 and its adjoint, linear
+// combinations (modality means).  All tensors are channels-last unless noted; channel is the
+// fastest thread index so a wave touches 256 contiguous bytes (4 B/lane) or 1 KiB (16 B/lane,
+// the float4 paths) per instruction.  Reductions are two-stage and deterministic: partial slabs
+// [rows][2][C] in fp32, combined in fp64 - no float atomics anywhere.
+#include "common.h"
+
+namespace mmtta {
+
+__device__ __forceinline__ void vox_decompose(const TV& t, long long v, int& n, int& z, int& y, int& x) {
+  x = (int)(v % t.w); v /= t.w;
+  y = (int)(v % t.h); v /= t.h;
+  z = (int)(v % t.d);
+  n = (int)(v / t.d);
+}
+__device__ __forceinline__ long long vox_addr(const TV& t, int n, int z, int y, int x) {
+  return (long long)n * t.sn + (long long)z * t.sd + (long long)y * t.sh + (long long)x * t.sw;
+}
+
+// ------------------------------------------------------------------ strided copy
+__global__ void copy_strided_kernel(TV s, TV d) {
+  const long long total = (long long)d.n * d.c * d.d * d.h * d.w;
+  // iterate in the destination's fastest order: if dst is channels-last, c fastest; else x fastest
+  const bool cl = d.sc == 1;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int n, c, z, y, x;
+    long long t = i;
+    if (cl) {
+      c = (int)(t % d.c); t /= d.c;
+      x = (int)(t % d.w); t /= d.w;
+      y = (int)(t % d.h); t /= d.h;
+      z = (int)(t % d.d); n = (int)(t / d.d);
+    } else {
+      x = (int)(t % d.w); t /= d.w;
+      y = (int)(t % d.h); t /= d.h;
+      z = (int)(t % d.d); t /= d.d;
+      c = (int)(t % d.c); n = (int)(t / d.c);
+    }
+    d.p[vox_addr(d, n, z, y, x) + (long long)c * d.sc] = s.p[vox_addr(s, n, z, y, x) + (long long)c * s.sc];
+  }
+}
+
+// ------------------------------------------------------------------ two-stage channel reductions
+// Block layout: cpl channel lanes (power of two >= min(C,256)) x (256/cpl) voxel lanes.
+// MODE 0: (sum x, sum x^2).  MODE 1: norm backward (sum dz, sum dz*xhat).
+struct RedArgs {
+  TV x;        // MODE 0: tensor ; MODE 1: y (pre-norm)
+  TV dout;     // MODE 1
+  NL t;        // MODE 1
+  float* part; // [N*rows_per_n][2][C]
+  int rows_per_n;
+  long long vox_per_row;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void channel_reduce_kernel(RedArgs a) {
+  __shared__ float red[2][256];
+  const int C = a.x.c;
+  int cpl = 1;
+  while (cpl < C && cpl < 256) cpl <<= 1;
+  const int nvl = 256 / cpl;
+  const int cl = threadIdx.x % cpl, vl = threadIdx.x / cpl;
+  const int n = blockIdx.x / a.rows_per_n, row = blockIdx.x % a.rows_per_n;
+  const long long dhw = (long long)a.x.d * a.x.h * a.x.w;
+  const long long v0 = row * a.vox_per_row;
+  const long long v1 = (v0 + a.vox_per_row < dhw) ? v0 + a.vox_per_row : dhw;
+  for (int cb = 0; cb < C; cb += cpl) {
+    const int c = cb + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+      float mu = 0.f, rs = 1.f, g = 1.f, b = 0.f;
+      if (MODE == 1 && a.t.mean) {
+        mu = a.t.mean[n * C + c]; rs = a.t.rstd[n * C + c];
+        if (a.t.gamma) g = a.t.gamma[c];
+        if (a.t.beta) b = a.t.beta[c];
+      }
+      for (long long v = v0 + vl; v < v1; v += nvl) {
+        long long t = v;
+        const int xx = (int)(t % a.x.w); t /= a.x.w;
+        const int yy = (int)(t % a.x.h);
+        const int zz = (int)(t / a.x.h);
+        const float xv = a.x.p[vox_addr(a.x, n, zz, yy, xx) + c];
+        if (MODE == 0) {
+          s0 += xv;
+          s1 += xv * xv;
+        } else {
+          const float xhat = (xv - mu) * rs;
+          float dz = a.dout.p[vox_addr(a.dout, n, zz, yy, xx) + c];
+          if (a.t.relu && !(fmaf(g, xhat, b) > 0.f)) dz = 0.f;
+          s0 += dz;
+          s1 += dz * xhat;
+        }
+      }
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (vl == 0 && c < C) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int j = 0; j < nvl; ++j) { t0 += red[0][j * cpl + cl]; t1 += red[1][j * cpl + cl]; }
+      a.part[((long long)blockIdx.x * 2 + 0) * C + c] = t0;
+      a.part[((long long)blockIdx.x * 2 + 1) * C + c] = t1;
+    }
+    __syncthreads();
+  }
+}
+
+// stage 2a: one wave per (n,c): fp64 sum over the partial rows -> tot[n*C+c][2]
+__global__ __launch_bounds__(64) void rows_reduce_kernel(const float* part, int rows_per_n, int C, double* tot) {
+  const int n = blockIdx.x / C, c = blockIdx.x % C;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = threadIdx.x; r < rows_per_n; r += 64) {
+    const long long row = (long long)n * rows_per_n + r;
+    s0 += (double)part[(row * 2 + 0) * C + c];
+    s1 += (double)part[(row * 2 + 1) * C + c];
+  }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  if (threadIdx.x == 0) {
+    tot[((long long)n * C + c) * 2 + 0] = s0;
+    tot[((long long)n * C + c) * 2 + 1] = s1;
+  }
+}
+
+struct StatFinArgs {
+  int kind, groups, N, C;
+  double count;
+  float eps;
+  int training;
+  float* running_mean; float* running_var; float momentum;
+  float* mean; float* rstd;
+  const double* tot;
+};
+
+__global__ void stats_finalize_kernel(StatFinArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.N * a.C) return;
+  const int n = i / a.C, c = i % a.C;
+  double S = 0.0, Q = 0.0, cnt = 0.0;
+  if (a.kind == MMTTA_NORM_INSTANCE) {
+    S = a.tot[(long long)i * 2]; Q = a.tot[(long long)i * 2 + 1]; cnt = a.count;
+  } else if (a.kind == MMTTA_NORM_BATCH) {
+    if (!a.training) {
+      a.mean[i] = a.running_mean[c];
+      a.rstd[i] = (float)(1.0 / sqrt((double)a.running_var[c] + (double)a.eps));
+      return;
+    }
+    for (int m = 0; m < a.N; ++m) { S += a.tot[((long long)m * a.C + c) * 2]; Q += a.tot[((long long)m * a.C + c) * 2 + 1]; }
+    cnt = a.count * a.N;
+  } else {
+    const int cg = a.C / a.groups, g0 = (c / cg) * cg;
+    for (int k = g0; k < g0 + cg; ++k) { S += a.tot[((long long)n * a.C + k) * 2]; Q += a.tot[((long long)n * a.C + k) * 2 + 1]; }
+    cnt = a.count * cg;
+  }
+  const double mu = S / cnt;
+  double var = Q / cnt - mu * mu;
+  if (var < 0.0) var = 0.0;
+  a.mean[i] = (float)mu;
+  a.rstd[i] = (float)(1.0 / sqrt(var + (double)a.eps));
+  if (a.kind == MMTTA_NORM_BATCH && a.training && n == 0 && a.running_mean != nullptr) {
+    const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+    a.running_mean[c] = (float)((1.0 - a.momentum) * a.running_mean[c] + a.momentum * mu);
+    a.running_var[c] = (float)((1.0 - a.momentum) * a.running_var[c] + a.momentum * unb);
+  }
+}
+
+struct BwdFinArgs {
+  int kind, groups, N, C;
+  double count;
+  const float* gamma;
+  int training;
+  float* m1; float* m2; float* dgamma; float* dbeta; int accumulate;
+  const double* tot;
+};
+
+__global__ void bwd_finalize_kernel(BwdFinArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.N * a.C) return;
+  const int n = i / a.C, c = i % a.C;
+  double A = 0.0, B = 0.0, cnt = 1.0;
+  if (a.kind == MMTTA_NORM_INSTANCE) {
+    const double g = a.gamma ? (double)a.gamma[c] : 1.0;
+    A = g * a.tot[(long long)i * 2]; B = g * a.tot[(long long)i * 2 + 1]; cnt = a.count;
+  } else if (a.kind == MMTTA_NORM_BATCH) {
+    const double g = a.gamma ? (double)a.gamma[c] : 1.0;
+    for (int m = 0; m < a.N; ++m) { A += g * a.tot[((long long)m * a.C + c) * 2]; B += g * a.tot[((long long)m * a.C + c) * 2 + 1]; }
+    cnt = a.count * a.N;
+  } else {
+    const int cg = a.C / a.groups, g0 = (c / cg) * cg;
+    for (int k = g0; k < g0 + cg; ++k) {
+      const double g = a.gamma ? (double)a.gamma[k] : 1.0;
+      A += g * a.tot[((long long)n * a.C + k) * 2]; B += g * a.tot[((long long)n * a.C + k) * 2 + 1];
+    }
+    cnt = a.count * cg;
+  }
+  const bool frozen = (a.kind == MMTTA_NORM_BATCH && !a.training);
+  a.m1[i] = frozen ? 0.f : (float)(A / cnt);
+  a.m2[i] = frozen ? 0.f : (float)(B / cnt);
+  if (n == 0 && a.dgamma != nullptr) {
+    double dg = 0.0, db = 0.0;
+    for (int m = 0; m < a.N; ++m) { db += a.tot[((long long)m * a.C + c) * 2]; dg += a.tot[((long long)m * a.C + c) * 2 + 1]; }
+    a.dgamma[c] = a.accumulate ? a.dgamma[c] + (float)dg : (float)dg;
+    if (a.dbeta) a.dbeta[c] = a.accumulate ? a.dbeta[c] + (float)db : (float)db;
+  }
+}
+
+// ------------------------------------------------------------------ elementwise (channel fastest)
+struct EwArgs {
+  TV a, b, o;
+  NL ta, tb;
+  const float* m1; const float* m2;
+  int hasb;
+};
+
+// MODE 0: combine  out = Ta(a) + Tb(b)
+// MODE 1: norm bwd apply: a = dout, b = y, T = ta(on y)   out = rstd*(g*dz - m1 - xhat*m2)
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void elementwise_kernel(EwArgs e) {
+  const int C = e.o.c;
+  const int CV = (C + VEC - 1) / VEC;
+  const long long nvox = (long long)e.o.n * e.o.d * e.o.h * e.o.w;
+  const long long total = nvox * CV;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % CV) * VEC;
+    const long long v = i / CV;
+    int n, z, y, x;
+    vox_decompose(e.o, v, n, z, y, x);
+    float av[VEC], bv[VEC], ov[VEC];
+    const float* ap = e.a.p + vox_addr(e.a, n, z, y, x) + c0;
+    const float* bp = e.hasb ? e.b.p + vox_addr(e.b, n, z, y, x) + c0 : nullptr;
+    if (VEC == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(ap);
+      av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+      if (bp) { const float4 u = *reinterpret_cast<const float4*>(bp); bv[0] = u.x; bv[1] = u.y; bv[2] = u.z; bv[3] = u.w; }
+    } else {
+      av[0] = ap[0];
+      if (bp) bv[0] = bp[0];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      if (MODE == 0) {
+        float sa, ha;
+        nl_coeff(e.ta, n, C, c, sa, ha);
+        float r = nl_apply(av[j], sa, ha, e.ta.relu);
+        if (bp) {
+          float sb, hb;
+          nl_coeff(e.tb, n, C, c, sb, hb);
+          r += nl_apply(bv[j], sb, hb, e.tb.relu);
+        }
+        ov[j] = r;
+      } else {
+        const float mu = e.ta.mean[n * C + c], rs = e.ta.rstd[n * C + c];
+        const float g = e.ta.gamma ? e.ta.gamma[c] : 1.f;
+        const float bt = e.ta.beta ? e.ta.beta[c] : 0.f;
+        const float xhat = (bv[j] - mu) * rs;
+        float dz = av[j];
+        if (e.ta.relu && !(fmaf(g, xhat, bt) > 0.f)) dz = 0.f;
+        ov[j] = rs * (g * dz - e.m1[n * C + c] - xhat * e.m2[n * C + c]);
+      }
+    }
+    float* op = e.o.p + vox_addr(e.o, n, z, y, x) + c0;
+    if (VEC == 4) *reinterpret_cast<float4*>(op) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    else op[0] = ov[0];
+  }
+}
+
+// ------------------------------------------------------------------ linear combination
+struct LinArgs {
+  TV in[8];
+  float w[8];
+  int count;
+  TV o;
+  int accumulate;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void lincomb_kernel(LinArgs e) {
+  const int C = e.o.c;
+  const int CV = (C + VEC - 1) / VEC;
+  const long long nvox = (long long)e.o.n * e.o.d * e.o.h * e.o.w;
+  const long long total = nvox * CV;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % CV) * VEC;
+    const long long v = i / CV;
+    int n, z, y, x;
+    vox_decompose(e.o, v, n, z, y, x);
+    float acc[VEC];
+    float* op = e.o.p + vox_addr(e.o, n, z, y, x) + c0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    if (e.accumulate) {
+      if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(op); acc[0] = t.x; acc[1] = t.y; acc[2] = t.z; acc[3] = t.w; }
+      else acc[0] = op[0];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < e.count) {
+        const float* ip = e.in[k].p + vox_addr(e.in[k], n, z, y, x) + c0;
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(ip);
+          acc[0] = fmaf(e.w[k], t.x, acc[0]); acc[1] = fmaf(e.w[k], t.y, acc[1]);
+          acc[2] = fmaf(e.w[k], t.z, acc[2]); acc[3] = fmaf(e.w[k], t.w, acc[3]);
+        } else {
+          acc[0] = fmaf(e.w[k], ip[0], acc[0]);
+        }
+      }
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else op[0] = acc[0];
+  }
+}
+
+// ------------------------------------------------------------------ trilinear x2 (align_corners=True)
+__device__ __forceinline__ void src_index(int dst, int in, int out, int& i0, int& i1, float& lam) {
+  // torch: scale = (in-1)/(out-1) (0 when out == 1); src = scale*dst; i0 = floor; i1 = min(i0+1, in-1)
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)dst;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  lam = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(TV x, TV y) {
+  const int C = y.c;
+  const long long total = (long long)y.n * y.d * y.h * y.w * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int n, oz, oy, ox;
+    vox_decompose(y, i / C, n, oz, oy, ox);
+    int z0, z1, y0, y1, x0, x1;
+    float lz, ly, lx;
+    src_index(oz, x.d, y.d, z0, z1, lz);
+    src_index(oy, x.h, y.h, y0, y1, ly);
+    src_index(ox, x.w, y.w, x0, x1, lx);
+    const float* xp = x.p + (long long)n * x.sn + c;
+    auto at = [&](int zz, int yy, int xx) { return xp[(long long)zz * x.sd + (long long)yy * x.sh + (long long)xx * x.sw]; };
+    const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
+    const float v = wz0 * (wy0 * (wx0 * at(z0, y0, x0) + lx * at(z0, y0, x1)) + ly * (wx0 * at(z0, y1, x0) + lx * at(z0, y1, x1))) +
+                    lz * (wy0 * (wx0 * at(z1, y0, x0) + lx * at(z1, y0, x1)) + ly * (wx0 * at(z1, y1, x0) + lx * at(z1, y1, x1)));
+    y.p[vox_addr(y, n, oz, oy, ox) + c] = v;
+  }
+}
+
+// adjoint as a gather: for input index i the outputs that touch it lie in [2i-2, 2i+2]
+__device__ __forceinline__ int axis_weights(int i, int in, int out, int* os, float* ws) {
+  int cnt = 0;
+  int lo = 2 * i - 2, hi = 2 * i + 2;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+  for (int o = lo; o <= hi; ++o) {
+    int i0, i1;
+    float lam;
+    src_index(o, in, out, i0, i1, lam);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - lam;
+    if (i1 == i) w += lam;   // i0 == i1 == i at the last sample: (1-lam) + lam = 1
+    if (i0 == i1 && i0 == i) w = 1.f;
+    if (w != 0.f) { os[cnt] = o; ws[cnt] = w; ++cnt; }
+  }
+  return cnt;
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(TV dy, TV dx, int accumulate) {
+  const int C = dx.c;
+  const long long total = (long long)dx.n * dx.d * dx.h * dx.w * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int n, iz, iy, ix;
+    vox_decompose(dx, i / C, n, iz, iy, ix);
+    int oz[5], oy[5], ox[5];
+    float wz[5], wy[5], wx[5];
+    const int nz = axis_weights(iz, dx.d, dy.d, oz, wz);
+    const int ny = axis_weights(iy, dx.h, dy.h, oy, wy);
+    const int nx = axis_weights(ix, dx.w, dy.w, ox, wx);
+    const float* gp = dy.p + (long long)n * dy.sn + c;
+    float s = 0.f;
+    for (int a = 0; a < nz; ++a)
+      for (int b = 0; b < ny; ++b) {
+        const float wzy = wz[a] * wy[b];
+        const float* row = gp + (long long)oz[a] * dy.sd + (long long)oy[b] * dy.sh;
+        for (int k = 0; k < nx; ++k) s += wzy * wx[k] * row[(long long)ox[k] * dy.sw];
+      }
+    float* o = dx.p + vox_addr(dx, n, iz, iy, ix) + c;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+static inline int grid_for(long long total, int cap = 8192) {
+  long long b = (total + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+static inline bool vec4_ok(const mmtta_tensor* t) {
+  return t->c % 4 == 0 && ((uintptr_t)t->ptr) % 16 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 &&
+         t->sn % 4 == 0 && t->sc == 1;
+}
+
+static inline bool same_shape(const mmtta_tensor* a, const mmtta_tensor* b) {
+  return a->n == b->n && a->c == b->c && a->d == b->d && a->h == b->h && a->w == b->w;
+}
+
+static void rows_geometry(const mmtta_tensor* t, int& rows_per_n, long long& vox_per_row) {
+  const long long dhw = (long long)t->d * t->h * t->w;
+  long long vpr = (dhw + 511) / 512;
+  if (vpr < 1024) vpr = 1024;
+  rows_per_n = (int)((dhw + vpr - 1) / vpr);
+  if (rows_per_n < 1) rows_per_n = 1;
+  vox_per_row = vpr;
+}
+
+}  // namespace mmtta
+
+using namespace mmtta;
+
+extern "C" int mmtta_copy_strided(const mmtta_tensor* src, const mmtta_tensor* dst, void* stream) {
+  MMTTA_CHECK(src && dst && src->ptr && dst->ptr, MMTTA_ERR_INVALID, "copy: null tensor");
+  MMTTA_CHECK(same_shape(src, dst), MMTTA_ERR_INVALID, "copy: shape mismatch");
+  const long long total = (long long)dst->n * dst->c * dst->d * dst->h * dst->w;
+  hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, tv(src), tv(dst));
+  return launch_status("copy_strided");
+}
+
+extern "C" int mmtta_reduce_rows_per_n(const mmtta_tensor* t) {
+  if (t == nullptr) return -1;
+  int r; long long v;
+  rows_geometry(t, r, v);
+  return r;
+}
+
+extern "C" int mmtta_channel_stats(const mmtta_tensor* x, float* part, void* stream) {
+  MMTTA_CHECK(x && x->ptr && part, MMTTA_ERR_INVALID, "channel_stats: null argument");
+  MMTTA_CHECK(is_cl(x), MMTTA_ERR_UNSUPPORTED, "channel_stats: tensor must be channels-last");
+  RedArgs a;
+  a.x = tv(x); a.dout = tv(x); a.t = nl(nullptr); a.part = part;
+  rows_geometry(x, a.rows_per_n, a.vox_per_row);
+  hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(x->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status("channel_stats");
+}
+
+extern "C" int mmtta_norm_stats_finalize(int kind, int groups, const float* part, int rows_per_n, int n, int c,
+                                         int64_t count, float eps, int training, float* running_mean,
+                                         float* running_var, float momentum, float* mean, float* rstd,
+                                         double* scratch, void* stream) {
+  MMTTA_CHECK(kind >= 0 && kind <= 2, MMTTA_ERR_INVALID, "norm: bad kind %d", kind);
+  MMTTA_CHECK(mean && rstd && n > 0 && c > 0 && count > 0, MMTTA_ERR_INVALID, "norm finalize: bad argument");
+  MMTTA_CHECK(scratch != nullptr, MMTTA_ERR_INVALID, "norm finalize: null scratch");
+  double* g_tot = scratch;
+  if (kind == MMTTA_NORM_GROUP) MMTTA_CHECK(groups > 0 && c % groups == 0, MMTTA_ERR_INVALID, "group norm: C %% groups != 0");
+  if (kind == MMTTA_NORM_BATCH && !training) MMTTA_CHECK(running_mean && running_var, MMTTA_ERR_INVALID, "batch norm eval needs running stats");
+  hipStream_t s = (hipStream_t)stream;
+  const bool need_rows = !(kind == MMTTA_NORM_BATCH && !training);
+  if (need_rows) {
+    MMTTA_CHECK(part != nullptr && rows_per_n > 0, MMTTA_ERR_INVALID, "norm finalize: null partials");
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3(n * c), dim3(64), 0, s, part, rows_per_n, c, g_tot);
+    int st = launch_status("norm rows reduce");
+    if (st) return st;
+  }
+  StatFinArgs a;
+  a.kind = kind; a.groups = groups; a.N = n; a.C = c; a.count = (double)count; a.eps = eps; a.training = training;
+  a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.mean = mean; a.rstd = rstd;
+  a.tot = g_tot;
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((n * c + 63) / 64), dim3(64), 0, s, a);
+  return launch_status("norm stats finalize");
+}
+
+extern "C" int mmtta_combine(const mmtta_tensor* a, const mmtta_norm_on_load* ta, const mmtta_tensor* b,
+                             const mmtta_norm_on_load* tb, const mmtta_tensor* out, void* stream) {
+  MMTTA_CHECK(a && out && a->ptr && out->ptr, MMTTA_ERR_INVALID, "combine: null tensor");
+  MMTTA_CHECK(same_shape(a, out) && (!b || same_shape(b, out)), MMTTA_ERR_INVALID, "combine: shape mismatch");
+  MMTTA_CHECK(is_cl(a) && is_cl(out) && (!b || is_cl(b)), MMTTA_ERR_UNSUPPORTED, "combine: channels-last only");
+  EwArgs e;
+  e.a = tv(a); e.b = b ? tv(b) : tv(a); e.o = tv(out); e.ta = nl(ta); e.tb = nl(tb); e.m1 = e.m2 = nullptr; e.hasb = b ? 1 : 0;
+  const bool v4 = vec4_ok(a) && vec4_ok(out) && (!b || vec4_ok(b));
+  const long long total = (long long)out->n * out->d * out->h * out->w * (v4 ? out->c / 4 : out->c);
+  if (v4) hipLaunchKernelGGL((elementwise_kernel<0, 4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
+  else hipLaunchKernelGGL((elementwise_kernel<0, 1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
+  return launch_status("combine");
+}
+
+extern "C" int mmtta_norm_bwd_reduce(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
+                                     float* part, void* stream) {
+  MMTTA_CHECK(dout && y && t && part && dout->ptr && y->ptr && t->mean && t->rstd, MMTTA_ERR_INVALID, "norm bwd reduce: null argument");
+  MMTTA_CHECK(same_shape(dout, y) && is_cl(dout) && is_cl(y), MMTTA_ERR_INVALID, "norm bwd reduce: shape/layout mismatch");
+  RedArgs a;
+  a.x = tv(y); a.dout = tv(dout); a.t = nl(t); a.part = part;
+  rows_geometry(y, a.rows_per_n, a.vox_per_row);
+  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(y->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status("norm bwd reduce");
+}
+
+extern "C" int mmtta_norm_bwd_finalize(int kind, int groups, const float* part, int rows_per_n, int n, int c,
+                                       int64_t count, const float* gamma, int training, float* m1, float* m2,
+                                       float* dgamma, float* dbeta, int accumulate, double* scratch, void* stream) {
+  MMTTA_CHECK(kind >= 0 && kind <= 2, MMTTA_ERR_INVALID, "norm: bad kind %d", kind);
+  MMTTA_CHECK(part && m1 && m2 && n > 0 && c > 0 && count > 0 && rows_per_n > 0, MMTTA_ERR_INVALID, "norm bwd finalize: bad argument");
+  MMTTA_CHECK(scratch != nullptr, MMTTA_ERR_INVALID, "norm bwd finalize: null scratch");
+  double* g_tot = scratch;
+  if (kind == MMTTA_NORM_GROUP) MMTTA_CHECK(groups > 0 && c % groups == 0, MMTTA_ERR_INVALID, "group norm: C %% groups != 0");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rows_reduce_kernel, dim3(n * c), dim3(64), 0, s, part, rows_per_n, c, g_tot);
+  int st = launch_status("norm bwd rows reduce");
+  if (st) return st;
+  BwdFinArgs a;
+  a.kind = kind; a.groups = groups; a.N = n; a.C = c; a.count = (double)count; a.gamma = gamma; a.training = training;
+  a.m1 = m1; a.m2 = m2; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate; a.tot = g_tot;
+  hipLaunchKernelGGL(bwd_finalize_kernel, dim3((n * c + 63) / 64), dim3(64), 0, s, a);
+  return launch_status("norm bwd finalize");
+}
+
+extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
+                                    const float* m1, const float* m2, const mmtta_tensor* dy, void* stream) {
+  MMTTA_CHECK(dout && y && t && dy && m1 && m2 && t->mean && t->rstd, MMTTA_ERR_INVALID, "norm bwd apply: null argument");
+  MMTTA_CHECK(same_shape(dout, y) && same_shape(dy, y), MMTTA_ERR_INVALID, "norm bwd apply: shape mismatch");
+  MMTTA_CHECK(is_cl(dout) && is_cl(y) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "norm bwd apply: channels-last only");
+  EwArgs e;
+  e.a = tv(dout); e.b = tv(y); e.o = tv(dy); e.ta = nl(t); e.tb = nl(nullptr); e.m1 = m1; e.m2 = m2; e.hasb = 1;
+  const bool v4 = vec4_ok(dout) && vec4_ok(y) && vec4_ok(dy);
+  const long long total = (long long)y->n * y->d * y->h * y->w * (v4 ? y->c / 4 : y->c);
+  if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
+  else hipLaunchKernelGGL((elementwise_kernel<1, 1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
+  return launch_status("norm bwd apply");
+}
+
+extern "C" int mmtta_upsample2x_fwd(const mmtta_tensor* x, const mmtta_tensor* y, void* stream) {
+  MMTTA_CHECK(x && y && x->ptr && y->ptr, MMTTA_ERR_INVALID, "upsample: null tensor");
+  MMTTA_CHECK(y->n == x->n && y->c == x->c && y->d == 2 * x->d && y->h == 2 * x->h && y->w == 2 * x->w, MMTTA_ERR_INVALID,
+              "upsample: y must be exactly 2x of x");
+  MMTTA_CHECK(is_cl(x) && is_cl(y), MMTTA_ERR_UNSUPPORTED, "upsample: channels-last only");
+  const long long total = (long long)y->n * y->d * y->h * y->w * y->c;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
+  return launch_status("upsample fwd");
+}
+
+extern "C" int mmtta_upsample2x_bwd(const mmtta_tensor* dy, const mmtta_tensor* dx, int accumulate, void* stream) {
+  MMTTA_CHECK(dx && dy && dx->ptr && dy->ptr, MMTTA_ERR_INVALID, "upsample bwd: null tensor");
+  MMTTA_CHECK(dy->n == dx->n && dy->c == dx->c && dy->d == 2 * dx->d && dy->h == 2 * dx->h && dy->w == 2 * dx->w,
+              MMTTA_ERR_INVALID, "upsample bwd: dy must be exactly 2x of dx");
+  MMTTA_CHECK(is_cl(dx) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "upsample bwd: channels-last only");
+  const long long total = (long long)dx->n * dx->d * dx->h * dx->w * dx->c;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
+  return launch_status("upsample bwd");
+}
+
+extern "C" int mmtta_lincomb(int count, const mmtta_tensor* const* in, const float* w, const mmtta_tensor* out,
+                             int accumulate, void* stream) {
+  MMTTA_CHECK(count >= 1 && count <= 8 && in && w && out && out->ptr, MMTTA_ERR_INVALID, "lincomb: bad argument");
+  LinArgs e;
+  bool v4 = vec4_ok(out);
+  for (int k = 0; k < count; ++k) {
+    MMTTA_CHECK(in[k] && in[k]->ptr && same_shape(in[k], out) && is_cl(in[k]), MMTTA_ERR_INVALID, "lincomb: input %d mismatch", k);
+    e.in[k] = tv(in[k]);
+    e.w[k] = w[k];
+    v4 = v4 && vec4_ok(in[k]);
+  }
+  for (int k = count; k < 8; ++k) { e.in[k] = e.in[0]; e.w[k] = 0.f; }
+  MMTTA_CHECK(is_cl(out), MMTTA_ERR_UNSUPPORTED, "lincomb: channels-last only");
+  e.count = count; e.o = tv(out); e.accumulate = accumulate;
+  const long long total = (long long)out->n * out->d * out->h * out->w * (v4 ? out->c / 4 : out->c);
+  if (v4) hipLaunchKernelGGL(lincomb_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
+  else hipLaunchKernelGGL(lincomb_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
+  return launch_status("lincomb");
+}

@@ -1,0 +1,346 @@
+"""Host-side execution engine of the adaptation path: explicit forward AND backward of the MONAI
+block vocabulary (Convolution / ADN / ResidualUnit / UpSample / SkipConnection) over
+channels-last device buffers, every arithmetic step a libmmtta.so kernel.
+
+Design (MI355X-first, not a translation of the reference's module-by-module torch graph):
+
+* no autograd graph: each block keeps references to the buffers it needs for backward, shapes
+  are static per input shape, so one adaptation step is a fixed launch sequence that is
+  captured into a hipGraph and replayed (tta.py);
+* norm + ReLU never materialise: a Convolution produces the raw conv output plus per-(n,c)
+  mean/rstd ("lazy" output, ops.NL); the consumer applies them while staging its input;
+* ``torch.cat`` never happens: producers write into channel slices of the concat buffer;
+* ResidualUnit's add is the epilogue of the residual conv (or one combine kernel when the
+  residual is the identity);
+* parameters, gradients and Adam moments live in four flat fp32 arenas (decay segment first,
+  reference src/core/experiment_manager.py:214-228), so the optimizer is one kernel launch
+  and the episodic reset one memcpy.
+
+Reference semantics of each block: SURVEY.md Appendix A (MONAI, restated in oracle/blocks.py).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .ops import NL, ConvOp, MmttaError
+
+GROUP_DECAY, GROUP_NO_DECAY, GROUP_FROZEN = 0, 1, 2
+
+
+# ----------------------------------------------------------------------------- parameters
+class ParamRef:
+    """A parameter adopted into the arena: ``data``/``grad`` are views into the flat buffers."""
+
+    def __init__(self, name: str, param: torch.nn.Parameter):
+        self.name, self.param = name, param
+        self.offset = -1
+        self.numel = param.numel()
+        self.shape = tuple(param.shape)
+        self.group = GROUP_DECAY
+        self.data: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+
+    @property
+    def trainable(self) -> bool:
+        return self.group != GROUP_FROZEN
+
+
+class Arena:
+    """Flat fp32 storage [decay | no-decay | frozen] for parameters, gradients and Adam moments."""
+
+    def __init__(self, refs: Sequence[ParamRef], device: torch.device):
+        self.device = device
+        order = sorted(range(len(refs)), key=lambda i: (refs[i].group, i))
+        off = 0
+        self.n_decay = self.n_train = 0
+        for i in order:
+            r = refs[i]
+            r.offset = off
+            off += (r.numel + 3) // 4 * 4          # keep every parameter 16-byte aligned
+            if r.group == GROUP_DECAY:
+                self.n_decay = off
+            if r.group != GROUP_FROZEN:
+                self.n_train = off
+        self.n_decay = min(self.n_decay, self.n_train) if self.n_train else 0
+        self.total = off
+        self.refs = list(refs)
+        self.params = torch.zeros(max(off, 4), dtype=torch.float32, device=device)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.step = torch.zeros(1, dtype=torch.int32, device=device)
+        for r in self.refs:
+            view = self.params[r.offset:r.offset + r.numel].view(r.shape)
+            with torch.no_grad():
+                view.copy_(r.param.detach().to(device=device, dtype=torch.float32))
+            r.param.data = view
+            r.data = view
+            r.grad = self.grads[r.offset:r.offset + r.numel].view(r.shape)
+            r.param.requires_grad_(r.group != GROUP_FROZEN)
+        self.source: Optional[torch.Tensor] = None
+
+    def owns(self) -> bool:
+        """True while every nn.Parameter still points into this arena (``module.to()`` can break it)."""
+        base = self.params.data_ptr()
+        return all(r.param.data_ptr() == base + 4 * r.offset for r in self.refs)
+
+    def snapshot_source(self) -> None:
+        self.source = self.params.clone()
+
+    def restore_source(self) -> None:
+        """Episodic reset: source weights back, optimizer state cleared."""
+        if self.source is None:
+            raise MmttaError("no source snapshot taken")
+        self.params.copy_(self.source)
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step.zero_()
+
+    def zero_grad(self) -> None:
+        self.grads.zero_()
+
+    def publish_grads(self) -> None:
+        """Expose gradients as ``param.grad`` for external torch optimizers (drop-in run_step path)."""
+        for r in self.refs:
+            r.param.grad = r.grad if r.trainable else None
+
+
+# ----------------------------------------------------------------------------- buffer pool
+class Pool:
+    """Named persistent device buffers (static addresses: required for graph capture)."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self._b: Dict[Tuple, torch.Tensor] = {}
+
+    def cl(self, key, n, d, h, w, c, ldc=None, zero=False) -> torch.Tensor:
+        k = ("cl", key, n, d, h, w, c, ldc)
+        t = self._b.get(k)
+        if t is None:
+            t = ops.new_cl(n, d, h, w, c, self.device, ldc, zero=zero)
+            self._b[k] = t
+        return t
+
+    def flat(self, key, numel, dtype=torch.float32, zero=False) -> torch.Tensor:
+        k = ("flat", key, numel, dtype)
+        t = self._b.get(k)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(max(int(numel), 1), dtype=dtype, device=self.device)
+            self._b[k] = t
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.untyped_storage().nbytes() for t in self._b.values())
+
+
+# ----------------------------------------------------------------------------- layers
+class NormLayer:
+    """MONAI ADN's "N": InstanceNorm3d (no parameters), BatchNorm3d or GroupNorm (affine)."""
+
+    def __init__(self, kind: str, channels: int, groups: int = 1, eps: float = 1e-5, momentum: float = 0.1,
+                 gamma: Optional[ParamRef] = None, beta: Optional[ParamRef] = None,
+                 running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
+                 num_batches_tracked: Optional[torch.Tensor] = None):
+        self.kind_name = kind
+        self.kind = ops.NORM_KINDS[kind]
+        self.C, self.groups, self.eps, self.momentum = channels, groups, eps, momentum
+        self.gamma, self.beta = gamma, beta
+        self.running_mean, self.running_var, self.nbt = running_mean, running_var, num_batches_tracked
+
+    def finalize(self, pool: Pool, key, part, rows_per_n: int, n: int, count: int, training: bool) -> NL:
+        mean = pool.flat((key, "mean"), n * self.C)
+        rstd = pool.flat((key, "rstd"), n * self.C)
+        scratch = pool.flat((key, "tot"), n * self.C * 2, dtype=torch.float64)
+        use_batch = training or self.kind != ops.NORM_BATCH
+        ops.norm_stats_finalize(self.kind, self.groups, part, rows_per_n, n, self.C, count, self.eps,
+                                use_batch, self.running_mean, self.running_var, self.momentum, mean, rstd, scratch)
+        if self.kind == ops.NORM_BATCH and training and self.nbt is not None:
+            self.nbt.add_(1)
+        return NL(mean, rstd, self.gamma.data if self.gamma else None, self.beta.data if self.beta else None, True)
+
+    def backward(self, pool: Pool, key, dT: torch.Tensor, y: torch.Tensor, nl: NL, dy: torch.Tensor,
+                 training: bool, accumulate: bool = False) -> None:
+        n, d, h, w, c = y.shape
+        rows = ops.reduce_rows_per_n(y)
+        part = pool.flat((key, "bpart"), n * rows * 2 * c)
+        m1 = pool.flat((key, "m1"), n * c)
+        m2 = pool.flat((key, "m2"), n * c)
+        scratch = pool.flat((key, "tot"), n * c * 2, dtype=torch.float64)
+        ops.norm_bwd_reduce(dT, y, nl, part)
+        train_g = self.gamma is not None and self.gamma.trainable
+        use_batch = training or self.kind != ops.NORM_BATCH
+        ops.norm_bwd_finalize(self.kind, self.groups, part, rows, n, c, d * h * w,
+                              self.gamma.data if self.gamma else None, use_batch, m1, m2,
+                              self.gamma.grad if train_g else None,
+                              self.beta.grad if (train_g and self.beta is not None) else None, accumulate, scratch)
+        ops.norm_bwd_apply(dT, y, nl, m1, m2, dy)
+
+
+class ConvLayer:
+    def __init__(self, op: ConvOp, weight: ParamRef, bias: Optional[ParamRef]):
+        self.op, self.weight, self.bias = op, weight, bias
+
+    def pack(self) -> None:
+        self.op.pack(self.weight.data)
+
+    def bias_data(self):
+        return self.bias.data if self.bias is not None else None
+
+    def wgrad(self, x, x_nl, dy, accumulate=False) -> None:
+        if not self.weight.trainable and not (self.bias is not None and self.bias.trainable):
+            return
+        # a frozen weight with a trainable bias still needs db; dw then lands in the (ignored) frozen grads
+        self.op.wgrad(x, x_nl, dy, self.weight.grad, self.bias.grad if self.bias is not None else None, accumulate)
+
+
+class Block:
+    """Common bookkeeping: a unique key for pooled buffers, the runtime that owns the pool."""
+    _next_id = 0
+
+    def __init__(self, rt: "Runtime"):
+        self.rt = rt
+        Block._next_id += 1
+        self.key = Block._next_id
+
+
+class ConvolutionBlock(Block):
+    """monai Convolution: conv (or transposed conv) [+ ADN = norm -> dropout(0) -> ReLU]."""
+
+    def __init__(self, rt, conv: ConvLayer, norm: Optional[NormLayer]):
+        super().__init__(rt)
+        self.conv, self.norm = conv, norm
+        self.saved = None
+
+    def fwd(self, x: torch.Tensor, x_nl: Optional[NL], y: Optional[torch.Tensor] = None):
+        op, pool = self.conv.op, self.rt.pool
+        n, d, h, w, c = op.out_shape(x)
+        if y is None:
+            y = pool.cl((self.key, "y"), n, d, h, w, c)
+        nl = None
+        if self.norm is not None:
+            rows = op.stats_rows(x, y)
+            stats = pool.flat((self.key, "stats"), rows * 2 * c)
+            op.forward(x, x_nl, self.conv.bias_data(), y, stats=stats)
+            nl = self.norm.finalize(pool, self.key, stats, rows // n, n, d * h * w, self.rt.training)
+        else:
+            op.forward(x, x_nl, self.conv.bias_data(), y)
+        self.saved = (x, x_nl, y, nl)
+        return y, nl
+
+    def bwd(self, dT: torch.Tensor, dx: Optional[torch.Tensor], accumulate: bool = False, need_dx: bool = True,
+            grad_accumulate: bool = False) -> None:
+        x, x_nl, y, nl = self.saved
+        dy = dT
+        if self.norm is not None:
+            dy = self.rt.pool.cl((self.key, "dy"), *y.shape)
+            self.norm.backward(self.rt.pool, self.key, dT, y, nl, dy, self.rt.training, grad_accumulate)
+        self.conv.wgrad(x, x_nl, dy, grad_accumulate)
+        if need_dx:
+            self.conv.op.dgrad(dy, dx, accumulate)
+
+
+class ResidualUnitBlock(Block):
+    """monai ResidualUnit: ``conv(x) + residual(x)``, residual = identity | conv k3 (strided) | conv k1."""
+
+    def __init__(self, rt, units: List[ConvolutionBlock], residual: Optional[ConvLayer]):
+        super().__init__(rt)
+        self.units, self.residual = units, residual
+        self.saved = None
+        self.fused_last = False
+
+    def out_shape(self, x):
+        return self.units[0].conv.op.out_shape(x)[:4] + (self.units[-1].conv.op.cout,)
+
+    def fwd(self, x: torch.Tensor, x_nl: Optional[NL], out: torch.Tensor) -> torch.Tensor:
+        cur, cur_nl = x, x_nl
+        self.fused_last = False
+        for u, unit in enumerate(self.units):
+            last = u == len(self.units) - 1
+            if last and unit.norm is None and self.residual is None:
+                # conv-only last unit + identity residual: the add is this conv's epilogue
+                unit.conv.op.forward(cur, cur_nl, unit.conv.bias_data(), out, add=x, add_nl=x_nl)
+                unit.saved = (cur, cur_nl, out, None)
+                self.fused_last = True
+                self.saved = (x, x_nl)
+                return out
+            cur, cur_nl = unit.fwd(cur, cur_nl)
+        if self.residual is not None:
+            self.residual.op.forward(x, x_nl, self.residual.bias_data(), out, add=cur, add_nl=cur_nl)
+        else:
+            ops.combine(cur, cur_nl, x, x_nl, out)
+        self.saved = (x, x_nl)
+        return out
+
+    def bwd(self, dout: torch.Tensor, dx: Optional[torch.Tensor], accumulate: bool = False, need_dx: bool = True,
+            grad_accumulate: bool = False) -> None:
+        x, x_nl = self.saved
+        pool = self.rt.pool
+        d = dout
+        for u in range(len(self.units) - 1, -1, -1):
+            unit = self.units[u]
+            if u > 0:
+                inp = unit.saved[0]
+                dprev = pool.cl((self.key, "dprev", u), *inp.shape)
+                unit.bwd(d, dprev, accumulate=False, need_dx=True, grad_accumulate=grad_accumulate)
+                d = dprev
+            else:
+                unit.bwd(d, dx, accumulate=accumulate, need_dx=need_dx, grad_accumulate=grad_accumulate)
+        if self.residual is not None:
+            self.residual.wgrad(x, x_nl, dout, grad_accumulate)
+            if need_dx:
+                self.residual.op.dgrad(dout, dx, accumulate=True)
+        elif need_dx:
+            ops.lincomb([dout], [1.0], dx, accumulate=True)
+
+
+# ----------------------------------------------------------------------------- runtime base
+class Runtime:
+    """Owns the arena, the buffer pool and the conv layers of one model instance on one device."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.pool = Pool(device)
+        self.training = False
+        self.convs: List[ConvLayer] = []
+        self.refs: List[ParamRef] = []
+        self.arena: Optional[Arena] = None
+
+    # -- construction helpers
+    def make_ref(self, name: str, param: torch.nn.Parameter) -> ParamRef:
+        r = ParamRef(name, param)
+        self.refs.append(r)
+        return r
+
+    def make_conv(self, name: str, module: torch.nn.Module, stride_hint: Optional[int] = None) -> ConvLayer:
+        transposed = isinstance(module, torch.nn.ConvTranspose3d)
+        k = module.kernel_size[0]
+        s = module.stride[0]
+        cin, cout = module.in_channels, module.out_channels
+        op = ConvOp(cin, cout, k, s, transposed, self.device)
+        w = self.make_ref(name + ".weight", module.weight)
+        b = self.make_ref(name + ".bias", module.bias) if module.bias is not None else None
+        layer = ConvLayer(op, w, b)
+        self.convs.append(layer)
+        return layer
+
+    def assign_groups(self, trainable: Optional[set], no_decay_keys: Sequence[str], treat_1d: bool) -> None:
+        """decay / no-decay split of reference src/core/experiment_manager.py:214-228; parameters whose
+        name is not in ``trainable`` (None = all) are frozen."""
+        for r in self.refs:
+            if trainable is not None and r.name not in trainable:
+                r.group = GROUP_FROZEN
+            elif any(k in r.name for k in no_decay_keys) or (treat_1d and len(r.shape) == 1):
+                r.group = GROUP_NO_DECAY
+            else:
+                r.group = GROUP_DECAY
+
+    def build_arena(self) -> Arena:
+        self.arena = Arena(self.refs, self.device)
+        return self.arena
+
+    def pack_all(self) -> None:
+        for c in self.convs:
+            c.pack()

@@ -1,0 +1,301 @@
+"""Thin, typed Python wrappers over the C ABI (one function per entry point of include/mmtta.h).
+
+Activations are channels-last views: torch tensors of logical shape [N, D, H, W, C] with unit
+stride along C (possibly a channel slice of a wider buffer, which is how ``torch.cat`` of the
+reference - src/models/unet_multimodal_midfusion.py:135, monai SkipConnection - disappears:
+producers write straight into their slice).  Everything runs on torch's current CUDA stream, so
+the calls can be captured into a graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (CONV_DGRAD, CONV_FWD, CONVT_DGRAD, CONVT_FWD, F32, NORM_BATCH, NORM_GROUP, NORM_INSTANCE,
+                   ConvDesc, ConvEpilogue, ConvPlan, MmttaError, check, desc_cl, desc_ncdhw, ptr, stream_ptr)
+
+NORM_KINDS = {"INSTANCE": NORM_INSTANCE, "BATCH": NORM_BATCH, "GROUP": NORM_GROUP}
+
+
+def _require_cuda() -> None:
+    if not torch.cuda.is_available():
+        raise MmttaError("the adaptation path needs an MI355X (gfx950) device; no CPU fallback exists")
+
+
+# ----------------------------------------------------------------------------- workspace
+class Workspace:
+    """One grow-only scratch buffer per device, shared by split-K convs and weight gradients
+    (stream ordered).  It must reach its final size before a graph capture starts."""
+
+    _buffers: Dict[int, torch.Tensor] = {}
+    frozen = False
+
+    @classmethod
+    def get(cls, nbytes: int, device: torch.device) -> torch.Tensor:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        buf = cls._buffers.get(idx)
+        if buf is None or buf.numel() < nbytes:
+            if cls.frozen:
+                raise MmttaError("workspace would have to grow during graph capture; run one eager warm-up step first")
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            cls._buffers[idx] = buf
+        return buf
+
+
+# ----------------------------------------------------------------------------- norm on load
+@dataclass
+class NL:
+    """Pending normalisation(+ReLU) of a raw conv output; consumers apply it when they read."""
+    mean: torch.Tensor
+    rstd: torch.Tensor
+    gamma: Optional[torch.Tensor] = None
+    beta: Optional[torch.Tensor] = None
+    relu: bool = True
+
+    def struct(self) -> _lib.NormOnLoad:
+        return _lib.norm_on_load(self.mean, self.rstd, self.gamma, self.beta, self.relu)
+
+
+def _nl_ref(nl: Optional[NL]):
+    if nl is None:
+        return None, None
+    s = nl.struct()
+    return s, C.byref(s)
+
+
+# ----------------------------------------------------------------------------- layout
+def new_cl(n: int, d: int, h: int, w: int, c: int, device, ldc: Optional[int] = None, zero: bool = False) -> torch.Tensor:
+    """Allocate a channels-last buffer [n,d,h,w,ldc] and return the [.., :c] view."""
+    ldc = c if ldc is None else ldc
+    buf = (torch.zeros if zero else torch.empty)((n, d, h, w, ldc), dtype=torch.float32, device=device)
+    return buf[..., :c] if ldc != c else buf
+
+
+def to_cl(x: torch.Tensor, out: Optional[torch.Tensor] = None, ldc: Optional[int] = None) -> torch.Tensor:
+    """NCDHW -> channels-last (reference tensor contract: src/datasets/brats.py:343-347)."""
+    _require_cuda()
+    n, c, d, h, w = x.shape
+    if out is None:
+        out = new_cl(n, d, h, w, c, x.device, ldc if ldc is not None else (c + 3) // 4 * 4, zero=True)
+    src = desc_ncdhw(x)
+    dst = desc_cl(out)
+    check(_lib.load().mmtta_copy_strided(C.byref(src), C.byref(dst), stream_ptr()), "copy_strided")
+    return out
+
+
+def from_cl(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """channels-last -> contiguous NCDHW (what reference src/evaluation/seg_eval.py:300 expects back)."""
+    n, d, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=x.device)
+    src = desc_cl(x)
+    # describe `out` with the logical (n,c,d,h,w) of src
+    dst = desc_ncdhw(out)
+    check(_lib.load().mmtta_copy_strided(C.byref(src), C.byref(dst), stream_ptr()), "copy_strided")
+    return out
+
+
+# ----------------------------------------------------------------------------- convolution
+class ConvOp:
+    """One Conv3d / ConvTranspose3d module's kernels: forward, input gradient, weight gradient.
+
+    Holds the two packed weight images (forward and input-gradient orientation), refreshed by
+    ``pack`` after every optimizer step.
+    """
+
+    def __init__(self, cin: int, cout: int, ksize: int, stride: int, transposed: bool, device, dtype: int = F32):
+        _require_cuda()
+        self.cin, self.cout, self.k, self.stride, self.transposed = cin, cout, ksize, stride, transposed
+        self.device = torch.device(device)
+        fwd_op, dg_op = (CONVT_FWD, CONVT_DGRAD) if transposed else (CONV_FWD, CONV_DGRAD)
+        self.d_fwd = ConvDesc(fwd_op, ksize, stride, cin, cout, dtype)
+        self.d_dgrad = ConvDesc(dg_op, ksize, stride, cin, cout, dtype)
+        lib = _lib.load()
+        nb_f = lib.mmtta_conv_packed_bytes(C.byref(self.d_fwd))
+        nb_d = lib.mmtta_conv_packed_bytes(C.byref(self.d_dgrad))
+        if nb_f < 0 or nb_d < 0:
+            check(-2, "conv_packed_bytes")
+        self.packed_fwd = torch.empty(nb_f, dtype=torch.uint8, device=self.device)
+        self.packed_dgrad = torch.empty(nb_d, dtype=torch.uint8, device=self.device)
+        self._plans: Dict[Tuple, ConvPlan] = {}
+        self.need_dgrad = True
+
+    def weight_shape(self) -> Tuple[int, ...]:
+        k = self.k
+        return (self.cin, self.cout, k, k, k) if self.transposed else (self.cout, self.cin, k, k, k)
+
+    def pack(self, weight: torch.Tensor) -> None:
+        if tuple(weight.shape) != self.weight_shape() or weight.dtype != torch.float32 or not weight.is_contiguous():
+            raise MmttaError(f"weight must be contiguous fp32 {self.weight_shape()}, got {tuple(weight.shape)}")
+        lib = _lib.load()
+        s = stream_ptr()
+        check(lib.mmtta_conv_pack_weights(C.byref(self.d_fwd), ptr(weight), ptr(self.packed_fwd), s), "pack fwd")
+        if self.need_dgrad:
+            check(lib.mmtta_conv_pack_weights(C.byref(self.d_dgrad), ptr(weight), ptr(self.packed_dgrad), s), "pack dgrad")
+
+    def out_shape(self, x: torch.Tensor) -> Tuple[int, int, int, int, int]:
+        n, d, h, w, _ = x.shape
+        if self.transposed:
+            return (n, d * 2, h * 2, w * 2, self.cout)
+        if self.stride == 1:
+            return (n, d, h, w, self.cout)
+        return (n, (d + 1) // 2, (h + 1) // 2, (w + 1) // 2, self.cout)
+
+    def plan(self, desc: ConvDesc, x: torch.Tensor, y: torch.Tensor) -> ConvPlan:
+        key = (desc.op, tuple(x.shape), tuple(y.shape))
+        p = self._plans.get(key)
+        if p is None:
+            p = ConvPlan()
+            dx, dy = desc_cl(x), desc_cl(y)
+            check(_lib.load().mmtta_conv_plan(C.byref(desc), C.byref(dx), C.byref(dy), C.byref(p)), "conv_plan")
+            self._plans[key] = p
+        return p
+
+    def stats_rows(self, x: torch.Tensor, y: torch.Tensor) -> int:
+        return int(self.plan(self.d_fwd, x, y).stats_rows)
+
+    def _run(self, desc, packed, x, x_nl, bias, y, accumulate, stats, add, add_nl):
+        p = self.plan(desc, x, y)
+        ws = Workspace.get(int(p.workspace_bytes), x.device) if p.workspace_bytes > 0 else None
+        dx, dy = desc_cl(x), desc_cl(y)
+        nls, nlr = _nl_ref(x_nl)
+        epi = None
+        keep = None
+        if add is not None:
+            keep = desc_cl(add)
+            epi = ConvEpilogue(C.pointer(keep), add_nl.struct() if add_nl is not None else _lib.norm_on_load())
+        check(
+            _lib.load().mmtta_conv_run(
+                C.byref(desc), C.byref(dx), nlr, ptr(packed), ptr(bias), C.byref(epi) if epi is not None else None,
+                C.byref(dy), 1 if accumulate else 0, ptr(stats), ptr(ws), int(p.workspace_bytes), stream_ptr()),
+            "conv_run")
+
+    def forward(self, x: torch.Tensor, x_nl: Optional[NL], bias: Optional[torch.Tensor], y: torch.Tensor,
+                stats: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
+                add_nl: Optional[NL] = None, accumulate: bool = False) -> None:
+        self._run(self.d_fwd, self.packed_fwd, x, x_nl, bias, y, accumulate, stats, add, add_nl)
+
+    def dgrad(self, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool = False) -> None:
+        self._run(self.d_dgrad, self.packed_dgrad, dy, None, None, dx, accumulate, None, None, None)
+
+    def wgrad(self, x: torch.Tensor, x_nl: Optional[NL], dy: torch.Tensor, dw: torch.Tensor,
+              db: Optional[torch.Tensor], accumulate: bool = False) -> None:
+        lib = _lib.load()
+        tx, tdy = desc_cl(x), desc_cl(dy)
+        need = lib.mmtta_conv_wgrad_workspace_bytes(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy))
+        if need < 0:
+            check(-1, "conv_wgrad_workspace_bytes")
+        ws = Workspace.get(int(need), x.device)
+        nls, nlr = _nl_ref(x_nl)
+        check(lib.mmtta_conv_wgrad(C.byref(self.d_fwd), C.byref(tx), nlr, C.byref(tdy), ptr(dw), ptr(db),
+                                   1 if accumulate else 0, ptr(ws), int(need), stream_ptr()), "conv_wgrad")
+
+
+# ----------------------------------------------------------------------------- normalisation
+def reduce_rows_per_n(x: torch.Tensor) -> int:
+    t = desc_cl(x)
+    return int(_lib.load().mmtta_reduce_rows_per_n(C.byref(t)))
+
+
+def channel_stats(x: torch.Tensor, part: torch.Tensor) -> None:
+    t = desc_cl(x)
+    check(_lib.load().mmtta_channel_stats(C.byref(t), ptr(part), stream_ptr()), "channel_stats")
+
+
+def norm_stats_finalize(kind: int, groups: int, part: Optional[torch.Tensor], rows_per_n: int, n: int, c: int,
+                        count: int, eps: float, training: bool, running_mean, running_var, momentum: float,
+                        mean: torch.Tensor, rstd: torch.Tensor, scratch: torch.Tensor) -> None:
+    check(_lib.load().mmtta_norm_stats_finalize(kind, groups, ptr(part), rows_per_n, n, c, count, eps,
+                                                1 if training else 0, ptr(running_mean), ptr(running_var),
+                                                momentum, ptr(mean), ptr(rstd), ptr(scratch), stream_ptr()),
+          "norm_stats_finalize")
+
+
+def combine(a: torch.Tensor, a_nl: Optional[NL], b: Optional[torch.Tensor], b_nl: Optional[NL], out: torch.Tensor) -> None:
+    ta, to = desc_cl(a), desc_cl(out)
+    tb = desc_cl(b) if b is not None else None
+    sa, ra = _nl_ref(a_nl)
+    sb, rb = _nl_ref(b_nl)
+    check(_lib.load().mmtta_combine(C.byref(ta), ra, C.byref(tb) if tb is not None else None, rb, C.byref(to),
+                                    stream_ptr()), "combine")
+
+
+def norm_bwd_reduce(dout: torch.Tensor, y: torch.Tensor, nl: NL, part: torch.Tensor) -> None:
+    td, ty = desc_cl(dout), desc_cl(y)
+    s, r = _nl_ref(nl)
+    check(_lib.load().mmtta_norm_bwd_reduce(C.byref(td), C.byref(ty), r, ptr(part), stream_ptr()), "norm_bwd_reduce")
+
+
+def norm_bwd_finalize(kind: int, groups: int, part: torch.Tensor, rows_per_n: int, n: int, c: int, count: int,
+                      gamma, training: bool, m1: torch.Tensor, m2: torch.Tensor, dgamma, dbeta, accumulate: bool,
+                      scratch: torch.Tensor) -> None:
+    check(_lib.load().mmtta_norm_bwd_finalize(kind, groups, ptr(part), rows_per_n, n, c, count, ptr(gamma),
+                                              1 if training else 0, ptr(m1), ptr(m2), ptr(dgamma), ptr(dbeta),
+                                              1 if accumulate else 0, ptr(scratch), stream_ptr()),
+          "norm_bwd_finalize")
+
+
+def norm_bwd_apply(dout: torch.Tensor, y: torch.Tensor, nl: NL, m1: torch.Tensor, m2: torch.Tensor,
+                   dy: torch.Tensor) -> None:
+    td, ty, to = desc_cl(dout), desc_cl(y), desc_cl(dy)
+    s, r = _nl_ref(nl)
+    check(_lib.load().mmtta_norm_bwd_apply(C.byref(td), C.byref(ty), r, ptr(m1), ptr(m2), C.byref(to), stream_ptr()),
+          "norm_bwd_apply")
+
+
+# ----------------------------------------------------------------------------- resample / glue
+def upsample2x_fwd(x: torch.Tensor, y: torch.Tensor) -> None:
+    tx, ty = desc_cl(x), desc_cl(y)
+    check(_lib.load().mmtta_upsample2x_fwd(C.byref(tx), C.byref(ty), stream_ptr()), "upsample2x_fwd")
+
+
+def upsample2x_bwd(dy: torch.Tensor, dx: torch.Tensor, accumulate: bool = False) -> None:
+    ty, tx = desc_cl(dy), desc_cl(dx)
+    check(_lib.load().mmtta_upsample2x_bwd(C.byref(ty), C.byref(tx), 1 if accumulate else 0, stream_ptr()),
+          "upsample2x_bwd")
+
+
+def lincomb(inputs: Sequence[torch.Tensor], weights: Sequence[float], out: torch.Tensor, accumulate: bool = False) -> None:
+    k = len(inputs)
+    descs = [desc_cl(t) for t in inputs]
+    arr = (C.POINTER(_lib.Tensor) * k)(*[C.pointer(d) for d in descs])
+    w = (C.c_float * k)(*[float(x) for x in weights])
+    to = desc_cl(out)
+    check(_lib.load().mmtta_lincomb(k, arr, w, C.byref(to), 1 if accumulate else 0, stream_ptr()), "lincomb")
+
+
+# ----------------------------------------------------------------------------- loss / optimizer / metric
+def entropy_partials(logits: torch.Tensor) -> int:
+    t = desc_cl(logits)
+    return int(_lib.load().mmtta_entropy_partials(C.byref(t)))
+
+
+def entropy_loss(logits: torch.Tensor, dlogits: torch.Tensor, partial: torch.Tensor, loss: torch.Tensor,
+                 softmax: bool = False) -> None:
+    tz, tg = desc_cl(logits), desc_cl(dlogits)
+    check(_lib.load().mmtta_entropy_loss(C.byref(tz), 1 if softmax else 0, C.byref(tg), ptr(partial), ptr(loss),
+                                         stream_ptr()), "entropy_loss")
+
+
+def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, n_decay: int, lr: float,
+              beta1: float, beta2: float, eps: float, weight_decay: float, step: torch.Tensor) -> None:
+    n = p.numel()
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise MmttaError("adam: p, g, m, v must be contiguous fp32 of equal length")
+    if step.dtype != torch.int32:
+        raise MmttaError("adam: step must be a device int32 scalar")
+    check(_lib.load().mmtta_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, int(n_decay), lr, beta1, beta2, eps,
+                                      weight_decay, ptr(step), stream_ptr()), "adam_step")
+
+
+def mask_dice_counts(logits_cl: torch.Tensor, label_ncdhw: torch.Tensor, threshold: float, counts: torch.Tensor,
+                     mask: Optional[torch.Tensor] = None) -> None:
+    tz = desc_cl(logits_cl)
+    tl = desc_ncdhw(label_ncdhw)
+    check(_lib.load().mmtta_mask_dice_counts(C.byref(tz), C.byref(tl), float(threshold), ptr(counts), ptr(mask),
+                                             stream_ptr()), "mask_dice_counts")

@@ -1,0 +1,169 @@
+"""Parity of the implicit-GEMM conv kernels (forward, input gradient, weight gradient) against
+torch CPU fp32 (F.conv3d / F.conv_transpose3d + autograd), through the C ABI.
+
+Tolerance: fp32 MFMA accumulates in k order like an fmaf chain; torch CPU (oneDNN) uses a
+different summation order, so agreement is to rounding: |err| <= 2e-4 * max|ref| + 1e-5.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_REL, TOL_ABS = 2e-4, 1e-5
+
+
+def close(name, got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= TOL_REL * scale + TOL_ABS, f"{name}: max|err|={err:.3e} (max|ref|={scale:.3e})"
+
+
+def cl(x):  # NCDHW cpu -> channels-last cuda view
+    from multimodal_tta_amd import ops
+    return ops.to_cl(x.cuda().contiguous())
+
+
+def ncdhw(x_cl):
+    return x_cl.permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+CASES = [
+    # (cin, cout, k, stride, transposed, (n, d, h, w))
+    (4, 8, 3, 1, False, (1, 12, 10, 8)),
+    (32, 32, 3, 1, False, (1, 16, 16, 16)),
+    (33, 32, 3, 1, False, (1, 8, 8, 16)),
+    (64, 64, 3, 1, False, (1, 8, 8, 8)),
+    (128, 136, 3, 1, False, (2, 4, 6, 8)),
+    (3, 3, 3, 1, False, (1, 8, 8, 8)),
+    (4, 32, 3, 2, False, (1, 16, 16, 16)),
+    (1, 32, 3, 2, False, (1, 8, 8, 8)),
+    (32, 64, 3, 2, False, (1, 8, 8, 16)),
+    (64, 128, 3, 2, False, (1, 5, 6, 7)),
+    (256, 512, 1, 1, False, (1, 4, 4, 4)),
+    (32, 3, 1, 1, False, (1, 8, 8, 8)),
+    (512, 512, 3, 1, False, (1, 4, 4, 4)),
+    (8, 3, 3, 2, True, (1, 5, 6, 4)),
+    (64, 32, 3, 2, True, (1, 4, 4, 8)),
+    (768, 128, 3, 2, True, (1, 2, 2, 2)),
+]
+
+
+def ref_module(cin, cout, k, stride, transposed):
+    pad = (k - 1) // 2
+    if transposed:
+        return torch.nn.ConvTranspose3d(cin, cout, k, stride=stride, padding=pad, output_padding=stride - 1)
+    return torch.nn.Conv3d(cin, cout, k, stride=stride, padding=pad)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", CASES)
+def test_conv_fwd_dgrad_wgrad(cin, cout, k, stride, transposed, shape):
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(1234 + cin * 7 + cout)
+    n, d, h, w = shape
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = torch.randn(n, cin, d, h, w, requires_grad=True)
+    y_ref = mod(x)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+
+    op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda")
+    wt = mod.weight.detach().cuda().contiguous()
+    bias = mod.bias.detach().cuda().contiguous()
+    op.pack(wt)
+    x_cl = cl(x.detach())
+    y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda")
+    rows = op.stats_rows(x_cl, y_cl)
+    stats = torch.full((rows, 2, cout), float("nan"), device="cuda")
+    op.forward(x_cl, None, bias, y_cl, stats=stats)
+    torch.cuda.synchronize()
+    close("forward", ncdhw(y_cl), y_ref)
+    # per-tile statistics add up to the per-(n,c) sums of the output
+    st = stats.view(n, rows // n, 2, cout).double().sum(1).cpu()
+    yr = y_ref.detach().double()
+    ref_sum = yr.sum(dim=(2, 3, 4))
+    ref_sq = (yr * yr).sum(dim=(2, 3, 4))
+    assert torch.allclose(st[:, 0], ref_sum, rtol=1e-3, atol=1e-2 * max(1.0, ref_sq.max().item()) ** 0.5), "stats sum"
+    assert torch.allclose(st[:, 1], ref_sq, rtol=1e-3, atol=1e-3), "stats sumsq"
+
+    gy_cl = cl(gy)
+    dx_cl = ops.new_cl(n, d, h, w, cin, "cuda")
+    op.dgrad(gy_cl, dx_cl)
+    torch.cuda.synchronize()
+    close("dgrad", ncdhw(dx_cl), x.grad)
+
+    dw = torch.empty_like(wt)
+    db = torch.empty_like(bias)
+    op.wgrad(x_cl, None, gy_cl, dw, db)
+    torch.cuda.synchronize()
+    close("wgrad", dw, mod.weight.grad)
+    close("bgrad", db, mod.bias.grad)
+    # accumulate paths
+    op.dgrad(gy_cl, dx_cl, accumulate=True)
+    op.wgrad(x_cl, None, gy_cl, dw, db, accumulate=True)
+    torch.cuda.synchronize()
+    close("dgrad accumulate", ncdhw(dx_cl), 2 * x.grad)
+    close("wgrad accumulate", dw, 2 * mod.weight.grad)
+
+
+def test_conv_norm_on_load_and_epilogue():
+    """y = conv(relu(instance_norm(x))) + relu(instance_norm(r)) with both transforms applied on load."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(7)
+    n, cin, cout, d, h, w = 2, 32, 64, 6, 8, 8
+    x = torch.randn(n, cin, d, h, w) * 2 + 0.5
+    r = torch.randn(n, cout, d, h, w)
+    mod = torch.nn.Conv3d(cin, cout, 3, padding=1)
+    xin = F.relu(F.instance_norm(x))
+    y_ref = mod(xin) + F.relu(F.instance_norm(r))
+
+    def stats_of(t):
+        mu = t.mean(dim=(2, 3, 4))
+        var = t.var(dim=(2, 3, 4), unbiased=False)
+        return mu.reshape(-1).cuda().contiguous(), (1.0 / torch.sqrt(var + 1e-5)).reshape(-1).cuda().contiguous()
+
+    mx, rx = stats_of(x)
+    mr, rr = stats_of(r)
+    op = ops.ConvOp(cin, cout, 3, 1, False, "cuda")
+    op.pack(mod.weight.detach().cuda().contiguous())
+    x_cl, r_cl = cl(x), cl(r)
+    y_cl = ops.new_cl(n, d, h, w, cout, "cuda")
+    op.forward(x_cl, ops.NL(mx, rx, relu=True), mod.bias.detach().cuda(), y_cl, add=r_cl, add_nl=ops.NL(mr, rr, relu=True))
+    torch.cuda.synchronize()
+    close("fused forward", ncdhw(y_cl), y_ref)
+
+    # weight gradient with the same norm-on-load of the input
+    xin2 = xin.clone().requires_grad_(False)
+    gy = torch.randn_like(y_ref)
+    w_ = mod.weight.detach().clone().requires_grad_(True)
+    F.conv3d(xin2, w_, None, padding=1).backward(gy)
+    dw = torch.empty_like(w_, device="cuda")
+    op.wgrad(x_cl, ops.NL(mx, rx, relu=True), cl(gy), dw, None)
+    torch.cuda.synchronize()
+    close("wgrad with norm on load", dw, w_.grad)
+
+
+def test_conv_channel_slices():
+    """Reading from and writing into channel slices of wider buffers (the concat replacement)."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(11)
+    n, d, h, w = 1, 8, 8, 8
+    a = torch.randn(n, 32, d, h, w)
+    b = torch.randn(n, 32, d, h, w)
+    mod = torch.nn.Conv3d(64, 32, 3, padding=1)
+    y_ref = mod(torch.cat([a, b], dim=1))
+    cat = torch.empty(n, d, h, w, 64, device="cuda")
+    ops.to_cl(a.cuda(), out=cat[..., :32])
+    ops.to_cl(b.cuda(), out=cat[..., 32:])
+    out = torch.zeros(n, d, h, w, 96, device="cuda")
+    op = ops.ConvOp(64, 32, 3, 1, False, "cuda")
+    op.pack(mod.weight.detach().cuda().contiguous())
+    op.forward(cat, None, mod.bias.detach().cuda(), out[..., 32:64])
+    torch.cuda.synchronize()
+    close("slice forward", ncdhw(out[..., 32:64]), y_ref)
+    assert out[..., :32].abs().max().item() == 0 and out[..., 64:].abs().max().item() == 0
