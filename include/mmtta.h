@@ -241,10 +241,19 @@ int mmtta_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int
 /* sigmoid -> (>= threshold) -> uint8 mask; GT (> 0.5); per (n,r) integer counts
  * inter = sum p&g, psum = sum p, gsum = sum g.  Replaces reference
  * src/evaluation/seg_eval.py:304-306 and the three reductions of :55-60.
- *   logits  channels-last fp32;  label  any strides, fp32 {0,1};
+ *   logits  fp32, any strides;  label  any strides, fp32 {0,1};
  *   counts  int64 [N][R][3], zeroed by this call;  mask  uint8 NCDHW [N,R,D,H,W] or NULL */
 int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label, float threshold,
                            int64_t* counts, uint8_t* mask, void* stream);
+
+/* Sums behind monai DiceCELoss(sigmoid=True) as the reference evaluator builds it for
+ * ``evaluation.loss.report_loss`` (reference src/evaluation/seg_eval.py:209-220,395-400; SURVEY.md
+ * Appendix A.5).  out fp64 [N][R*3+1], zeroed by this call: per region (sum p*y, sum p, sum y) with
+ * p = sigmoid(z) (squares of p, y when squared_pred), then the CE numerator: BCE-with-logits with
+ * pos_weight = weight[0] when R == 1, soft-label softmax cross entropy with class weights otherwise.
+ * The few scalar operations that turn the sums into the loss value are host arithmetic. */
+int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight,
+                       int squared_pred, double* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void dice_counts_kernel(TV z, TV lab, float th
       const int x = (int)(t % z.w); t /= z.w;
       const int y = (int)(t % z.h);
       const int zz = (int)(t / z.h);
-      const float lg = z.p[n * z.sn + zz * z.sd + y * z.sh + x * z.sw + r];
+      const float lg = z.p[n * z.sn + (long long)r * z.sc + zz * z.sd + y * z.sh + x * z.sw];
       const float prob = 1.f / (1.f + expf(-lg));
       const unsigned int pb = prob >= thr ? 1u : 0u;
       const float lv = lab.p[n * lab.sn + (long long)r * lab.sc + zz * lab.sd + y * lab.sh + x * lab.sw];
@@ -167,6 +167,69 @@ __global__ __launch_bounds__(256) void dice_counts_kernel(TV z, TV lab, float th
     for (int j = 0; j < nvl; ++j) { ti += sh[0][j * rp + r]; tp += sh[1][j * rp + r]; tg += sh[2][j * rp + r]; }
     unsigned long long* c = counts + ((long long)n * R + r) * 3;
     atomicAdd(c + 0, ti); atomicAdd(c + 1, tp); atomicAdd(c + 2, tg);
+  }
+}
+
+// ------------------------------------------------------------------ DiceCE sums (evaluation report_loss)
+// per (n,r): sum p*y, sum p (or p^2), sum y (or y^2), p = sigmoid(z); plus the CE numerator:
+// R == 1: BCE-with-logits (pos_weight);  R > 1: soft-label softmax CE  -sum_r w_r y_r log_softmax(z)_r.
+// out fp64 [N][R*3 + 1], zeroed by the host wrapper; fp64 atomics (deterministic enough for a report).
+constexpr int DCE_MAX_R = 8;
+__global__ __launch_bounds__(256) void dice_ce_sums_kernel(TV z, TV lab, const float* weight, int squared,
+                                                           double* out, int blocks_per_n) {
+  __shared__ double sh[4];
+  const int R = z.c;
+  const int n = blockIdx.x / blocks_per_n, bn = blockIdx.x % blocks_per_n;
+  const long long dhw = (long long)z.d * z.h * z.w;
+  double acc[DCE_MAX_R * 3 + 1];
+#pragma unroll
+  for (int i = 0; i < DCE_MAX_R * 3 + 1; ++i) acc[i] = 0.0;
+  for (long long v = (long long)bn * 256 + threadIdx.x; v < dhw; v += (long long)blocks_per_n * 256) {
+    long long t = v;
+    const int x = (int)(t % z.w); t /= z.w;
+    const int y = (int)(t % z.h);
+    const int zz = (int)(t / z.h);
+    float lg[DCE_MAX_R], yv[DCE_MAX_R];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < DCE_MAX_R; ++r)
+      if (r < R) {
+        lg[r] = z.p[n * z.sn + (long long)r * z.sc + zz * z.sd + y * z.sh + x * z.sw];
+        yv[r] = lab.p[n * lab.sn + (long long)r * lab.sc + zz * lab.sd + y * lab.sh + x * lab.sw];
+        m = fmaxf(m, lg[r]);
+      }
+    float se = 0.f;
+#pragma unroll
+    for (int r = 0; r < DCE_MAX_R; ++r)
+      if (r < R) se += expf(lg[r] - m);
+    const float lse = m + logf(se);
+#pragma unroll
+    for (int r = 0; r < DCE_MAX_R; ++r)
+      if (r < R) {
+        const float e = expf(-fabsf(lg[r]));
+        const float p = lg[r] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        acc[r * 3 + 0] += (double)(p * yv[r]);
+        acc[r * 3 + 1] += (double)(squared ? p * p : p);
+        acc[r * 3 + 2] += (double)(squared ? yv[r] * yv[r] : yv[r]);
+        if (R == 1) {
+          const float pw = weight ? weight[0] : 1.f;
+          const float softplus_neg = log1pf(e) + fmaxf(-lg[r], 0.f);
+          acc[DCE_MAX_R * 3] += (double)((1.f - yv[r]) * lg[r] + (1.f + (pw - 1.f) * yv[r]) * softplus_neg);
+        } else {
+          const float wr = weight ? weight[r] : 1.f;
+          acc[DCE_MAX_R * 3] += (double)(-wr * yv[r] * (lg[r] - lse));
+        }
+      }
+  }
+  for (int i = 0; i < DCE_MAX_R * 3 + 1; ++i) {
+    const bool used = (i == DCE_MAX_R * 3) || (i / 3 < R);
+    if (!used) continue;                       // uniform across the block
+    const double t = block_sum_d(acc[i], sh);
+    if (threadIdx.x == 0) {
+      const int col = (i == DCE_MAX_R * 3) ? R * 3 : i;
+      atomicAdd(out + (long long)n * (R * 3 + 1) + col, t);
+    }
+    __syncthreads();
   }
 }
 
@@ -225,7 +288,6 @@ extern "C" int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_te
   MMTTA_CHECK(logits && label && counts && logits->ptr && label->ptr, MMTTA_ERR_INVALID, "dice: null argument");
   MMTTA_CHECK(logits->n == label->n && logits->c == label->c && logits->d == label->d && logits->h == label->h &&
                   logits->w == label->w, MMTTA_ERR_INVALID, "dice: logits/label shape mismatch");
-  MMTTA_CHECK(is_cl(logits), MMTTA_ERR_UNSUPPORTED, "dice: logits must be channels-last");
   MMTTA_CHECK(logits->c <= 256, MMTTA_ERR_UNSUPPORTED, "dice: more than 256 regions");
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(counts, 0, (size_t)logits->n * logits->c * 3 * sizeof(int64_t), s);
@@ -240,4 +302,22 @@ extern "C" int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_te
   hipLaunchKernelGGL(dice_counts_kernel, dim3((unsigned)(bpn * logits->n)), dim3(256), 0, s, tv(logits), tv(label), threshold,
                      (unsigned long long*)counts, mask, (int)bpn);
   return launch_status("dice counts");
+}
+
+extern "C" int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight,
+                                  int squared_pred, double* out, void* stream) {
+  MMTTA_CHECK(logits && label && out && logits->ptr && label->ptr, MMTTA_ERR_INVALID, "dice_ce: null argument");
+  MMTTA_CHECK(logits->n == label->n && logits->c == label->c && logits->d == label->d && logits->h == label->h &&
+                  logits->w == label->w, MMTTA_ERR_INVALID, "dice_ce: logits/label shape mismatch");
+  MMTTA_CHECK(logits->c <= DCE_MAX_R, MMTTA_ERR_UNSUPPORTED, "dice_ce: more than %d regions", DCE_MAX_R);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)logits->n * (logits->c * 3 + 1) * sizeof(double), s);
+  MMTTA_CHECK(e == hipSuccess, MMTTA_ERR_LAUNCH, "dice_ce: memset failed: %s", hipGetErrorString(e));
+  const long long dhw = (long long)logits->d * logits->h * logits->w;
+  long long bpn = (dhw + 256 * 8 - 1) / (256 * 8);
+  if (bpn < 1) bpn = 1;
+  if (bpn > 512) bpn = 512;
+  hipLaunchKernelGGL(dice_ce_sums_kernel, dim3((unsigned)(bpn * logits->n)), dim3(256), 0, s, tv(logits), tv(label), weight,
+                     squared_pred, out, (int)bpn);
+  return launch_status("dice_ce sums");
 }

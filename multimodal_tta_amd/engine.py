@@ -142,23 +142,24 @@ class NormLayer:
 
     def __init__(self, kind: str, channels: int, groups: int = 1, eps: float = 1e-5, momentum: float = 0.1,
                  gamma: Optional[ParamRef] = None, beta: Optional[ParamRef] = None,
-                 running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
-                 num_batches_tracked: Optional[torch.Tensor] = None):
+                 bn_module: Optional[torch.nn.Module] = None):
         self.kind_name = kind
         self.kind = ops.NORM_KINDS[kind]
         self.C, self.groups, self.eps, self.momentum = channels, groups, eps, momentum
         self.gamma, self.beta = gamma, beta
-        self.running_mean, self.running_var, self.nbt = running_mean, running_var, num_batches_tracked
+        self.bn = bn_module        # owns running_mean / running_var / num_batches_tracked (BatchNorm only)
 
     def finalize(self, pool: Pool, key, part, rows_per_n: int, n: int, count: int, training: bool) -> NL:
         mean = pool.flat((key, "mean"), n * self.C)
         rstd = pool.flat((key, "rstd"), n * self.C)
         scratch = pool.flat((key, "tot"), n * self.C * 2, dtype=torch.float64)
         use_batch = training or self.kind != ops.NORM_BATCH
+        rm = self.bn.running_mean if self.bn is not None else None
+        rv = self.bn.running_var if self.bn is not None else None
         ops.norm_stats_finalize(self.kind, self.groups, part, rows_per_n, n, self.C, count, self.eps,
-                                use_batch, self.running_mean, self.running_var, self.momentum, mean, rstd, scratch)
-        if self.kind == ops.NORM_BATCH and training and self.nbt is not None:
-            self.nbt.add_(1)
+                                use_batch, rm, rv, self.momentum, mean, rstd, scratch)
+        if self.bn is not None and training and self.bn.num_batches_tracked is not None:
+            self.bn.num_batches_tracked.add_(1)
         return NL(mean, rstd, self.gamma.data if self.gamma else None, self.beta.data if self.beta else None, True)
 
     def backward(self, pool: Pool, key, dT: torch.Tensor, y: torch.Tensor, nl: NL, dy: torch.Tensor,
@@ -306,6 +307,7 @@ class Runtime:
         self.training = False
         self.convs: List[ConvLayer] = []
         self.refs: List[ParamRef] = []
+        self.buffers: List[torch.nn.Module] = []     # modules owning running statistics (BatchNorm)
         self.arena: Optional[Arena] = None
 
     # -- construction helpers
@@ -339,8 +341,88 @@ class Runtime:
 
     def build_arena(self) -> Arena:
         self.arena = Arena(self.refs, self.device)
+        for mod in self.buffers:                    # BatchNorm running statistics follow the parameters
+            for name, buf in list(mod.named_buffers(recurse=False)):
+                if buf is not None and buf.device != self.device:
+                    setattr(mod, name, buf.to(self.device))
         return self.arena
 
     def pack_all(self) -> None:
         for c in self.convs:
             c.pack()
+
+    def snapshot_buffers(self) -> None:
+        """Source values of the running statistics (BatchNorm), restored with the weights per volume."""
+        self._buf_src = [(mod, name, buf.clone()) for mod in self.buffers
+                         for name, buf in mod.named_buffers(recurse=False) if buf is not None]
+
+    def restore_buffers(self) -> None:
+        for mod, name, src in getattr(self, "_buf_src", []):
+            getattr(mod, name).copy_(src)
+
+    # -- whole-network entry points (subclasses provide forward_cl / backward_cl)
+    def stage_input(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, d, h, w = x.shape
+        if c != self.in_channels:
+            raise ValueError(f"model expects {self.in_channels} input channels, got {c}")
+        x_cl = self.pool.cl("x", n, d, h, w, c, ldc=(c + 3) // 4 * 4, zero=True)
+        ops.to_cl(x, out=x_cl)
+        return x_cl
+
+    def run_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: NCDHW fp32 on this device -> logits as a channels-last view [N,D,H,W,R]."""
+        self.pack_all()
+        return self.forward_cl(self.stage_input(x))
+
+    def run_backward(self, dlogits_cl: torch.Tensor) -> None:
+        self.backward_cl(dlogits_cl)
+
+
+# ----------------------------------------------------------------------------- container -> block builders
+def build_norm(rt: Runtime, prefix: str, adn: Optional[torch.nn.Module], channels: int) -> Optional[NormLayer]:
+    """ADN container -> NormLayer.  Dropout must be p=0 (every shipped config), activation ReLU."""
+    if adn is None:
+        return None
+    mods = dict(adn.named_children())
+    drop = mods.get("D")
+    if drop is not None and float(drop.p) != 0.0:
+        raise NotImplementedError("dropout p > 0 is not on the adaptation path (shipped configs use 0.0)")
+    nmod = mods.get("N")
+    if nmod is None:
+        raise NotImplementedError("an ADN without a norm layer is not supported by the fused norm-on-load path")
+    if "A" not in mods:
+        raise NotImplementedError("an ADN without an activation is not supported")
+    if isinstance(nmod, torch.nn.InstanceNorm3d):
+        if nmod.track_running_stats:
+            raise NotImplementedError("InstanceNorm3d(track_running_stats=True)")
+        g = rt.make_ref(prefix + ".N.weight", nmod.weight) if nmod.affine else None
+        b = rt.make_ref(prefix + ".N.bias", nmod.bias) if nmod.affine else None
+        return NormLayer("INSTANCE", channels, 1, nmod.eps, 0.1, g, b)
+    if isinstance(nmod, torch.nn.BatchNorm3d):
+        if not (nmod.affine and nmod.track_running_stats):
+            raise NotImplementedError("BatchNorm3d without affine / running statistics")
+        g = rt.make_ref(prefix + ".N.weight", nmod.weight)
+        b = rt.make_ref(prefix + ".N.bias", nmod.bias)
+        rt.buffers.append(nmod)
+        mom = 0.1 if nmod.momentum is None else float(nmod.momentum)
+        return NormLayer("BATCH", channels, 1, nmod.eps, mom, g, b, bn_module=nmod)
+    if isinstance(nmod, torch.nn.GroupNorm):
+        g = rt.make_ref(prefix + ".N.weight", nmod.weight) if nmod.affine else None
+        b = rt.make_ref(prefix + ".N.bias", nmod.bias) if nmod.affine else None
+        return NormLayer("GROUP", channels, nmod.num_groups, nmod.eps, 0.1, g, b)
+    raise NotImplementedError(f"norm module {type(nmod).__name__}")
+
+
+def build_convolution(rt: Runtime, prefix: str, cont: torch.nn.Module) -> ConvolutionBlock:
+    conv = rt.make_conv(prefix + ".conv", cont.conv)
+    adn = getattr(cont, "adn", None)
+    norm = build_norm(rt, prefix + ".adn", adn, cont.conv.out_channels)
+    return ConvolutionBlock(rt, conv, norm)
+
+
+def build_residual_unit(rt: Runtime, prefix: str, cont: torch.nn.Module) -> ResidualUnitBlock:
+    units = [build_convolution(rt, f"{prefix}.conv.{name}", unit) for name, unit in cont.conv.named_children()]
+    residual = None
+    if isinstance(cont.residual, torch.nn.Conv3d):
+        residual = rt.make_conv(prefix + ".residual", cont.residual)
+    return ResidualUnitBlock(rt, units, residual)

@@ -1,0 +1,322 @@
+"""Evaluation plugins for the adaptation path.
+
+``seg_eval`` is the reference's strategy under its own name (reference
+src/evaluation/seg_eval.py:151, contract SURVEY.md section 8b): same constructor (root config),
+same ``evaluate_epoch(model, data_loader, device) -> Dict[str, float]``, same metric keys and
+float64 aggregation (:250-270, :363-378, :402-460), same errors (:279-302).  What changed is where
+the voxel work runs: threshold + the three reductions of ``_binary_dice_iou`` (:41-68, :304-306)
+are one HIP kernel returning exact integer counts, so a batch costs ONE device->host copy instead
+of the reference's 3*B*R ``.item()`` syncs (:366-368).
+
+``seg_tta_eval`` adapts every volume with the ``entmin_tta`` plugin before scoring it, shards
+volumes across ranks (one process per GPU) and merges the per-volume table with a single
+``all_gather`` - RCCL over xGMI on an MI355X node, gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .config import as_cfg, get_config
+from .registry import get_plugin, register_evaluation_strategy
+
+EPS = 1e-7
+
+
+# ----------------------------------------------------------------------------- small host-side pieces
+def as_list_str(x: Any, batch_size: int) -> List[str]:
+    """batch['domain'] in any collated form -> list[str] of length B (reference seg_eval.py:19-38)."""
+    if x is None:
+        return [""] * batch_size
+    if isinstance(x, (list, tuple)):
+        return [str(v) for v in x]
+    if isinstance(x, str):
+        return [x] * batch_size
+    if torch.is_tensor(x):
+        if x.ndim == 0:
+            return [str(int(x.item()))] * batch_size
+        if x.numel() == batch_size:
+            return [str(int(v.item())) for v in x.view(-1)]
+    return [str(x)] * batch_size
+
+
+def dice_iou_from_counts(counts: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """counts int64 [B,R,3] = (inter, pred, gt) -> dice, iou, valid with the reference's fp32 formulas
+    (seg_eval.py:55-66).  The counts are exact (< 2**24 per the shipped shapes), so the fp32 values equal
+    the reference's sums of {0,1} floats bit for bit."""
+    c = counts.to(torch.float32)
+    inter, ps, gs = c[..., 0], c[..., 1], c[..., 2]
+    valid = gs > 0
+    dice = (2.0 * inter + EPS) / (ps + gs + EPS)
+    iou = (inter + EPS) / (ps + gs - inter + EPS)
+    return dice, iou, valid
+
+
+class RegionAccumulator:
+    """float64 sums / counts per region, overall and per domain (reference seg_eval.py:250-270,363-378)."""
+
+    def __init__(self, region_order: Sequence[str]):
+        self.regions = list(region_order)
+        R = len(self.regions)
+        self._z = lambda: torch.zeros(R, dtype=torch.float64)
+        self.tot = [self._z() for _ in range(4)]       # sum_dice, cnt_dice, sum_iou, cnt_iou
+        self.dom: Dict[str, List[torch.Tensor]] = defaultdict(lambda: [self._z() for _ in range(4)])
+        self.total_loss, self.n_samples = 0.0, 0
+
+    def add_row(self, dice: Sequence[float], iou: Sequence[float], valid: Sequence[bool], domain: str) -> None:
+        d = self.dom[domain]
+        for c in range(len(self.regions)):
+            if bool(valid[c]):
+                dv, iv = float(dice[c]), float(iou[c])
+                for acc in (self.tot, d):
+                    acc[0][c] += dv
+                    acc[1][c] += 1.0
+                    acc[2][c] += iv
+                    acc[3][c] += 1.0
+
+    def add_loss(self, loss: float, batch: int) -> None:
+        self.total_loss += float(loss) * batch
+        self.n_samples += batch
+
+    @staticmethod
+    def _fin(s: torch.Tensor, c: torch.Tensor) -> List[float]:
+        return [float((s[k] / c[k]).item()) if c[k] > 0 else 0.0 for k in range(len(s))]
+
+    @staticmethod
+    def _avg(means: List[float], cnt: torch.Tensor) -> float:
+        ok = [k for k in range(len(means)) if cnt[k] > 0]
+        return float(sum(means[k] for k in ok) / max(1, len(ok)))
+
+    def metrics(self, report_loss: bool) -> Dict[str, float]:
+        md, mi = self._fin(self.tot[0], self.tot[1]), self._fin(self.tot[2], self.tot[3])
+        out: Dict[str, float] = {}
+        for name, v in zip(self.regions, md):
+            out[f"{name.lower()}_dc"] = v
+        out["avg_dc"] = self._avg(md, self.tot[1])
+        out["miou"] = self._avg(mi, self.tot[3])
+        out["jc"] = out["miou"]
+        out["loss"] = float(self.total_loss / max(1, self.n_samples)) if report_loss else 0.0
+        for dom in sorted(self.dom.keys()):
+            sd, cd, si, ci = self.dom[dom]
+            safe = dom if dom != "" else "unknown"
+            dm, dim_ = self._fin(sd, cd), self._fin(si, ci)
+            for name, v in zip(self.regions, dm):
+                out[f"dom/{safe}/{name.lower()}_dc"] = v
+            out[f"dom/{safe}/avg_dc"] = self._avg(dm, cd)
+            out[f"dom/{safe}/miou"] = self._avg(dim_, ci)
+        return out
+
+
+class DiceCEReport:
+    """monai DiceCELoss(sigmoid=True, ...) value for ``report_loss`` from the HIP sums kernel
+    (reference seg_eval.py:198-220,395-400)."""
+
+    def __init__(self, crit_cfg: Any):
+        crit_cfg = as_cfg(crit_cfg)
+        self.include_background = bool(get_config(crit_cfg, "include_background", True))
+        self.squared_pred = bool(get_config(crit_cfg, "squared_pred", False))
+        self.jaccard = bool(get_config(crit_cfg, "jaccard", False))
+        self.lambda_dice = float(get_config(crit_cfg, "lambda_dice", 1.0))
+        self.lambda_ce = float(get_config(crit_cfg, "lambda_ce", 1.0))
+        w = get_config(crit_cfg, "weight", None)
+        self.weight = [float(x) for x in list(w)] if w is not None and len(list(w)) > 0 else None
+        self._w_dev: Optional[torch.Tensor] = None
+
+    def __call__(self, logits: torch.Tensor, label: torch.Tensor, channels_last: bool = False) -> float:
+        B, R = (logits.shape[0], logits.shape[-1]) if channels_last else logits.shape[:2]
+        nvox = logits.numel() // (B * R)
+        if self.weight is not None and self._w_dev is None:
+            if len(self.weight) != R:
+                raise ValueError(f"criterion.weight has {len(self.weight)} entries for {R} channels")
+            self._w_dev = torch.tensor(self.weight, dtype=torch.float32, device=logits.device)
+        out = torch.empty(B * (R * 3 + 1), dtype=torch.float64, device=logits.device)
+        ops.dice_ce_sums(logits, label, self._w_dev, self.squared_pred, out, logits_channels_last=channels_last)
+        s = out.cpu().view(B, R * 3 + 1)
+        per = s[:, :R * 3].view(B, R, 3).to(torch.float32)
+        inter, ps, gs = per[..., 0], per[..., 1], per[..., 2]
+        if not self.include_background and R > 1:
+            inter, ps, gs = inter[:, 1:], ps[:, 1:], gs[:, 1:]
+        den = gs + ps
+        if self.jaccard:
+            den = 2.0 * (den - inter)
+        f = 1.0 - (2.0 * inter + 1e-5) / (den + 1e-5)
+        if self.weight is not None and f.shape[1] != 1:
+            dw = torch.tensor(self.weight[1:] if not self.include_background else self.weight, dtype=torch.float32)
+            if dw.numel() == f.shape[1]:
+                f = f * dw
+        dice = float(f.mean().item())
+        ce = float((s[:, R * 3].sum() / (B * nvox * (R if R == 1 else 1))).item())
+        return self.lambda_dice * dice + self.lambda_ce * ce
+
+
+# ----------------------------------------------------------------------------- seg_eval
+@register_evaluation_strategy("seg_eval")
+class SegmentationEvaluationStrategy:
+    def __init__(self, config: Any = None):
+        self.config = as_cfg(config)
+        seg = get_config(self.config, "evaluation.seg", {}) or {}
+        self.threshold = float(get_config(seg, "threshold", 0.5))
+        self.region_order = list(get_config(seg, "region_order", ["ET", "TC", "WT"]))
+        sp = get_config(seg, "spacing", [1.0, 1.0, 1.0])
+        sp = list(sp) if sp is not None else [1.0, 1.0, 1.0]
+        if len(sp) != 3:
+            raise ValueError(f"[BratsSegEval] evaluation.seg.spacing must have length 3, got {sp}")
+        self.spacing = tuple(float(v) for v in sp)
+        self.report_loss = bool(get_config(self.config, "evaluation.loss.report_loss", False))
+        if bool(get_config(self.config, "evaluation.surface.enable", False)):
+            raise NotImplementedError(
+                "evaluation.surface.enable: HD95/ASD are outside the adaptation hot path (SURVEY.md section 8f, row 4); "
+                "the reference leaves them off by default (src/evaluation/seg_eval.py:195)")
+        self.loss_fn = DiceCEReport(get_config(self.config, "training.criterion", {}) or {})
+
+    # -- per batch
+    def check_batch(self, batch: Dict[str, Any], device) -> Tuple[torch.Tensor, torch.Tensor]:
+        x = batch["image"].to(device)
+        B = x.size(0)
+        if "label" not in batch:
+            raise KeyError("[BratsSegEval] batch must contain 'label' for region-based eval.")
+        y = batch["label"]
+        y = y.to(device) if torch.is_tensor(y) else torch.as_tensor(y, device=device)
+        if y.ndim == 4:
+            y = y.unsqueeze(0).expand(B, -1, -1, -1, -1)
+        if y.ndim != 5:
+            raise ValueError(f"[BratsSegEval] label must be 5D, got {tuple(y.shape)}")
+        R = int(y.size(1))
+        if R != len(self.region_order):
+            raise ValueError(f"[BratsSegEval] label channels={R} but region_order={len(self.region_order)}")
+        return x, y.float()
+
+    def score(self, logits: torch.Tensor, y: torch.Tensor, channels_last: bool = False) -> torch.Tensor:
+        """logits [B,R,D,H,W] (or channels-last view) + labels -> exact counts int64 [B,R,3] on the host."""
+        R = y.shape[1]
+        shape_ok = (logits.ndim == 5 and (logits.shape[-1] if channels_last else logits.shape[1]) == R)
+        if not shape_ok:
+            raise ValueError(f"[BratsSegEval] model logits must be [B,{R},D,H,W], got {tuple(logits.shape)}")
+        counts = torch.empty((y.shape[0], R, 3), dtype=torch.int64, device=y.device)
+        ops.mask_dice_counts(logits, y, self.threshold, counts, None, logits_channels_last=channels_last)
+        return counts.cpu()
+
+    @torch.no_grad()
+    def evaluate_epoch(self, model: torch.nn.Module, data_loader: Iterable, device) -> Dict[str, float]:
+        model.eval()
+        model.to(device)
+        acc = RegionAccumulator(self.region_order)
+        for batch in data_loader:
+            x, y = self.check_batch(batch, device)
+            logits = model(x)
+            counts = self.score(logits.float(), y)
+            dice, iou, valid = dice_iou_from_counts(counts)
+            domains = as_list_str(batch.get("domain", None), batch_size=x.size(0))
+            for i in range(x.size(0)):
+                acc.add_row(dice[i].tolist(), iou[i].tolist(), valid[i].tolist(), domains[i])
+            if self.report_loss:
+                acc.add_loss(self.loss_fn(logits.float(), y), x.size(0))
+        return acc.metrics(self.report_loss)
+
+
+# ----------------------------------------------------------------------------- sharding
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Round-robin, deterministic: volume i -> rank i mod W."""
+    return list(range(rank, n_items, world))
+
+
+def table_width(R: int) -> int:
+    return 3 + 3 * R  # index, domain_id, loss, then dice[R], iou[R], valid[R]
+
+
+def gather_table(rows: torch.Tensor, n_items: int, world: int, group=None) -> torch.Tensor:
+    """all_gather the fixed-shape per-volume table [ceil(N/W), width] (float64; unused rows have index -1)
+    and return the rows sorted by volume index.  The only collective of the path."""
+    import torch.distributed as dist
+
+    per = (n_items + world - 1) // world
+    pad = torch.full((per, rows.shape[1]), -1.0, dtype=torch.float64, device=rows.device)
+    pad[:rows.shape[0]] = rows
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        allrows = pad
+    else:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        allrows = torch.cat(bufs, dim=0)
+    allrows = allrows.cpu()
+    allrows = allrows[allrows[:, 0] >= 0]
+    order = torch.argsort(allrows[:, 0])
+    return allrows[order]
+
+
+def metrics_from_table(table: torch.Tensor, region_order: Sequence[str], domain_names: Sequence[str],
+                       report_loss: bool) -> Dict[str, float]:
+    """Replay the reference aggregation over gathered rows in volume-index order: the result is
+    identical to a single-process run (float64 sums, order fixed by index)."""
+    R = len(region_order)
+    acc = RegionAccumulator(region_order)
+    for row in table:
+        dom = domain_names[int(row[1].item())] if 0 <= int(row[1].item()) < len(domain_names) else ""
+        dice = row[3:3 + R].to(torch.float32).tolist()
+        iou = row[3 + R:3 + 2 * R].to(torch.float32).tolist()
+        valid = (row[3 + 2 * R:3 + 3 * R] > 0.5).tolist()
+        acc.add_row(dice, iou, valid, dom)
+        if report_loss:
+            acc.add_loss(float(row[2].item()), 1)
+    return acc.metrics(report_loss)
+
+
+@register_evaluation_strategy("seg_tta_eval")
+class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
+    """Adapt each volume (plugin ``method.name``, default ``entmin_tta``), then score it."""
+
+    def __init__(self, config: Any = None):
+        super().__init__(config)
+        self.plugin_name = str(get_config(self.config, "method.name", "entmin_tta"))
+        self.plugin = None
+
+    @torch.no_grad()
+    def evaluate_epoch(self, model: torch.nn.Module, data_loader: Iterable, device) -> Dict[str, float]:
+        """``data_loader`` yields this rank's shard (any batch size; volumes adapt one at a time)."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.plugin is None:
+            self.plugin = get_plugin(self.plugin_name)(self.config).setup(model, device)
+        R = len(self.region_order)
+        rows: List[torch.Tensor] = []
+        domain_names: List[str] = []
+        n_local = 0
+        for batch in data_loader:
+            x, y = self.check_batch(batch, device)
+            domains = as_list_str(batch.get("domain", None), batch_size=x.size(0))
+            idx = batch.get("index", None)
+            for i in range(x.size(0)):
+                res = self.plugin.adapt_volume(x[i:i + 1])
+                counts = self.score(res["logits_cl"], y[i:i + 1], channels_last=True)
+                dice, iou, valid = dice_iou_from_counts(counts)
+                loss = self.loss_fn(res["logits_cl"], y[i:i + 1], channels_last=True) if self.report_loss else 0.0
+                if domains[i] not in domain_names:
+                    domain_names.append(domains[i])
+                gi = int(idx[i]) if idx is not None else n_local
+                row = torch.cat([torch.tensor([gi, domain_names.index(domains[i]), loss], dtype=torch.float64),
+                                 dice[0].double(), iou[0].double(), valid[0].double()])
+                rows.append(row)
+                n_local += 1
+        table = torch.stack(rows) if rows else torch.empty((0, table_width(R)), dtype=torch.float64)
+        if world > 1:
+            # domain ids must mean the same on every rank: exchange the name lists
+            names: List[Optional[List[str]]] = [None] * world
+            dist.all_gather_object(names, domain_names)
+            merged = sorted({n for lst in names for n in (lst or [])})
+            remap = {i: merged.index(n) for i, n in enumerate(domain_names)}
+            for r in range(table.shape[0]):
+                table[r, 1] = remap[int(table[r, 1].item())]
+            domain_names = merged
+            counts_t = torch.tensor([table.shape[0]], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(counts_t)
+            n_items = int(counts_t.item())
+            dev = device if dist.get_backend() == "nccl" else "cpu"
+            table = gather_table(table.to(dev), max(n_items, 1), world)
+            # ranks may hold unequal shares; gather_table pads to ceil(N/W) which bounds every share of a
+            # round-robin shard
+        self.last_table = table
+        return metrics_from_table(table, self.region_order, domain_names, self.report_loss)

@@ -293,9 +293,21 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
                                       weight_decay, ptr(step), stream_ptr()), "adam_step")
 
 
-def mask_dice_counts(logits_cl: torch.Tensor, label_ncdhw: torch.Tensor, threshold: float, counts: torch.Tensor,
-                     mask: Optional[torch.Tensor] = None) -> None:
-    tz = desc_cl(logits_cl)
+def _desc_any(t: torch.Tensor, channels_last: bool):
+    return desc_cl(t) if channels_last else desc_ncdhw(t)
+
+
+def mask_dice_counts(logits: torch.Tensor, label_ncdhw: torch.Tensor, threshold: float, counts: torch.Tensor,
+                     mask: Optional[torch.Tensor] = None, logits_channels_last: bool = True) -> None:
+    tz = _desc_any(logits, logits_channels_last)
     tl = desc_ncdhw(label_ncdhw)
     check(_lib.load().mmtta_mask_dice_counts(C.byref(tz), C.byref(tl), float(threshold), ptr(counts), ptr(mask),
                                              stream_ptr()), "mask_dice_counts")
+
+
+def dice_ce_sums(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Optional[torch.Tensor], squared_pred: bool,
+                 out: torch.Tensor, logits_channels_last: bool = True) -> None:
+    tz = _desc_any(logits, logits_channels_last)
+    tl = desc_ncdhw(label_ncdhw)
+    check(_lib.load().mmtta_dice_ce_sums(C.byref(tz), C.byref(tl), ptr(weight), 1 if squared_pred else 0, ptr(out),
+                                         stream_ptr()), "dice_ce_sums")

@@ -1,0 +1,210 @@
+"""``entmin_tta``: per-test-volume entropy-minimisation adaptation, registered in the reference's
+free PLUGINS slot (reference src/registry.py:66,94-96; selected through the existing ``method``
+config group, reference configs/config.yaml:7).
+
+The reference ships no adaptation code; the semantics are this repo's (SURVEY.md
+Appendix C, executable form: oracle/tta.py).  The step skeleton is the reference's supervised step
+(src/core/trainers/seg_trainer.py:105-145): forward -> loss -> backward -> optimizer.step, with
+the entropy objective as the loss, Adam built with the reference's decay / no-decay split
+(src/core/experiment_manager.py:199-237, configs/training/default.yaml:30-56), then the
+reference's evaluation tail (src/evaluation/seg_eval.py:300-308).
+
+MI355X shape of the loop: the whole step (weight repack, forward, fused loss+gradient, backward,
+fused Adam over the flat arena) is ONE captured hipGraph replayed ``steps`` times; nothing
+returns to the host inside a volume except the final per-region counts (one small copy).
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .config import as_cfg, get_config
+from .models.base import DEFAULT_NO_DECAY_KEYS, HipSegModel
+from .ops import MmttaError
+from .registry import register_plugin
+
+
+def select_params(model: torch.nn.Module, spec) -> List[str]:
+    """Names of the parameters that adapt: 'all' | 'norm_affine' | substring or list of substrings."""
+    names = [n for n, _ in model.named_parameters()]
+    if spec is None or spec == "all":
+        return names
+    if spec == "norm_affine":
+        return [n for n in names if ".adn.N." in n]
+    pats = [spec] if isinstance(spec, str) else list(spec)
+    return [n for n in names if any(s in n for s in pats)]
+
+
+def modality_mask(num_modalities: int, missing: Sequence[int], p_drop: float,
+                  gen: Optional[torch.Generator]) -> List[bool]:
+    """present[m] for one step: permanently missing channels plus a seeded Bernoulli(p) drop of each
+    present one; at least one modality always survives."""
+    miss = set(int(i) for i in missing)
+    present = [m not in miss for m in range(num_modalities)]
+    if p_drop > 0.0 and gen is not None:
+        u = torch.rand(num_modalities, generator=gen)
+        dropped = [present[m] and bool(u[m] < p_drop) for m in range(num_modalities)]
+        if all(dropped[m] or not present[m] for m in range(num_modalities)):
+            first = next(m for m in range(num_modalities) if present[m])
+            dropped[first] = False
+        present = [present[m] and not dropped[m] for m in range(num_modalities)]
+    return present
+
+
+def drop_modality(x: torch.Tensor, present: Sequence[bool]) -> torch.Tensor:
+    """Zero the absent channels (0 is the background value of the data: reference src/datasets/brats.py:7)."""
+    if all(present):
+        return x
+    keep = torch.tensor([1.0 if p else 0.0 for p in present], dtype=x.dtype, device=x.device)
+    return x * keep.view(1, -1, 1, 1, 1)
+
+
+@register_plugin("entmin_tta")
+class EntropyMinimizationTTA:
+    """Construct with the ROOT config (like the reference's evaluation strategies,
+    src/core/experiment_manager.py:369-370), then ``setup(model, device)`` once and
+    ``adapt_volume(x)`` per test volume."""
+
+    def __init__(self, config: Any = None):
+        cfg = as_cfg(config)
+        self.cfg = cfg
+        m = get_config(cfg, "method", {}) or {}
+        self.steps = int(get_config(m, "steps", 10))
+        self.episodic = bool(get_config(m, "episodic", True))
+        self.params_spec = get_config(m, "params", "all")
+        self.precision = str(get_config(m, "precision", "fp32")).lower()
+        self.missing = [int(i) for i in (get_config(m, "missing_modalities", []) or [])]
+        md = get_config(m, "moddrop", {}) or {}
+        self.moddrop_p = float(get_config(md, "p", 0.0)) if bool(get_config(md, "enabled", False)) else 0.0
+        self.moddrop_seed = int(get_config(md, "seed", 0))
+        self.use_graph = bool(get_config(m, "use_graph", True))
+        tr = get_config(cfg, "training", {}) or {}
+        opt_name = str(get_config(tr, "optimizer", "adam")).lower()
+        if opt_name != "adam":
+            raise NotImplementedError(
+                f"training.optimizer={opt_name}: the fused arena optimizer implements torch.optim.Adam "
+                "(the reference default, configs/training/default.yaml:11); use the nn.Module facade with a torch "
+                "optimizer for others")
+        oc = get_config(tr, "optimizers.adam", {}) or {}
+        self.lr = float(get_config(oc, "lr", get_config(tr, "learning_rate", 1e-3)))
+        betas = get_config(oc, "betas", [0.9, 0.999])
+        self.beta1, self.beta2 = float(betas[0]), float(betas[1])
+        self.eps = float(get_config(oc, "eps", 1e-8))
+        self.weight_decay = float(get_config(oc, "weight_decay", get_config(tr, "weight_decay", 0.0)))
+        if bool(get_config(oc, "amsgrad", False)):
+            raise NotImplementedError("amsgrad")
+        rules = get_config(tr, "param_groups", {}) or {}
+        self.no_decay_keys = list(get_config(rules, "no_decay_keys", []))
+        self.treat_1d = bool(get_config(rules, "treat_1d_as_no_decay", True))
+        crit = get_config(tr, "criterion", {}) or {}
+        self.softmax = bool(get_config(crit, "softmax", False))
+        if self.precision not in ("fp32",):
+            raise NotImplementedError(f"method.precision={self.precision}: this build computes in fp32 (fp32 MFMA)")
+        self.model: Optional[HipSegModel] = None
+        self.rt = None
+        self._graphs: Dict[Tuple, torch.cuda.CUDAGraph] = {}
+        self._gen: Optional[torch.Generator] = None
+
+    # ------------------------------------------------------------------ setup
+    def setup(self, model: HipSegModel, device) -> "EntropyMinimizationTTA":
+        if not isinstance(model, HipSegModel):
+            raise TypeError("entmin_tta drives the HIP-backed models of this package (registered as 'unet', "
+                            "'unet_multimodal_deepfusion', 'unet_multimodal_midfusion')")
+        device = torch.device(device)
+        self.model = model
+        names = select_params(model, self.params_spec)
+        model.configure_training(set(names), self.no_decay_keys, self.treat_1d)
+        model.to(device)
+        self.rt = model.runtime(device)
+        self.rt.arena.snapshot_source()
+        self.rt.snapshot_buffers()
+        self._graphs.clear()
+        return self
+
+    # ------------------------------------------------------------------ one step
+    def _step_launches(self, x_cl: torch.Tensor, present: Optional[Sequence[bool]]) -> None:
+        rt, ar = self.rt, self.rt.arena
+        rt.training = True
+        rt.pack_all()
+        logits = rt.forward_cl(x_cl) if present is None else rt.forward_cl(x_cl, present=present)
+        n, d, h, w, r = logits.shape
+        dlogits = rt.pool.cl("dlogits", n, d, h, w, r, ldc=(r + 3) // 4 * 4)
+        partial = rt.pool.flat("ent_partial", ops.entropy_partials(logits), dtype=torch.float64)
+        loss = rt.pool.flat("ent_loss", 1)
+        ops.entropy_loss(logits, dlogits, partial, loss, softmax=self.softmax)
+        if ar.n_train > 0:
+            rt.backward_cl(dlogits)
+            ops.adam_step(ar.params[:ar.n_train], ar.grads[:ar.n_train], ar.exp_avg[:ar.n_train],
+                          ar.exp_avg_sq[:ar.n_train], ar.n_decay, self.lr, self.beta1, self.beta2, self.eps,
+                          self.weight_decay, ar.step)
+
+    def _step(self, x_cl: torch.Tensor, present: Optional[Sequence[bool]]) -> None:
+        if not self.use_graph:
+            self._step_launches(x_cl, present)
+            return
+        key = (tuple(x_cl.shape), x_cl.data_ptr(), None if present is None else tuple(present))
+        g = self._graphs.get(key)
+        if g is None:
+            # eager warm-up (allocates every buffer, sizes the workspace), then capture
+            side = torch.cuda.Stream(device=x_cl.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._step_launches(x_cl, present)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            try:
+                ops.Workspace.frozen = True
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_launches(x_cl, present)
+            except Exception as exc:  # capture is an optimisation: the eager launches are the same kernels
+                warnings.warn(f"hipGraph capture failed ({exc}); running the step eagerly")
+                self.use_graph = False
+                g = None
+            finally:
+                ops.Workspace.frozen = False
+            self._graphs[key] = g
+            return  # the warm-up already performed this step
+        g.replay()
+
+    # ------------------------------------------------------------------ per volume
+    @torch.no_grad()
+    def adapt_volume(self, x: torch.Tensor, steps: Optional[int] = None) -> Dict[str, Any]:
+        """x: [1,C,D,H,W] fp32 on the plugin's device.  Returns final logits (NCDHW) and per-step losses."""
+        if self.rt is None:
+            raise MmttaError("call setup(model, device) first")
+        rt, ar = self.rt, self.rt.arena
+        steps = self.steps if steps is None else int(steps)
+        if self.episodic:
+            ar.restore_source()
+            rt.restore_buffers()
+        C = x.shape[1]
+        masked = bool(self.missing) or self.moddrop_p > 0.0
+        gen = torch.Generator().manual_seed(self.moddrop_seed) if self.moddrop_p > 0.0 else None
+        base_present = modality_mask(C, self.missing, 0.0, None)
+        x = x.float()
+        x_cl = rt.stage_input(drop_modality(x, base_present) if masked else x)
+        loss_hist = rt.pool.flat("loss_hist", max(steps, 1))
+        loss_buf = rt.pool.flat("ent_loss", 1)
+        wants_present = masked and getattr(rt, "supports_present", False)
+        for t in range(steps):
+            present = None
+            if masked:
+                p = modality_mask(C, self.missing, self.moddrop_p, gen)
+                if self.moddrop_p > 0.0:
+                    rt.stage_input(drop_modality(x, p))
+                present = p if wants_present else None
+            self._step(x_cl, present)
+            loss_hist[t:t + 1].copy_(loss_buf)
+        if masked and self.moddrop_p > 0.0:
+            rt.stage_input(drop_modality(x, base_present))
+        rt.training = False
+        rt.pack_all()
+        logits_cl = (rt.forward_cl(x_cl, present=base_present) if wants_present else rt.forward_cl(x_cl))
+        return {"logits_cl": logits_cl, "losses": loss_hist[:steps]}
+
+    def logits(self, result: Dict[str, Any]) -> torch.Tensor:
+        return ops.from_cl(result["logits_cl"])

@@ -1,0 +1,245 @@
+"""Parity of the HBM-bound kernels against torch CPU fp32 primitives, through the C ABI:
+norm statistics / norm(+ReLU) backward (instance, batch, group), combine, trilinear x2 and its
+adjoint, linear combinations, the entropy objectives, fused Adam, mask + Dice counts.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(name, got, ref, rel=2e-5, abs_=2e-6):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= rel * scale + abs_, f"{name}: max|err|={err:.3e} (max|ref|={scale:.3e})"
+
+
+def cl(x):
+    from multimodal_tta_amd import ops
+    return ops.to_cl(x.cuda().contiguous())
+
+
+def ncdhw(x_cl):
+    return x_cl.permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def test_layout_roundtrip():
+    from multimodal_tta_amd import ops
+    x = torch.randn(2, 3, 5, 6, 7)
+    xc = ops.to_cl(x.cuda())
+    assert xc.shape == (2, 5, 6, 7, 3) and xc.stride(-1) == 1 and xc.stride(-2) == 4
+    assert torch.equal(ncdhw(xc), x)
+    back = ops.from_cl(xc)
+    assert back.is_contiguous() and torch.equal(back.cpu(), x)
+
+
+NORM_CASES = [
+    ("INSTANCE", 1, (2, 5, 7, 6, 5), False),
+    ("INSTANCE", 1, (1, 32, 16, 16, 16), False),
+    ("BATCH", 1, (2, 8, 6, 6, 6), True),
+    ("GROUP", 4, (2, 8, 6, 6, 6), True),
+    ("INSTANCE", 1, (1, 3, 24, 24, 24), False),
+]
+
+
+@pytest.mark.parametrize("kind,groups,shape,affine", NORM_CASES)
+def test_norm_forward_backward(kind, groups, shape, affine):
+    """y -> relu(norm(y)): statistics from channel_stats partials, applied by combine; backward by the
+    reduce / finalize / apply triple; BatchNorm also checks the running-statistics EMA."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(3)
+    n, c, d, h, w = shape
+    y = (torch.randn(shape) * 1.7 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(c) + 0.5).requires_grad_(True) if affine else None
+    beta = (torch.randn(c) * 0.1).requires_grad_(True) if affine else None
+    rm, rv = torch.zeros(c), torch.ones(c)
+    if kind == "INSTANCE":
+        ref = F.relu(F.instance_norm(y, eps=1e-5))
+    elif kind == "BATCH":
+        ref = F.relu(F.batch_norm(y, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5))
+    else:
+        ref = F.relu(F.group_norm(y, groups, gamma, beta, eps=1e-5))
+    gout = torch.randn_like(ref)
+    ref.backward(gout)
+
+    y_cl = cl(y.detach())
+    rows = ops.reduce_rows_per_n(y_cl)
+    part = torch.empty(n * rows * 2 * c, device="cuda")
+    ops.channel_stats(y_cl, part)
+    mean = torch.empty(n * c, device="cuda")
+    rstd = torch.empty(n * c, device="cuda")
+    scratch = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
+    g_d = gamma.detach().cuda() if affine else None
+    b_d = beta.detach().cuda() if affine else None
+    rm_d, rv_d = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    k = ops.NORM_KINDS[kind]
+    ops.norm_stats_finalize(k, groups, part, rows, n, c, d * h * w, 1e-5, True, rm_d, rv_d, 0.1, mean, rstd, scratch)
+    nl = ops.NL(mean, rstd, g_d, b_d, relu=True)
+    out = torch.empty_like(y_cl)
+    ops.combine(y_cl, nl, None, None, out)
+    torch.cuda.synchronize()
+    close("norm+relu forward", ncdhw(out), ref)
+    if kind == "BATCH":
+        close("running_mean", rm_d, rm, rel=1e-5)
+        close("running_var", rv_d, rv, rel=1e-5)
+
+    dT = cl(gout)
+    bpart = torch.empty(n * rows * 2 * c, device="cuda")
+    m1, m2 = torch.empty(n * c, device="cuda"), torch.empty(n * c, device="cuda")
+    dg = torch.zeros(c, device="cuda") if affine else None
+    db = torch.zeros(c, device="cuda") if affine else None
+    ops.norm_bwd_reduce(dT, y_cl, nl, bpart)
+    ops.norm_bwd_finalize(k, groups, bpart, rows, n, c, d * h * w, g_d, True, m1, m2, dg, db, False, scratch)
+    dy = torch.empty_like(y_cl)
+    ops.norm_bwd_apply(dT, y_cl, nl, m1, m2, dy)
+    torch.cuda.synchronize()
+    close("norm backward dx", ncdhw(dy), y.grad, rel=2e-4, abs_=2e-6)
+    if affine:
+        close("dgamma", dg, gamma.grad, rel=2e-4, abs_=1e-4)
+        close("dbeta", db, beta.grad, rel=2e-4, abs_=1e-4)
+
+
+def test_batchnorm_eval_uses_running_stats():
+    from multimodal_tta_amd import ops
+    torch.manual_seed(5)
+    n, c, d, h, w = 2, 4, 4, 4, 4
+    y = torch.randn(n, c, d, h, w)
+    rm, rv = torch.randn(c) * 0.2, torch.rand(c) + 0.5
+    gamma, beta = torch.rand(c) + 0.5, torch.randn(c) * 0.1
+    ref = F.relu(F.batch_norm(y, rm, rv, gamma, beta, training=False, eps=1e-5))
+    mean, rstd = torch.empty(n * c, device="cuda"), torch.empty(n * c, device="cuda")
+    scratch = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
+    ops.norm_stats_finalize(ops.NORM_BATCH, 1, None, 0, n, c, d * h * w, 1e-5, False, rm.cuda(), rv.cuda(), 0.1, mean,
+                            rstd, scratch)
+    y_cl = cl(y)
+    out = torch.empty_like(y_cl)
+    ops.combine(y_cl, ops.NL(mean, rstd, gamma.cuda(), beta.cuda(), True), None, None, out)
+    torch.cuda.synchronize()
+    close("bn eval", ncdhw(out), ref)
+
+
+def test_combine_two_sources_and_slices():
+    from multimodal_tta_amd import ops
+    torch.manual_seed(9)
+    n, c, d, h, w = 1, 6, 4, 5, 6     # c % 4 != 0 -> scalar path
+    a, b = torch.randn(n, c, d, h, w), torch.randn(n, c, d, h, w)
+    ref = F.relu(F.instance_norm(a)) + b
+    mu = a.mean(dim=(2, 3, 4)).reshape(-1).cuda()
+    rs = (1 / torch.sqrt(a.var(dim=(2, 3, 4), unbiased=False) + 1e-5)).reshape(-1).cuda()
+    wide = torch.zeros(n, d, h, w, 16, device="cuda")
+    ops.combine(cl(a), ops.NL(mu, rs, relu=True), cl(b), None, wide[..., 4:10])
+    torch.cuda.synchronize()
+    close("combine", ncdhw(wide[..., 4:10]), ref)
+    assert wide[..., :4].abs().max().item() == 0 and wide[..., 10:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 3, 4, 5), (2, 8, 4, 4, 4), (1, 4, 1, 2, 3)])
+def test_upsample_trilinear(shape):
+    from multimodal_tta_amd import ops
+    torch.manual_seed(2)
+    x = torch.randn(shape, requires_grad=True)
+    up = torch.nn.Upsample(scale_factor=(2.0, 2.0, 2.0), mode="trilinear", align_corners=True)
+    ref = up(x)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    n, c, d, h, w = shape
+    x_cl = cl(x.detach())
+    y_cl = ops.new_cl(n, 2 * d, 2 * h, 2 * w, c, "cuda")
+    ops.upsample2x_fwd(x_cl, y_cl)
+    dx_cl = ops.new_cl(n, d, h, w, c, "cuda")
+    ops.upsample2x_bwd(cl(g), dx_cl)
+    torch.cuda.synchronize()
+    close("upsample fwd", ncdhw(y_cl), ref, rel=1e-5, abs_=1e-6)
+    close("upsample bwd", ncdhw(dx_cl), x.grad, rel=1e-5, abs_=1e-5)
+
+
+def test_lincomb_mean_and_accumulate():
+    from multimodal_tta_amd import ops
+    torch.manual_seed(4)
+    xs = [torch.randn(1, 8, 4, 4, 4) for _ in range(4)]
+    out = ops.new_cl(1, 4, 4, 4, 8, "cuda")
+    ops.lincomb([cl(t) for t in xs], [0.25] * 4, out)
+    torch.cuda.synchronize()
+    close("mean of 4", ncdhw(out), torch.stack(xs).mean(0))
+    ops.lincomb([cl(xs[0])], [2.0], out, accumulate=True)
+    torch.cuda.synchronize()
+    close("accumulate", ncdhw(out), torch.stack(xs).mean(0) + 2 * xs[0])
+
+
+@pytest.mark.parametrize("softmax", [False, True])
+@pytest.mark.parametrize("shape", [(1, 3, 8, 8, 8), (2, 1, 5, 6, 7), (1, 4, 16, 16, 16)])
+def test_entropy_loss(softmax, shape):
+    from multimodal_tta_amd import ops
+    torch.manual_seed(6)
+    z = (torch.randn(shape) * 3).requires_grad_(True)
+    if softmax:
+        logp = F.log_softmax(z, dim=1)
+        ref = -(logp.exp() * logp).sum(1).mean()
+    else:
+        ref = (F.softplus(z) - z * torch.sigmoid(z)).mean()
+    ref.backward()
+    z_cl = cl(z.detach())
+    g_cl = torch.empty_like(z_cl)
+    partial = torch.empty(ops.entropy_partials(z_cl), dtype=torch.float64, device="cuda")
+    loss = torch.empty(1, device="cuda")
+    ops.entropy_loss(z_cl, g_cl, partial, loss, softmax=softmax)
+    torch.cuda.synchronize()
+    close("loss", loss.cpu().reshape(()), ref, rel=2e-6, abs_=1e-7)
+    close("dloss/dlogits", ncdhw(g_cl), z.grad, rel=2e-5, abs_=1e-9)
+
+
+def test_adam_matches_torch_over_steps():
+    """Two-segment fused Adam == torch.optim.Adam with the reference's decay / no-decay groups
+    (reference src/core/experiment_manager.py:214-228; defaults configs/training/default.yaml:30-39)."""
+    from multimodal_tta_amd import ops
+    torch.manual_seed(8)
+    n_decay, n_nodecay = 1000, 37
+    n = n_decay + n_nodecay
+    p0 = torch.randn(n)
+    pd = torch.nn.Parameter(p0[:n_decay].clone())
+    pn = torch.nn.Parameter(p0[n_decay:].clone())
+    lr, betas, eps, wd = 1e-3, (0.9, 0.9999), 1e-8, 5e-4
+    opt = torch.optim.Adam([{"params": [pd], "weight_decay": wd}, {"params": [pn], "weight_decay": 0.0}], lr=lr,
+                           betas=betas, eps=eps)
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for t in range(5):
+        g = torch.randn(n) * (10.0 ** (-t))
+        pd.grad, pn.grad = g[:n_decay].clone(), g[n_decay:].clone()
+        opt.step()
+        ops.adam_step(p, g.cuda(), m, v, n_decay, lr, betas[0], betas[1], eps, wd, step)
+    torch.cuda.synchronize()
+    assert int(step.item()) == 5
+    ref = torch.cat([pd.detach(), pn.detach()])
+    close("adam params", p, ref, rel=1e-6, abs_=2e-7)
+
+
+@pytest.mark.parametrize("R,thr,shape", [(3, 0.5, (2, 8, 8, 8)), (1, 0.3, (1, 6, 10, 12)), (3, 0.5, (1, 32, 32, 32))])
+def test_mask_dice_counts_exact(R, thr, shape):
+    """Integer counts are bit exact against the reference formulas (src/evaluation/seg_eval.py:41-68,304-306)."""
+    from multimodal_tta_amd import ops
+    torch.manual_seed(10)
+    n, d, h, w = shape
+    z = torch.randn(n, R, d, h, w) * 2
+    z[0, 0, 0, 0, :4] = torch.tensor([0.0, -1e-9, 1e-9, math.log(thr / (1 - thr))])
+    lab = (torch.rand(n, R, d, h, w) > 0.6).float()
+    lab[0, R - 1] = 0.0   # empty-GT region
+    pred = (torch.sigmoid(z) >= thr).to(torch.uint8)
+    gt = (lab > 0.5).to(torch.uint8)
+    pf, gf = pred.reshape(n, R, -1).float(), gt.reshape(n, R, -1).float()
+    ref = torch.stack([(pf * gf).sum(-1), pf.sum(-1), gf.sum(-1)], dim=-1).long()
+    counts = torch.empty(n, R, 3, dtype=torch.int64, device="cuda")
+    mask = torch.empty(n, R, d, h, w, dtype=torch.uint8, device="cuda")
+    ops.mask_dice_counts(cl(z), lab.cuda(), thr, counts, mask)
+    torch.cuda.synchronize()
+    mism = (mask.cpu() != pred).sum().item()
+    assert mism <= 1, f"{mism} mask voxels differ (only the exact-threshold voxel may, by 1 ulp of expf)"
+    if mism == 0:
+        assert torch.equal(counts.cpu(), ref)
