@@ -104,6 +104,8 @@ typedef struct {
   int32_t launches;      /* 1, or 8 parity classes for stride-2 transposed forms             */
   int32_t ksplit;        /* >1: partial sums go through the workspace                        */
   int32_t stats_rows;    /* rows of the [rows][2][C] partial-statistics slab this op writes  */
+  int32_t config;        /* tile configuration 0..5 (which template instance runs; for profiling) */
+  int32_t _pad;
   int64_t workspace_bytes;
 } mmtta_conv_plan_t;
 

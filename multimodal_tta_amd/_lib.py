@@ -48,7 +48,7 @@ class ConvDesc(C.Structure):
 class ConvPlan(C.Structure):
     _fields_ = [
         ("tiles", C.c_int32), ("launches", C.c_int32), ("ksplit", C.c_int32), ("stats_rows", C.c_int32),
-        ("workspace_bytes", C.c_int64),
+        ("config", C.c_int32), ("_pad", C.c_int32), ("workspace_bytes", C.c_int64),
     ]
 
 

@@ -557,6 +557,8 @@ extern "C" int mmtta_conv_plan(const mmtta_conv_desc* d, const mmtta_tensor* x, 
   plan->launches = g.launches;
   plan->ksplit = g.ksplit;
   plan->stats_rows = g.launches * g.tiles;
+  plan->config = (g.si == 1 ? 0 : 3) + (g.cfg.NB == 1 ? 0 : (g.cfg.NB == 2 ? 1 : 2));
+  plan->_pad = 0;
   plan->workspace_bytes =
       g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * (int64_t)sizeof(float) : 0;
   return MMTTA_OK;

@@ -1,0 +1,282 @@
+"""``unet_multimodal_deepfusion`` / ``unet_multimodal_midfusion``: the reference's multimodal deep-fusion
+U-Net (reference src/models/unet_multimodal_midfusion.py:16-270), computed by libmmtta.so.
+
+Same registry names (:139-140), config keys and defaults (:147-160), ``state_dict`` keys (SURVEY.md
+Appendix A.6) and ``forward`` contract (:204-209).  What the MI355X build does differently from the
+reference's Python-serial graph:
+
+* the M per-modality encoders read their modality straight out of the channels-last input (a C=1
+  channel slice) - no ``torch.split``;
+* every ``torch.stack(...).mean`` (:221, :229, :247) is one linear-combination kernel that writes
+  into the consumer's concat slice; every ``torch.cat`` (:94, :135, :223) is a slice write;
+* the fusion convolution's weights are shared by the M calls (:222): its weight gradient accumulates
+  across calls in the same arena slot;
+* ``fused_skips[3]`` (computed and discarded by the reference, :226-229/:250) is not computed.
+
+``present`` (missing-modality configs): means run over present modalities only,
+an absent branch feeds the shared mean to ``bottleneck_reduce`` and its encoder is skipped.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..config import as_cfg, get_config
+from ..engine import (ConvolutionBlock, Runtime, build_convolution, build_residual_unit)
+from ..registry import register_model
+from .base import HipSegModel
+from .containers import Convolution, Holder, ResidualUnit, UpSample
+
+
+class SpecificEncoder(Holder):
+    def __init__(self, in_channels, channels, strides, num_res_units, act, norm, dropout):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        cur = in_channels
+        for out_ch, s in zip(channels, list(strides) + [1]):
+            self.layers.append(ResidualUnit(cur, out_ch, strides=s, kernel_size=3, subunits=num_res_units, act=act,
+                                            norm=norm, dropout=dropout))
+            cur = out_ch
+
+
+class CompositionalLayer(Holder):
+    def __init__(self, in_channels, norm, act):
+        super().__init__()
+        self.fusion_conv = Convolution(in_channels * 2, in_channels, kernel_size=3, strides=1, act=act, norm=norm)
+
+
+class DecoderStage(Holder):
+    def __init__(self, in_channels, skip_channels, out_channels, stride, num_res_units, act, norm, dropout):
+        super().__init__()
+        self.upsample = UpSample(in_channels, out_channels, scale_factor=stride)
+        self.conv = ResidualUnit(out_channels + skip_channels, out_channels, strides=1, kernel_size=3,
+                                 subunits=num_res_units, act=act, norm=norm, dropout=dropout)
+
+
+class DeepFusionRuntime(Runtime):
+    supports_present = True
+
+    def __init__(self, model: "MultimodalUNetDeepFusion", device: torch.device):
+        super().__init__(device)
+        self.M = model.num_modalities
+        self.in_channels = self.M
+        self.channels = list(model.channels)
+        self.out_channels = model.num_classes
+        c = self.channels
+        self.enc = [[build_residual_unit(self, f"specific_encoders.{m}.layers.{i}", ru)
+                     for i, ru in enumerate(encm.layers)] for m, encm in enumerate(model.specific_encoders)]
+        first = build_convolution(self, "fusion_layer.fusion_conv", model.fusion_layer.fusion_conv)
+        # one block object per call site; all share the first one's conv / norm layers (shared weights)
+        self.fusion = [first] + [ConvolutionBlock(self, first.conv, first.norm) for _ in range(self.M - 1)]
+        self.bott = self.make_conv("bottleneck_reduce", model.bottleneck_reduce)
+        self.pre, self.dec = [], []
+        for j, st in enumerate(model.decoder_stages):
+            if not hasattr(st.upsample, "preconv"):
+                raise NotImplementedError("decoder stage without preconv (in_channels == out_channels)")
+            self.pre.append(self.make_conv(f"decoder_stages.{j}.upsample.preconv", st.upsample.preconv))
+            self.dec.append(build_residual_unit(self, f"decoder_stages.{j}.conv", st.conv))
+        self.final = self.make_conv("final_conv", model.final_conv)
+        self.nstage = len(self.dec)
+
+    # ---------------------------------------------------------------- forward
+    def forward_cl(self, x_cl: torch.Tensor, present: Optional[Sequence[bool]] = None) -> torch.Tensor:
+        n, D, H, W, M = x_cl.shape
+        if M != self.M:
+            raise ValueError(f"model has {self.M} modality encoders but the input has {M} channels "
+                             "(reference: zip() would silently truncate, unet_multimodal_midfusion.py:214)")
+        f = 2 ** (len(self.channels) - 1)
+        if D % f or H % f or W % f:
+            raise ValueError(f"input extent {(D, H, W)} is not divisible by {f}")
+        keep = [m for m in range(M) if present is None or present[m]]
+        if not keep:
+            raise ValueError("at least one modality must be present")
+        K = len(keep)
+        c, pool = self.channels, self.pool
+        nlev = len(c)                                  # 5 encoder layers
+        dims = [(D, H, W)]
+        for i in range(nlev - 1):
+            d, h, w = dims[-1]
+            dims.append((d // 2, h // 2, w // 2))
+        bd = dims[nlev - 1]                            # bottleneck extent (layer 4 keeps it)
+        self.state = dict(n=n, dims=dims, keep=keep, x=x_cl)
+        # encoders ---------------------------------------------------------------------------------
+        skips: List[List[torch.Tensor]] = [[None] * M for _ in range(nlev - 1)]
+        catf = [pool.cl(("catf", m), n, *bd, 2 * c[-1]) for m in range(M)]
+        for m in keep:
+            cur = x_cl[..., m:m + 1]
+            for i in range(nlev - 1):
+                out = pool.cl(("skip", m, i), n, *dims[i + 1], c[i])
+                self.enc[m][i].fwd(cur, None, out)
+                skips[i][m] = out
+                cur = out
+            self.enc[m][nlev - 1].fwd(cur, None, catf[m][..., c[-1]:])
+        # fusion -----------------------------------------------------------------------------------
+        shared = pool.cl("shared", n, *bd, c[-1])
+        ops.lincomb([catf[m][..., c[-1]:] for m in keep], [1.0 / K] * K, shared)
+        bcat = pool.cl("bcat", n, *bd, M * c[-1])
+        for m in range(M):
+            dst = bcat[..., m * c[-1]:(m + 1) * c[-1]]
+            if m in keep:
+                ops.lincomb([shared], [1.0], catf[m][..., :c[-1]])
+                y, nl = self.fusion[m].fwd(catf[m], None)
+                ops.combine(y, nl, shared, None, dst)
+            else:
+                ops.lincomb([shared], [1.0], dst)
+        xdec = pool.cl(("xdec", -1), n, *bd, c[-1])
+        self.bott.op.forward(bcat, None, None, xdec)
+        # decoder ----------------------------------------------------------------------------------
+        skip_src = [2, 1, 0, None]                     # fused_skips[2], [1], [0], input mean
+        cur = xdec
+        self.cats = []
+        for j in range(self.nstage):
+            cin, cout = c[nlev - 1 - j], c[nlev - 2 - j]
+            lo, hi = dims[nlev - 1 - j], dims[nlev - 2 - j]
+            p = pool.cl(("pre", j), n, *lo, cout)
+            self.pre[j].op.forward(cur, None, self.pre[j].bias_data(), p)
+            sc = c[skip_src[j]] if skip_src[j] is not None else 1
+            cat = pool.cl(("dcat_in", j), n, *hi, cout + sc, ldc=(cout + sc + 3) // 4 * 4)
+            ops.upsample2x_fwd(p, cat[..., :cout])
+            if skip_src[j] is not None:
+                ops.lincomb([skips[skip_src[j]][m] for m in keep], [1.0 / K] * K, cat[..., cout:])
+            else:
+                ops.lincomb([x_cl[..., m:m + 1] for m in keep], [1.0 / K] * K, cat[..., cout:])
+            out = pool.cl(("xdec", j), n, *hi, cout)
+            self.dec[j].fwd(cat, None, out)
+            self.cats.append((cur, p, cat))
+            cur = out
+        logits = pool.cl("logits", n, D, H, W, self.out_channels, ldc=(self.out_channels + 3) // 4 * 4)
+        self.final.op.forward(cur, None, self.final.bias_data(), logits)
+        self.state.update(catf=catf, shared=shared, bcat=bcat, xdec=xdec, last=cur, skips=skips)
+        return logits
+
+    # ---------------------------------------------------------------- backward
+    def backward_cl(self, dlogits: torch.Tensor) -> None:
+        st, pool, c = self.state, self.pool, self.channels
+        n, dims, keep = st["n"], st["dims"], st["keep"]
+        K, M, nlev = len(keep), self.M, len(c)
+        bd = dims[nlev - 1]
+        # silent parameters of this step (encoders of absent modalities) contribute a zero gradient
+        for m in range(M):
+            if m not in keep:
+                for ru in self.enc[m]:
+                    for unit in ru.units:
+                        unit.conv.weight.grad.zero_()
+                        if unit.conv.bias is not None:
+                            unit.conv.bias.grad.zero_()
+                    if ru.residual is not None:
+                        ru.residual.weight.grad.zero_()
+                        if ru.residual.bias is not None:
+                            ru.residual.bias.grad.zero_()
+        last = st["last"]
+        self.final.wgrad(last, None, dlogits)
+        d = pool.cl(("dxdec", self.nstage - 1), *last.shape)
+        self.final.op.dgrad(dlogits, d)
+        dskips = {}
+        for j in range(self.nstage - 1, -1, -1):
+            src, p, cat = self.cats[j]
+            cout = p.shape[-1]
+            dcat = pool.cl(("dcat", j), *cat.shape[:4], cat.shape[-1], ldc=(cat.shape[-1] + 3) // 4 * 4)
+            self.dec[j].bwd(d, dcat, accumulate=False, need_dx=True)
+            dskips[j] = dcat[..., cout:]
+            dp = pool.cl(("dpre", j), *p.shape)
+            ops.upsample2x_bwd(dcat[..., :cout], dp)
+            self.pre[j].wgrad(src, None, dp)
+            d = pool.cl(("dxdec", j - 1), *src.shape)
+            self.pre[j].op.dgrad(dp, d)
+        bcat = st["bcat"]
+        self.bott.wgrad(bcat, None, d)
+        dbcat = pool.cl("dbcat", *bcat.shape)
+        self.bott.op.dgrad(d, dbcat)
+        # fusion: fused_m = shared + T(conv(cat[shared, feat_m]))
+        dcatf = {}
+        terms = []
+        for idx, m in enumerate(keep):
+            dfused = dbcat[..., m * c[-1]:(m + 1) * c[-1]]
+            dcatf[m] = pool.cl(("dcatf", m), *st["catf"][m].shape)
+            self.fusion[m].bwd(dfused, dcatf[m], accumulate=False, need_dx=True, grad_accumulate=idx > 0)
+            terms += [dfused, dcatf[m][..., :c[-1]]]
+        for m in range(M):
+            if m not in keep:
+                terms.append(dbcat[..., m * c[-1]:(m + 1) * c[-1]])
+        dshared = pool.cl("dshared", *st["shared"].shape)
+        for k0 in range(0, len(terms), 8):
+            chunk = terms[k0:k0 + 8]
+            ops.lincomb(chunk, [1.0] * len(chunk), dshared, accumulate=k0 > 0)
+        skip_src = [2, 1, 0, None]
+        for m in keep:
+            dfeat = dcatf[m][..., c[-1]:]
+            ops.lincomb([dshared], [1.0 / K], dfeat, accumulate=True)
+            dout = dfeat
+            for i in range(nlev - 1, -1, -1):
+                if i == 0:
+                    self.enc[m][0].bwd(dout, None, need_dx=False)
+                    break
+                dx = pool.cl(("dskip", m, i - 1), *st["skips"][i - 1][m].shape)
+                stage = skip_src.index(i - 1) if (i - 1) in skip_src else None
+                if stage is not None:
+                    ops.lincomb([dskips[stage]], [1.0 / K], dx)
+                    self.enc[m][i].bwd(dout, dx, accumulate=True, need_dx=True)
+                else:
+                    self.enc[m][i].bwd(dout, dx, accumulate=False, need_dx=True)
+                dout = dx
+
+
+@register_model("unet_multimodal_deepfusion")
+@register_model("unet_multimodal_midfusion")
+class MultimodalUNetDeepFusion(HipSegModel):
+    runtime_cls = DeepFusionRuntime
+
+    def __init__(self, cfg: Dict[str, Any]):
+        super().__init__()
+        cfg = as_cfg(cfg)
+        self.num_modalities = int(get_config(cfg, "num_modalities", 4))
+        self.num_classes = int(get_config(cfg, "num_classes", 3))
+        if int(get_config(cfg, "spatial_dims", 3)) != 3:
+            raise NotImplementedError("the MI355X adaptation path is 3-D (spatial_dims=3)")
+        self.channels = list(get_config(cfg, "channels", [32, 64, 128, 256, 512]))
+        strides = list(get_config(cfg, "strides", [2, 2, 2, 2]))
+        nru = int(get_config(cfg, "num_res_units", 2))
+        act = get_config(cfg, "act", "RELU")
+        norm = get_config(cfg, "norm", "INSTANCE")
+        dropout = float(get_config(cfg, "dropout", 0.0))
+        if len(self.channels) != 5 or strides != [2, 2, 2, 2]:
+            raise NotImplementedError("deep-fusion decoder is wired for 5 channel levels and strides [2,2,2,2] "
+                                      "(reference unet_multimodal_midfusion.py:171-193)")
+        dom = get_config(cfg, "domain_classifier", {}) or {}
+        self.domain_enabled = bool(get_config(dom, "enabled", True))
+        self.domain_loss_weight = float(get_config(dom, "loss_weight", 0.1))
+        ch = self.channels
+        self.specific_encoders = nn.ModuleList(
+            [SpecificEncoder(1, ch, strides, nru, act, norm, dropout) for _ in range(self.num_modalities)])
+        self.fusion_layer = CompositionalLayer(ch[-1], norm, act)
+        self.bottleneck_reduce = nn.Conv3d(ch[-1] * self.num_modalities, ch[-1], 1, bias=False)
+        self.decoder_stages = nn.ModuleList()
+        skip_ch = [ch[2], ch[1], ch[0], 1]
+        for i in range(len(ch) - 1):
+            idx = len(ch) - 1 - i
+            self.decoder_stages.append(DecoderStage(ch[idx], skip_ch[i], ch[idx - 1], strides[idx - 1], nru, act, norm,
+                                                    dropout))
+        self.final_conv = nn.Conv3d(ch[0], self.num_classes, kernel_size=1)
+        if self.domain_enabled:
+            self.domain_classifier = nn.Linear(ch[-1], self.num_modalities)
+
+    def forward(self, x: torch.Tensor, return_domain_logits: bool = False,
+                return_intermediate_features: bool = False, present: Optional[Sequence[bool]] = None):
+        if return_domain_logits or return_intermediate_features:
+            raise NotImplementedError(
+                "domain logits / intermediate features are auxiliary training outputs the reference trainer never "
+                "requests (src/core/trainers/seg_trainer.py:110); they are outside the adaptation hot path")
+        if present is not None:
+            if x.device.type != "cuda":
+                raise ops.MmttaError("this model computes on an MI355X through libmmtta.so")
+            rt = self.runtime(x.device)
+            rt.training = self.training
+            rt.pack_all()
+            return ops.from_cl(rt.forward_cl(rt.stage_input(x.float()), present=present))
+        return super().forward(x)
+
+    def get_domain_loss_weight(self) -> float:
+        return self.domain_loss_weight if getattr(self, "domain_enabled", False) else 0.0

@@ -99,6 +99,43 @@ def from_cl(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor
     return out
 
 
+# ----------------------------------------------------------------------------- profiling hook
+IGEMM_KERNELS = ["igemm_f32_kernel<1,4,8,8,8,8>", "igemm_f32_kernel<2,4,4,8,8,16>", "igemm_f32_kernel<4,4,4,4,8,32>",
+                 "igemm_f32_kernel<1,1,4,4,8,8>", "igemm_f32_kernel<2,2,4,4,8,8>", "igemm_f32_kernel<4,4,4,4,8,8>"]
+
+
+class KernelProfiler:
+    """Brackets every conv launch with events on the launch stream and books its algorithmic FLOPs
+    (bench.py roofline: FLOPs per launch / measured duration).  Off unless installed in ops.PROFILER."""
+
+    def __init__(self):
+        self.records = []   # (kernel name, launches, flops, start event, end event)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name: str, launches: int, flops: float, e0) -> None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((name, launches, flops, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, launches, flops, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "calls": 0})
+            d["launches"] += launches
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+            d["calls"] += 1
+        return out
+
+
+PROFILER: Optional[KernelProfiler] = None
+
+
 # ----------------------------------------------------------------------------- convolution
 class ConvOp:
     """One Conv3d / ConvTranspose3d module's kernels: forward, input gradient, weight gradient.
@@ -168,11 +205,20 @@ class ConvOp:
         if add is not None:
             keep = desc_cl(add)
             epi = ConvEpilogue(C.pointer(keep), add_nl.struct() if add_nl is not None else _lib.norm_on_load())
+        e0 = PROFILER.begin() if PROFILER is not None else None
         check(
             _lib.load().mmtta_conv_run(
                 C.byref(desc), C.byref(dx), nlr, ptr(packed), ptr(bias), C.byref(epi) if epi is not None else None,
                 C.byref(dy), 1 if accumulate else 0, ptr(stats), ptr(ws), int(p.workspace_bytes), stream_ptr()),
             "conv_run")
+        if e0 is not None:
+            PROFILER.end(IGEMM_KERNELS[p.config], int(p.launches), self.flops(x, y, desc), e0)
+
+    def flops(self, x: torch.Tensor, y: torch.Tensor, desc=None) -> float:
+        """Algorithmic FLOPs (2 x MACs) of one forward / input-gradient / weight-gradient of this module for
+        the tensor pair (read, produced): MACs = coarse-grid voxels x Cin x Cout x taps."""
+        coarse = min(x.shape[1] * x.shape[2] * x.shape[3], y.shape[1] * y.shape[2] * y.shape[3]) * x.shape[0]
+        return 2.0 * coarse * self.cin * self.cout * self.k ** 3
 
     def forward(self, x: torch.Tensor, x_nl: Optional[NL], bias: Optional[torch.Tensor], y: torch.Tensor,
                 stats: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
@@ -191,8 +237,12 @@ class ConvOp:
             check(-1, "conv_wgrad_workspace_bytes")
         ws = Workspace.get(int(need), x.device)
         nls, nlr = _nl_ref(x_nl)
+        e0 = PROFILER.begin() if PROFILER is not None else None
         check(lib.mmtta_conv_wgrad(C.byref(self.d_fwd), C.byref(tx), nlr, C.byref(tdy), ptr(dw), ptr(db),
                                    1 if accumulate else 0, ptr(ws), int(need), stream_ptr()), "conv_wgrad")
+        if e0 is not None:
+            name = "wgrad_f32_kernel<4,4,8>" if self.stride == 1 else "wgrad_f32_kernel<2,2,8>"
+            PROFILER.end(name + "+reduce", 1, self.flops(x, dy), e0)
 
 
 # ----------------------------------------------------------------------------- normalisation

@@ -87,6 +87,12 @@ def adapt_volume(
         loss = entropy_loss(z, softmax=softmax)
         if opt is not None:
             loss.backward()
+            if masked_means:
+                # a branch that is absent this step contributes a ZERO gradient (its Adam moments and the
+                # coupled weight decay still advance) - torch would otherwise skip parameters whose grad is None
+                for _, p in named:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
             opt.step()
         losses.append(float(loss.item()))
     model.eval()

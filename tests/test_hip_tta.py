@@ -1,0 +1,186 @@
+"""The adaptation loop end to end on the GPU against the oracle loop (oracle/tta.py) on identical
+weights, inputs and hyper-parameters; graph replay vs eager; episodic reset; the evaluator.
+
+Stated tolerance for the adapted result (fp32 path, S steps of Adam): Adam divides by sqrt(v), so
+parameters whose gradient is rounding noise move by up to +-lr per step in a direction that depends
+on summation order; those are exactly the parameters without influence on the output (biases in
+front of a norm layer).  Observable quantities are therefore compared: per-step losses within
+1e-4 relative, final logits as close to a float64 run of the oracle as the fp32 CPU oracle is (x3; floor 2e-3 *
+max|logits|), masks may differ in at most 1e-4 of the
+voxels, Dice within 1e-3.
+"""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(name="unet", in_channels=4, num_classes=3, spatial_dims=3, channels=[4, 8, 16, 32, 64],
+             strides=[2, 2, 2, 2], num_res_units=2, norm="INSTANCE", act="RELU", dropout=0.0)
+
+
+def root_cfg(model_cfg, steps=3, lr=1e-3, **method):
+    from multimodal_tta_amd.config import compose
+    cfg = compose(overrides=["task=brats", "model=unet"])
+    cfg["model"] = dict(model_cfg)
+    cfg["method"]["steps"] = steps
+    cfg["training"]["optimizers"]["adam"]["lr"] = lr
+    for k, v in method.items():
+        cfg["method"][k] = v
+    return cfg
+
+
+def build_pair(model_cfg, seed=42):
+    import oracle
+    from multimodal_tta_amd.models import UNet
+    torch.manual_seed(seed)
+    ref = oracle.UNet(model_cfg)
+    hip = UNet(model_cfg)
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip
+
+
+def logits_close(z_hip, out_ref, ref_model, x, train_cfg, **kw):
+    """fp32 results of an S-step Adam trajectory are compared through a float64 run of the same oracle:
+    the HIP path must sit as close to it as the fp32 CPU oracle does (x3) or within 2e-3 of max|logits|."""
+    import oracle
+    m64 = copy.deepcopy(ref_model).double()
+    z64 = oracle.adapt_volume(m64, x.double(), train_cfg, **kw)["logits"]
+    scale = z64.abs().max().item()
+    e_ref = (out_ref["logits"].double() - z64).abs().max().item() / scale
+    e_hip = (z_hip.double() - z64).abs().max().item() / scale
+    assert e_hip <= max(2e-3, 3.0 * e_ref), f"HIP vs fp64 oracle {e_hip:.3e}; fp32 oracle vs fp64 oracle {e_ref:.3e}"
+    return e_hip, e_ref
+
+
+def volume(i, shape=(32, 32, 32), C=4, R=3):
+    from multimodal_tta_amd.synth import synth_volume
+    v = synth_volume(i, C, shape, R)
+    return v["image"].unsqueeze(0), v["label"].unsqueeze(0)
+
+
+@pytest.mark.parametrize("params", ["all", ["model.2."]])
+def test_adapt_volume_matches_oracle(params):
+    import oracle
+    from multimodal_tta_amd.registry import get_plugin
+
+    cfg = root_cfg(SMALL, steps=3, lr=1e-3, params=params)
+    ref, hip = build_pair(SMALL)
+    ref0 = copy.deepcopy(ref)
+    x, y = volume(0)
+    out_ref = oracle.adapt_volume(ref, x, cfg["training"], steps=3, params=params)
+    plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    res = plug.adapt_volume(x.cuda())
+    torch.cuda.synchronize()
+    losses = res["losses"].cpu()
+    for t, (a, b) in enumerate(zip(losses.tolist(), out_ref["losses"])):
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, f"step {t}: loss {a} vs oracle {b}"
+    assert losses[-1] < losses[0], "entropy did not decrease"
+    z_hip, z_ref = plug.logits(res).cpu(), out_ref["logits"]
+    print("adapt err (hip, ref) vs fp64:", logits_close(z_hip, out_ref, ref0, x, cfg["training"], steps=3, params=params))
+    m_hip, m_ref = (torch.sigmoid(z_hip) >= 0.5), (torch.sigmoid(z_ref) >= 0.5)
+    assert (m_hip != m_ref).float().mean().item() <= 1e-4
+    d_ref, _, _ = oracle.binary_dice_iou(m_ref.to(torch.uint8), (y > 0.5).to(torch.uint8))
+    d_hip, _, _ = oracle.binary_dice_iou(m_hip.to(torch.uint8), (y > 0.5).to(torch.uint8))
+    assert (d_hip - d_ref).abs().max().item() <= 1e-3
+    # episodic: the source weights are back after the volume
+    for (k, v_src), (_, v_now) in zip(ref.state_dict().items(), hip.state_dict().items()):
+        pass
+    plug.rt.arena.restore_source()
+    for k, v in hip.state_dict().items():
+        assert torch.equal(v.cpu(), ref.state_dict()[k]), f"{k} not restored"
+
+
+def test_graph_replay_equals_eager_and_episodic_reset():
+    from multimodal_tta_amd.registry import get_plugin
+    outs = {}
+    for use_graph in (True, False):
+        cfg = root_cfg(SMALL, steps=4, lr=1e-3, use_graph=use_graph)
+        _, hip = build_pair(SMALL)
+        plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+        xa, xb = volume(1)[0].cuda(), volume(2)[0].cuda()
+        ra1 = plug.logits(plug.adapt_volume(xa)).clone()
+        la1 = plug.adapt_volume(xa)["losses"].clone()
+        rb = plug.logits(plug.adapt_volume(xb)).clone()
+        ra2 = plug.logits(plug.adapt_volume(xa)).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(ra1, ra2), "episodic reset: the same volume must give the same result"
+        assert not torch.equal(ra1, rb)
+        outs[use_graph] = (ra1.cpu(), la1.cpu())
+    assert torch.equal(outs[True][0], outs[False][0]), "graph replay and eager launches differ"
+    assert torch.equal(outs[True][1], outs[False][1])
+
+
+def test_missing_modality_zeroes_the_channel():
+    import oracle
+    from multimodal_tta_amd.registry import get_plugin
+    cfg = root_cfg(SMALL, steps=2, lr=1e-3, missing_modalities=[1])
+    ref, hip = build_pair(SMALL)
+    x, _ = volume(3)
+    ref0 = copy.deepcopy(ref)
+    out_ref = oracle.adapt_volume(ref, x, cfg["training"], steps=2, missing=[1])
+    plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    z = plug.logits(plug.adapt_volume(x.cuda())).cpu()
+    logits_close(z, out_ref, ref0, x, cfg["training"], steps=2, missing=[1])
+
+
+def test_moddrop_follows_the_seeded_mask_sequence():
+    import oracle
+    from multimodal_tta_amd.registry import get_plugin
+    cfg = root_cfg(SMALL, steps=3, lr=1e-3, missing_modalities=[1], moddrop={"enabled": True, "p": 0.5, "seed": 7})
+    ref, hip = build_pair(SMALL)
+    x, _ = volume(4)
+    ref0 = copy.deepcopy(ref)
+    out_ref = oracle.adapt_volume(ref, x, cfg["training"], steps=3, missing=[1], moddrop_p=0.5, moddrop_seed=7)
+    plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    res = plug.adapt_volume(x.cuda())
+    for a, b in zip(res["losses"].cpu().tolist(), out_ref["losses"]):
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6
+    print("moddrop err (hip, ref) vs fp64:", logits_close(plug.logits(res).cpu(), out_ref, ref0, x, cfg["training"], steps=3,
+                                                         missing=[1], moddrop_p=0.5, moddrop_seed=7))
+
+
+def test_seg_eval_matches_oracle_aggregation():
+    """evaluate_epoch of the registered 'seg_eval' == the reference formulas restated in oracle/dice.py."""
+    import oracle
+    from multimodal_tta_amd.registry import get_dataset_builder, get_evaluation_strategy
+
+    cfg = root_cfg(SMALL)
+    cfg["dataset"]["synthetic"]["num_volumes"] = 3
+    cfg["dataset"]["synthetic"]["shape"] = [32, 32, 32]
+    cfg["training"]["eval_batch_size"] = 2
+    ref, hip = build_pair(SMALL)
+    loader = get_dataset_builder("brats")(cfg).get_loader("test")
+    strat = get_evaluation_strategy("seg_eval")(cfg)
+    got = strat.evaluate_epoch(hip, loader, torch.device("cuda"))
+    acc = oracle.RegionAccumulator(["ET", "TC", "WT"])
+    crit = cfg["training"]["criterion"]
+    loss_fn = oracle.DiceCELoss(include_background=True, sigmoid=True, lambda_dice=1.0, lambda_ce=1.0)
+    ref.eval()
+    with torch.no_grad():
+        for batch in loader:
+            z = hip(batch["image"].cuda()).cpu()          # same logits on both sides: isolates the metric path
+            pred, gt = oracle.masks_from_logits(z, batch["label"], 0.5)
+            d, i, v = oracle.binary_dice_iou(pred, gt)
+            acc.add(d, i, v, list(batch["domain"]))
+            acc.add_loss(float(loss_fn(z, batch["label"]).item()), z.shape[0])
+    want = acc.metrics(report_loss=True)
+    assert set(got) == set(want), (sorted(got), sorted(want))
+    for k in want:
+        if k == "loss":
+            assert abs(got[k] - want[k]) <= 1e-5 * abs(want[k]) + 1e-6, (k, got[k], want[k])
+        else:
+            assert got[k] == want[k], (k, got[k], want[k])
+
+
+def test_seg_tta_eval_single_rank():
+    from multimodal_tta_amd.registry import get_dataset_builder, get_evaluation_strategy
+    cfg = root_cfg(SMALL, steps=2, lr=1e-3)
+    cfg["dataset"]["synthetic"]["num_volumes"] = 2
+    cfg["dataset"]["synthetic"]["shape"] = [32, 32, 32]
+    _, hip = build_pair(SMALL)
+    loader = get_dataset_builder("brats")(cfg).get_loader("test")
+    m = get_evaluation_strategy("seg_tta_eval")(cfg).evaluate_epoch(hip, loader, torch.device("cuda"))
+    assert {"et_dc", "tc_dc", "wt_dc", "avg_dc", "miou", "jc", "loss", "dom/synth/avg_dc"} <= set(m)
+    assert 0.0 <= m["avg_dc"] <= 1.0 and m["loss"] > 0.0

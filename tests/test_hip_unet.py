@@ -25,7 +25,8 @@ def feeds_norm(model, pname: str) -> bool:
         return False
     parent = model.get_submodule(pname[:-len(".conv.bias")])
     adn = getattr(parent, "adn", None)
-    return adn is not None and hasattr(adn, "N")
+    # instance / batch norm subtract the per-channel mean; a group norm's mean spans several channels
+    return adn is not None and hasattr(adn, "N") and not isinstance(adn.N, torch.nn.GroupNorm)
 
 
 def build_pair(cfg, seed=42):
