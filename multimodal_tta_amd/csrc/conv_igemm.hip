@@ -32,8 +32,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Taps {
   int n;
+  int toff[27];   // box-relative voxel offset of the tap (filled at launch: depends on the tile template)
+  int slab[27];   // weight slab of the tap.  int32 so the kernel reads both tables with SCALAR loads
   signed char dz[27], dy[27], dx[27];
-  unsigned char slab[27];
   int zmin, ymin, xmin;
   int zext, yext, xext;
 };
@@ -90,12 +91,12 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
   const int colbase = (blockIdx.y * NB + cb) * 32;
   const bool colact = colbase < a.Np;
 
-  int rowvox[MB];
+  int rowaddr[MB];   // LDS word address of (row's voxel, channel h) inside the box
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     int zl, yl, xl;
     row_to_local<TZ, TY, TX>((mg * MB + mb) * 32 + r, zl, yl, xl);
-    rowvox[mb] = ((zl * a.si) * BY + yl * a.si) * BX + xl * a.si;
+    rowaddr[mb] = (((zl * a.si) * BY + yl * a.si) * BX + xl * a.si) * VS + h;
   }
 
   f32x16 acc[MB];
@@ -156,36 +157,52 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
 
     // ---------------- MFMA over taps x channel pairs ----------------
     if (colact) {
+      constexpr int KK = KCI / 2;
       const int kreal = min(KCI, a.Ci - c0);
-      const int kkn = (kreal + 1) >> 1;          // channel pairs that carry data
       const float* wcol = a.wp + (long long)c0 * a.Np + colbase + r + (long long)h * a.Np;
       const long long slabsz = (long long)a.Kp * a.Np;
-      float bcur[KCI / 2], bnxt[KCI / 2];
-      {
-        const float* wb = wcol + a.taps.slab[0] * slabsz;
+      const int np2 = 2 * a.Np;
+      const int ntap = a.taps.n;
+      if (kreal == KCI) {
+        // full stage: branch-free body, weight fragments one tap ahead
+        float bcur[KK], bnxt[KK];
+        {
+          const float* wb = wcol + a.taps.slab[0] * slabsz;
 #pragma unroll
-        for (int kk = 0; kk < KCI / 2; ++kk) bcur[kk] = (kk < kkn) ? wb[(long long)(2 * kk) * a.Np] : 0.f;
-      }
-      for (int tp = 0; tp < a.taps.n; ++tp) {
-        if (tp + 1 < a.taps.n) {
-          const float* wb = wcol + a.taps.slab[tp + 1] * slabsz;
-#pragma unroll
-          for (int kk = 0; kk < KCI / 2; ++kk) bnxt[kk] = (kk < kkn) ? wb[(long long)(2 * kk) * a.Np] : 0.f;
+          for (int kk = 0; kk < KK; ++kk) bcur[kk] = wb[kk * np2];
         }
-        const int toff = ((a.taps.dz[tp] - a.taps.zmin) * BY + (a.taps.dy[tp] - a.taps.ymin)) * BX +
-                         (a.taps.dx[tp] - a.taps.xmin);
+        for (int tp = 0; tp < ntap; ++tp) {
+          const int tn = min(tp + 1, ntap - 1);
+          const float* wb = wcol + a.taps.slab[tn] * slabsz;
 #pragma unroll
-        for (int kk = 0; kk < KCI / 2; ++kk) {
-          if (kk < kkn) {
+          for (int kk = 0; kk < KK; ++kk) bnxt[kk] = wb[kk * np2];
+          const int ta = a.taps.toff[tp] * VS;
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-              const float av = lds[(rowvox[mb] + toff) * VS + 2 * kk + h];
+              const float av = lds[rowaddr[mb] + ta + 2 * kk];
               acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bcur[kk], acc[mb], 0, 0, 0);
             }
           }
-        }
 #pragma unroll
-        for (int kk = 0; kk < KCI / 2; ++kk) bcur[kk] = bnxt[kk];
+          for (int kk = 0; kk < KK; ++kk) bcur[kk] = bnxt[kk];
+        }
+      } else {
+        // tail stage (Cin not a multiple of KCI): only the channel pairs that carry data
+        const int kkn = (kreal + 1) >> 1;
+        for (int tp = 0; tp < ntap; ++tp) {
+          const float* wb = wcol + a.taps.slab[tp] * slabsz;
+          const int ta = a.taps.toff[tp] * VS;
+          for (int kk = 0; kk < kkn; ++kk) {
+            const float b = wb[kk * np2];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+              const float av = lds[rowaddr[mb] + ta + 2 * kk];
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[mb], 0, 0, 0);
+            }
+          }
+        }
       }
     }
     __syncthreads();
@@ -455,7 +472,7 @@ static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t
     const int sgn = (d->op == MMTTA_CONV_DGRAD) ? -1 : 1;   // stride-1 input gradient mirrors the taps
     for (int kz = 0; kz < 3; ++kz) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
       t.dz[n] = (signed char)(sgn * (kz - 1)); t.dy[n] = (signed char)(sgn * (ky - 1));
-      t.dx[n] = (signed char)(sgn * (kx - 1)); t.slab[n] = (unsigned char)((kz * 3 + ky) * 3 + kx); ++n;
+      t.dx[n] = (signed char)(sgn * (kx - 1)); t.slab[n] = (kz * 3 + ky) * 3 + kx; ++n;
     }
   } else {
     // out index i = 2*o - 1 + k.  parity 0: k=1 reads o=g (d=0); parity 1: k=0 reads g+1, k=2 reads g.
@@ -465,7 +482,7 @@ static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t
     nz = axis(pz, kzs, dzs); ny = axis(py, kys, dys); nx = axis(px, kxs, dxs);
     for (int a = 0; a < nz; ++a) for (int b = 0; b < ny; ++b) for (int c = 0; c < nx; ++c) {
       t.dz[n] = (signed char)dzs[a]; t.dy[n] = (signed char)dys[b]; t.dx[n] = (signed char)dxs[c];
-      t.slab[n] = (unsigned char)((kzs[a] * 3 + kys[b]) * 3 + kxs[c]); ++n;
+      t.slab[n] = (kzs[a] * 3 + kys[b]) * 3 + kxs[c]; ++n;
     }
   }
   t.n = n;
@@ -480,9 +497,13 @@ static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t
 }
 
 template <int NB, int MB, int TZ, int TY, int TX, int KCI>
-static int launch_cfg(const GArgs& a, int tiles, hipStream_t s) {
+static int launch_cfg(const GArgs& a_in, int tiles, hipStream_t s) {
+  GArgs a = a_in;
   const int BZ = (TZ - 1) * a.si + a.taps.zext + 1, BY = (TY - 1) * a.si + a.taps.yext + 1,
             BX = (TX - 1) * a.si + a.taps.xext + 1;
+  for (int t = 0; t < a.taps.n; ++t)
+    a.taps.toff[t] = ((a.taps.dz[t] - a.taps.zmin) * BY + (a.taps.dy[t] - a.taps.ymin)) * BX +
+                     (a.taps.dx[t] - a.taps.xmin);
   size_t lds = (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
   if (lds < 4 * 2 * 32 * sizeof(float)) lds = 4 * 2 * 32 * sizeof(float);
   MMTTA_CHECK(lds <= 160 * 1024, MMTTA_ERR_UNSUPPORTED, "conv: LDS box of %zu bytes exceeds 160 KiB", lds);

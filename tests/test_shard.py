@@ -1,0 +1,82 @@
+"""Sharding and the gather/merge of per-volume results: N simulated ranks == one rank, and a real
+2-process gloo run of the single collective of the path."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from multimodal_tta_amd.evaluation import (RegionAccumulator, gather_table, metrics_from_table, shard_indices,
+                                           table_width)
+
+R = 3
+REGIONS = ["ET", "TC", "WT"]
+
+
+def fake_rows(n):
+    g = torch.Generator().manual_seed(5)
+    rows = []
+    for i in range(n):
+        dice, iou = torch.rand(R, generator=g, dtype=torch.float64), torch.rand(R, generator=g, dtype=torch.float64)
+        valid = (torch.rand(R, generator=g) > 0.3).double()
+        rows.append(torch.cat([torch.tensor([i, i % 2, 0.1 * i], dtype=torch.float64), dice.float().double(),
+                               iou.float().double(), valid]))
+    return torch.stack(rows)
+
+
+@pytest.mark.parametrize("n,world", [(7, 2), (8, 8), (5, 8), (64, 8), (1, 4)])
+def test_shards_partition_and_merge_equals_single_rank(n, world):
+    shards = [shard_indices(n, r, world) for r in range(world)]
+    assert sorted(i for s in shards for i in s) == list(range(n))
+    assert max(len(s) for s in shards) <= (n + world - 1) // world
+    rows = fake_rows(n)
+    want = metrics_from_table(rows, REGIONS, ["a", "b"], True)
+    # simulate the all_gather: pad each shard to ceil(N/W), concatenate in rank order, drop pads, sort
+    per = (n + world - 1) // world
+    bufs = []
+    for s in shards:
+        pad = torch.full((per, table_width(R)), -1.0, dtype=torch.float64)
+        if s:
+            pad[:len(s)] = rows[s]
+        bufs.append(pad)
+    allrows = torch.cat(bufs)
+    allrows = allrows[allrows[:, 0] >= 0]
+    merged = allrows[torch.argsort(allrows[:, 0])]
+    assert torch.equal(merged, rows)
+    assert metrics_from_table(merged, REGIONS, ["a", "b"], True) == want
+
+
+def test_metrics_from_table_equals_accumulator():
+    rows = fake_rows(6)
+    acc = RegionAccumulator(REGIONS)
+    for row in rows:
+        acc.add_row(row[3:6].float().tolist(), row[6:9].float().tolist(), (row[9:12] > 0.5).tolist(), ["a", "b"][int(row[1])])
+        acc.add_loss(float(row[2]), 1)
+    assert acc.metrics(True) == metrics_from_table(rows, REGIONS, ["a", "b"], True)
+
+
+def _worker(rank, world, port, n, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = fake_rows(n)
+    mine = rows[shard_indices(n, rank, world)]
+    table = gather_table(mine, n, world)
+    torch.save(table, os.path.join(out_dir, f"t{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gather_table_two_processes_gloo(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n, world = 5, 2
+    mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    want = fake_rows(n)
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f"t{r}.pt"), weights_only=True)
+        assert torch.equal(got, want), f"rank {r}"
