@@ -183,7 +183,7 @@ def main():
 
     if rank == 0 and not args.no_profile_pass:
         # instrumented eager pass: events around every conv launch, on the launch stream
-        prof = ops.KernelProfiler()
+        prof = ops.KernelProfiler(reps=4)
         ops.PROFILER = prof
         saved = plug.use_graph
         plug.use_graph = False

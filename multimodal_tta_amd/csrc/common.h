@@ -88,4 +88,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// shared between translation units (defined in pointwise.hip)
+int channel_partial_rows(const mmtta_tensor* t);                        // partial rows per batch item
+int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s);  // part: [N*rows][2][C] (sum, sumsq)
+
+// direct path for layers producing <= 4 channels (conv_direct.hip)
+bool direct_applicable(const mmtta_conv_desc* d);
+int direct_blocks_per_n(const mmtta_tensor* y);
+int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed,
+                    const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
+                    hipStream_t stream);
+
 }  // namespace mmtta

@@ -1,0 +1,186 @@
+// Direct convolution for layers that PRODUCE at most 4 channels (gfx950).
+//
+// The U-Net's last layers run at full resolution with 3 (BraTS) or 1 (HECKTOR) output channels
+// (reference src/models/unet.py:56-66 -> monai UNet top level: ConvTranspose3d 64->R and the
+// conv-only ResidualUnit R->R; src/models/unet_multimodal_midfusion.py:196 final_conv 32->R).
+// On the matrix cores their N dimension would be padded 3 -> 32 (10x wasted MFMA work on the largest
+// grids), while their real arithmetic is tiny: they are HBM / L1 bound.  So: one thread per output voxel
+// (lanes along W, coalesced), weights [tap][K][4] broadcast from LDS, the norm-on-load coefficients of the
+// input in LDS, fp32 FMA accumulation in registers, the same epilogue as the implicit-GEMM kernel
+// (bias, fused residual add, per-block statistics for a following norm).
+//
+// Two gather modes cover all four ops:
+//   gather      in = out*stride + k - pad                    (Conv3d forward, ConvTranspose3d input gradient)
+//   transposed  t = out + pad - k, in = t/stride if t % stride == 0   (ConvTranspose3d forward, Conv3d input gradient)
+#include "common.h"
+
+namespace mmtta {
+
+struct DArgs {
+  TV in; NL tin;
+  TV out;
+  const float* w;      // [T][K][4]
+  const float* bias;   // [N] or null
+  const float* add; long long asn, asd, ash, asw; NL tadd;
+  int K, N, ksize, stride, transposed, accumulate;
+  float* stats; int blocks_per_n;
+};
+
+__global__ __launch_bounds__(256) void direct_conv_kernel(DArgs a) {
+  extern __shared__ float lds[];
+  const int T = a.ksize * a.ksize * a.ksize;
+  float* wl = lds;                       // [T*K][4]
+  float* coef = lds + T * a.K * 4;       // [K][2] scale, shift
+  float* red = coef + 2 * a.K;           // [sum|sq][wave][channel] = 32 floats
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < T * a.K * 4; i += 256) wl[i] = a.w[i];
+  for (int k = threadIdx.x; k < a.K; k += 256) {
+    float sc, sh;
+    nl_coeff(a.tin, n, a.K, k, sc, sh);
+    coef[2 * k] = sc; coef[2 * k + 1] = sh;
+  }
+  __syncthreads();
+  const long long dhw = (long long)a.out.d * a.out.h * a.out.w;
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool active = v < dhw;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int ox = 0, oy = 0, oz = 0;
+  if (active) {
+    long long t = v;
+    ox = (int)(t % a.out.w); t /= a.out.w;
+    oy = (int)(t % a.out.h);
+    oz = (int)(t / a.out.h);
+    const int pad = (a.ksize - 1) / 2;
+    const float* inb = a.in.p + (long long)n * a.in.sn;
+    const bool vec = (a.K % 4 == 0) && (a.in.sw % 4 == 0) && (a.in.sh % 4 == 0) && (a.in.sd % 4 == 0) &&
+                     (a.in.sn % 4 == 0) && (((uintptr_t)a.in.p) % 16 == 0);
+    for (int kz = 0; kz < a.ksize; ++kz) {
+      int iz;
+      if (!a.transposed) iz = oz * a.stride + kz - pad;
+      else { const int tz = oz + pad - kz; if (tz % a.stride != 0) continue; iz = tz / a.stride; }
+      if ((unsigned)iz >= (unsigned)a.in.d) continue;
+      for (int ky = 0; ky < a.ksize; ++ky) {
+        int iy;
+        if (!a.transposed) iy = oy * a.stride + ky - pad;
+        else { const int ty = oy + pad - ky; if (ty % a.stride != 0) continue; iy = ty / a.stride; }
+        if ((unsigned)iy >= (unsigned)a.in.h) continue;
+        for (int kx = 0; kx < a.ksize; ++kx) {
+          int ix;
+          if (!a.transposed) ix = ox * a.stride + kx - pad;
+          else { const int tx = ox + pad - kx; if (tx % a.stride != 0) continue; ix = tx / a.stride; }
+          if ((unsigned)ix >= (unsigned)a.in.w) continue;
+          const float* ip = inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw;
+          const float* wt = wl + ((kz * a.ksize + ky) * a.ksize + kx) * a.K * 4;
+          if (vec) {
+            for (int k = 0; k < a.K; k += 4) {
+              const float4 x4 = *reinterpret_cast<const float4*>(ip + k);
+              const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float xv = nl_apply(xs[j], coef[2 * (k + j)], coef[2 * (k + j) + 1], a.tin.relu);
+                const float4 w4 = *reinterpret_cast<const float4*>(wt + (k + j) * 4);
+                acc[0] = fmaf(xv, w4.x, acc[0]); acc[1] = fmaf(xv, w4.y, acc[1]);
+                acc[2] = fmaf(xv, w4.z, acc[2]); acc[3] = fmaf(xv, w4.w, acc[3]);
+              }
+            }
+          } else {
+            for (int k = 0; k < a.K; ++k) {
+              const float xv = nl_apply(ip[k], coef[2 * k], coef[2 * k + 1], a.tin.relu);
+              const float4 w4 = *reinterpret_cast<const float4*>(wt + k * 4);
+              acc[0] = fmaf(xv, w4.x, acc[0]); acc[1] = fmaf(xv, w4.y, acc[1]);
+              acc[2] = fmaf(xv, w4.z, acc[2]); acc[3] = fmaf(xv, w4.w, acc[3]);
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    float* op = a.out.p + (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh +
+                (long long)ox * a.out.sw;
+    const float* ap = a.add ? a.add + (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash +
+                                  (long long)ox * a.asw : nullptr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < a.N) {
+        float val = acc[c] + (a.bias ? a.bias[c] : 0.f);
+        if (ap) {
+          float sc, sh;
+          nl_coeff(a.tadd, n, a.N, c, sc, sh);
+          val += nl_apply(ap[c], sc, sh, a.tadd.relu);
+        }
+        if (a.accumulate) val += op[c];
+        op[c] = val;
+        ssum[c] = val; ssq[c] = val * val;
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float s = wave_sum(ssum[c]), q = wave_sum(ssq[c]);
+      if (lane == 0) { red[(0 * 4 + wave) * 4 + c] = s; red[(1 * 4 + wave) * 4 + c] = q; }
+    }
+    __syncthreads();
+    if (threadIdx.x < a.N) {
+      const int c = threadIdx.x;
+      const float s = red[0 * 4 + c] + red[1 * 4 + c] + red[2 * 4 + c] + red[3 * 4 + c];
+      const float q = red[16 + 0 * 4 + c] + red[16 + 1 * 4 + c] + red[16 + 2 * 4 + c] + red[16 + 3 * 4 + c];
+      const long long row = (long long)n * a.blocks_per_n + blockIdx.x;
+      a.stats[(row * 2 + 0) * a.N + c] = s;
+      a.stats[(row * 2 + 1) * a.N + c] = q;
+    }
+  }
+}
+
+bool direct_applicable(const mmtta_conv_desc* d) {
+  int N;
+  switch (d->op) {
+    case MMTTA_CONV_FWD: case MMTTA_CONVT_FWD: N = d->cout; break;
+    default: N = d->cin; break;
+  }
+  int K = (N == d->cout) ? d->cin : d->cout;
+  const int T = d->ksize * d->ksize * d->ksize;
+  // weights + coefficients must fit in LDS next to nothing else: T*K*16 + K*8 bytes
+  return N <= 4 && (size_t)T * K * 16 + (size_t)K * 8 + 128 <= 96 * 1024;
+}
+
+int direct_blocks_per_n(const mmtta_tensor* y) {
+  const long long dhw = (long long)y->d * y->h * y->w;
+  return (int)((dhw + 255) / 256);
+}
+
+int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed,
+                    const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
+                    hipStream_t stream) {
+  DArgs a;
+  a.in = tv(x); a.tin = nl(x_norm); a.out = tv(y);
+  a.w = (const float*)packed; a.bias = bias;
+  a.add = nullptr; a.asn = a.asd = a.ash = a.asw = 0; a.tadd = nl(nullptr);
+  if (epi && epi->add) {
+    const mmtta_tensor* ad = epi->add;
+    MMTTA_CHECK(ad->ptr && is_cl(ad) && ad->n == y->n && ad->c == y->c && ad->d == y->d && ad->h == y->h && ad->w == y->w,
+                MMTTA_ERR_INVALID, "conv: epilogue `add` must be channels-last with the shape of y");
+    a.add = (const float*)ad->ptr; a.asn = ad->sn; a.asd = ad->sd; a.ash = ad->sh; a.asw = ad->sw;
+    a.tadd = nl(&epi->add_norm);
+  }
+  a.K = x->c; a.N = y->c; a.ksize = d->ksize; a.stride = d->stride;
+  a.transposed = (d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONV_DGRAD) ? 1 : 0;
+  a.accumulate = accumulate;
+  a.stats = stats; a.blocks_per_n = direct_blocks_per_n(y);
+  const int T = d->ksize * d->ksize * d->ksize;
+  const size_t lds = (size_t)T * a.K * 16 + (size_t)a.K * 8 + 32 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)direct_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    MMTTA_CHECK(e == hipSuccess, MMTTA_ERR_LAUNCH, "direct conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(direct_conv_kernel, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
+  return launch_status("direct conv");
+}
+
+}  // namespace mmtta

@@ -280,13 +280,16 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
 }
 
 // Reduce split-K slabs: sum over splits, then the same epilogue as above.
-// grid (tiles, ceil(Np/32)); 256 threads = 8 row groups x 32 columns.
+// grid (tiles * MT/32, ceil(Np/32)); 256 threads = 8 row lanes x 32 columns, 4 rows per thread, i.e. one
+// block per 32 rows x 32 columns; each block writes ONE statistics row (rows per tile = MT/32).
 template <int TZ, int TY, int TX>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles) {
   __shared__ float red[2][8][32];
   constexpr int MT = TZ * TY * TX;
+  constexpr int RB = MT / 32;
   const int tid = threadIdx.x, r = tid & 31, rg = tid >> 5;
-  int t = blockIdx.x;
+  const int tile = blockIdx.x / RB, rb = blockIdx.x % RB;
+  int t = tile;
   const int txi = t % a.tx; t /= a.tx;
   const int tyi = t % a.ty; t /= a.ty;
   const int tzi = t % a.tz;
@@ -299,17 +302,25 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
     if (a.add) nl_coeff(a.tadd, n, a.Co, col, asc, ash);
   }
   float s_sum = 0.f, s_sq = 0.f;
-  for (int v = rg; v < MT; v += 8) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int v = rb * 32 + rg * 4 + q;
     int zl, yl, xl;
     row_to_local<TZ, TY, TX>(v, zl, yl, xl);
     const int gz = tzi * TZ + zl, gy = tyi * TY + yl, gx = txi * TX + xl;
     if (!(colok && gz < a.Dg && gy < a.Hg && gx < a.Wg)) continue;
     const int oz = gz * a.so + a.oz, oy = gy * a.so + a.oy, ox = gx * a.so + a.ox;
     if (!(oz < a.Do && oy < a.Ho && ox < a.Wo)) continue;
-    float sum = 0.f;
-    for (int kz = 0; kz < a.ksplit; ++kz)
-      sum += a.ws[(((long long)kz * tiles + blockIdx.x) * MT + v) * a.Np + col];
-    float val = sum + bias;
+    const float* wsp = a.ws + ((long long)tile * MT + v) * a.Np + col;
+    const long long kstride = (long long)tiles * MT * a.Np;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    int kz = 0;
+    for (; kz + 4 <= a.ksplit; kz += 4) {        // four independent loads in flight
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += wsp[(kz + u) * kstride];
+    }
+    for (; kz < a.ksplit; ++kz) s4[0] += wsp[kz * kstride];
+    float val = (s4[0] + s4[1]) + (s4[2] + s4[3]) + bias;
     if (a.add)
       val += nl_apply(a.add[(long long)n * a.asn + oz * a.asd + oy * a.ash + ox * a.asw + col], asc, ash,
                       a.tadd.relu);
@@ -327,8 +338,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
       float ts = 0.f, tq = 0.f;
 #pragma unroll
       for (int g = 0; g < 8; ++g) { ts += red[0][g][r]; tq += red[1][g][r]; }
-      const int tile_in_n = blockIdx.x % (a.tz * a.ty * a.tx);
-      const long long row = (long long)n * a.stats_rows_per_n + a.stats_row_off + tile_in_n;
+      const int tile_in_n = tile % (a.tz * a.ty * a.tx);
+      const long long row = (long long)n * a.stats_rows_per_n + a.stats_row_off + tile_in_n * RB + rb;
       a.stats[(row * 2 + 0) * a.Co + col] = ts;
       a.stats[(row * 2 + 1) * a.Co + col] = tq;
     }
@@ -371,10 +382,14 @@ static void op_dims(const mmtta_conv_desc* d, int& K, int& N, int& si, bool& cla
   }
 }
 
-static Config pick_config(int Np, int si) {
+static Config pick_config(int Np, int si, long long voxels, int K) {
   if (si == 1) {
     if (Np == 32) return {1, 4, 8, 8, 8, 8};
     if (Np == 64) return {2, 4, 4, 8, 8, 16};
+    // wide layers on a small grid (the 8^3 / 16^3 levels): 8-channel stages so that split-K can reach
+    // >= 256 workgroups; otherwise 32-channel stages (fewer barriers, fewer weight fetches)
+    const long long tiles = (voxels + 127) / 128, colgroups = (Np + 127) / 128;
+    if (tiles * colgroups * ((K + 31) / 32) < 384) return {4, 4, 4, 4, 8, 8};
     return {4, 4, 4, 4, 8, 32};
   }
   if (Np == 32) return {1, 1, 4, 4, 8, 8};
@@ -439,9 +454,9 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   }
   g.Kp = roundup(g.K, 32);
   g.Np = roundup(g.N, 32);
-  g.cfg = pick_config(g.Np, g.si);
   int Dg = y->d, Hg = y->h, Wg = y->w;
   if (g.classes) { Dg = (y->d + 1) / 2; Hg = (y->h + 1) / 2; Wg = (y->w + 1) / 2; }
+  g.cfg = pick_config(g.Np, g.si, (long long)x->n * Dg * Hg * Wg, g.K);
   g.tz = (Dg + g.cfg.TZ - 1) / g.cfg.TZ;
   g.ty = (Hg + g.cfg.TY - 1) / g.cfg.TY;
   g.tx = (Wg + g.cfg.TX - 1) / g.cfg.TX;
@@ -453,14 +468,17 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   const int wgs = g.tiles * ncolgroups;
   g.ksplit = 1;
   g.sps = g.nstages;
-  if (wgs < 128 && g.nstages > 1) {
-    int want = (256 + wgs - 1) / wgs;
+  if (wgs < 384 && g.nstages > 1) {
+    int want = (512 + wgs - 1) / wgs;
     if (want > g.nstages) want = g.nstages;
     g.sps = (g.nstages + want - 1) / want;
     g.ksplit = (g.nstages + g.sps - 1) / g.sps;
   }
   return MMTTA_OK;
 }
+
+// statistics rows written per tile: 1 by the conv epilogue, MT/32 by the split-K finalize
+static int stats_rows_per_tile(const Geometry& g) { return g.ksplit > 1 ? g.cfg.TZ * g.cfg.TY * g.cfg.TX / 32 : 1; }
 
 static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t) {
   // pz/py/px: output parity class for the transposed forms, ignored otherwise
@@ -518,22 +536,28 @@ static int launch_cfg(const GArgs& a_in, int tiles, hipStream_t s) {
   int st = launch_status("conv igemm");
   if (st) return st;
   if (a.ksplit > 1) {
-    dim3 g2(tiles, (a.Np + 31) / 32);
+    dim3 g2(tiles * (TZ * TY * TX / 32), (a.Np + 31) / 32);
     hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX>), g2, dim3(256), 0, s, a, tiles);
     st = launch_status("conv split-K finalize");
   }
   return st;
 }
 
+static int config_id(const Config& c) {
+  if (c.NB == 1) return c.MB == 4 ? 0 : 3;
+  if (c.NB == 2) return c.MB == 4 ? 1 : 4;
+  return c.KCI == 32 ? 2 : 5;
+}
+
 static int launch_any(const Config& c, const GArgs& a, int tiles, hipStream_t s) {
-  if (a.si == 1) {
-    if (c.NB == 1) return launch_cfg<1, 4, 8, 8, 8, 8>(a, tiles, s);
-    if (c.NB == 2) return launch_cfg<2, 4, 4, 8, 8, 16>(a, tiles, s);
-    return launch_cfg<4, 4, 4, 4, 8, 32>(a, tiles, s);
+  switch (config_id(c)) {
+    case 0: return launch_cfg<1, 4, 8, 8, 8, 8>(a, tiles, s);
+    case 1: return launch_cfg<2, 4, 4, 8, 8, 16>(a, tiles, s);
+    case 2: return launch_cfg<4, 4, 4, 4, 8, 32>(a, tiles, s);
+    case 3: return launch_cfg<1, 1, 4, 4, 8, 8>(a, tiles, s);
+    case 4: return launch_cfg<2, 2, 4, 4, 8, 8>(a, tiles, s);
+    default: return launch_cfg<4, 4, 4, 4, 8, 8>(a, tiles, s);
   }
-  if (c.NB == 1) return launch_cfg<1, 1, 4, 4, 8, 8>(a, tiles, s);
-  if (c.NB == 2) return launch_cfg<2, 2, 4, 4, 8, 8>(a, tiles, s);
-  return launch_cfg<4, 4, 4, 4, 8, 8>(a, tiles, s);
 }
 
 }  // namespace mmtta
@@ -545,6 +569,7 @@ extern "C" int64_t mmtta_conv_packed_bytes(const mmtta_conv_desc* d) {
   int K, N, si; bool cl;
   op_dims(d, K, N, si, cl);
   const int T = d->ksize * d->ksize * d->ksize;
+  if (direct_applicable(d)) return (int64_t)T * K * 4 * (int64_t)sizeof(float);
   return (int64_t)T * roundup(K, 32) * roundup(N, 32) * (int64_t)sizeof(float);
 }
 
@@ -559,7 +584,8 @@ extern "C" int mmtta_conv_pack_weights(const mmtta_conv_desc* d, const float* w,
   const int A = convt ? d->cin : d->cout, B = convt ? d->cout : d->cin;
   // K,N in terms of (A,B): CONV_FWD K=cin=B ; CONV_DGRAD K=cout=A ; CONVT_FWD K=cin=A ; CONVT_DGRAD K=cout=B
   const int kn_is_ba = (d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_DGRAD) ? 1 : 0;
-  const int Kp = roundup(K, 32), Np = roundup(N, 32);
+  const bool direct = direct_applicable(d);
+  const int Kp = direct ? K : roundup(K, 32), Np = direct ? 4 : roundup(N, 32);
   const long long total = (long long)T * Kp * Np;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -574,11 +600,21 @@ extern "C" int mmtta_conv_plan(const mmtta_conv_desc* d, const mmtta_tensor* x, 
   Geometry g;
   int st = geometry(d, x, y, g);
   if (st) return st;
+  if (direct_applicable(d)) {
+    plan->tiles = direct_blocks_per_n(y) * y->n;
+    plan->launches = 1;
+    plan->ksplit = 1;
+    plan->stats_rows = plan->tiles;
+    plan->config = 6;
+    plan->_pad = 0;
+    plan->workspace_bytes = 0;
+    return MMTTA_OK;
+  }
   plan->tiles = g.tiles;
   plan->launches = g.launches;
   plan->ksplit = g.ksplit;
-  plan->stats_rows = g.launches * g.tiles;
-  plan->config = (g.si == 1 ? 0 : 3) + (g.cfg.NB == 1 ? 0 : (g.cfg.NB == 2 ? 1 : 2));
+  plan->stats_rows = g.launches * g.tiles * stats_rows_per_tile(g);
+  plan->config = config_id(g.cfg);
   plan->_pad = 0;
   plan->workspace_bytes =
       g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * (int64_t)sizeof(float) : 0;
@@ -593,6 +629,7 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   int st = geometry(d, x, y, g);
   if (st) return st;
   MMTTA_CHECK(packed != nullptr, MMTTA_ERR_INVALID, "conv: null packed weights");
+  if (direct_applicable(d)) return direct_conv_run(d, x, x_norm, packed, bias, epi, y, accumulate, stats, (hipStream_t)stream);
   const int64_t need = g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * 4 : 0;
   MMTTA_CHECK(need == 0 || (workspace != nullptr && workspace_bytes >= need), MMTTA_ERR_WORKSPACE,
               "conv: workspace %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
@@ -614,7 +651,8 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
     a.tadd = nl(&epi->add_norm);
   }
   a.accumulate = accumulate;
-  a.stats = stats; a.stats_rows_per_n = g.launches * g.tiles_per_n;
+  const int srt = stats_rows_per_tile(g);
+  a.stats = stats; a.stats_rows_per_n = g.launches * g.tiles_per_n * srt;
   a.ws = (float*)workspace; a.ksplit = g.ksplit; a.stages_per_split = g.sps; a.nstages = g.nstages;
   a.tz = g.tz; a.ty = g.ty; a.tx = g.tx;
   const bool al = (((uintptr_t)x->ptr) % 16 == 0) && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0;
@@ -631,7 +669,7 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
     build_taps(d, pz, py, px, a.taps);
     a.so = 2; a.oz = pz; a.oy = py; a.ox = px;
     a.Dg = (y->d - pz + 1) / 2; a.Hg = (y->h - py + 1) / 2; a.Wg = (y->w - px + 1) / 2;
-    a.stats_row_off = cls * g.tiles_per_n;
+    a.stats_row_off = cls * g.tiles_per_n * srt;
     st = launch_any(g.cfg, a, g.tiles, (hipStream_t)stream);
     if (st) return st;
   }

@@ -21,6 +21,7 @@
 namespace mmtta {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+static inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
 struct WArgs {
   const float* g; long long gsn, gsd, gsh, gsw; int Cg, Dgg, Hgg, Wgg; NL tg;
@@ -34,35 +35,34 @@ struct WArgs {
   int gvec4, dvec4;
 };
 
-template <int TZ, int TY, int TX>
+// NTW = accumulators per wave: 7 for the 27-tap kernel (taps wave, wave+4, ...; slot 27 is a dummy that is
+// never flushed), 1 for a single tap (the four waves then split the voxel pairs instead).
+template <int TZ, int TY, int TX, int NTW>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
   extern __shared__ float lds[];
   constexpr int MT = TZ * TY * TX;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: keeps every tap branch uniform
   const int h = lane >> 5, r = lane & 31;
-  const int ext = a.ntaps == 1 ? 0 : 2;
+  const int ext = NTW == 1 ? 0 : 2;
   const int BZ = (TZ - 1) * a.si + ext + 1, BY = (TY - 1) * a.si + ext + 1, BX = (TX - 1) * a.si + ext + 1;
   const int boxvox = BZ * BY * BX;
-  const int dmin = a.ntaps == 1 ? 0 : -1;
+  const int dmin = NTW == 1 ? 0 : -1;
   float* gl = lds;                 // [boxvox][32]
   float* dl = lds + boxvox * 32;   // [MT][32]
   const int cg0 = blockIdx.y * 32, cd0 = blockIdx.z * 32;
 
-  // taps of this wave: tap = wave + 4*j (27 taps) ; single tap: every wave, k-steps interleaved
-  int toff[7];
-  int ntw = 0;
+  int toff[NTW];
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int tap = wave + 4 * j;
-    toff[j] = 0;
-    if (a.ntaps == 1) { if (j == 0) ntw = 1; }
-    else if (tap < 27) { toff[j] = ((tap / 9) * BY + ((tap / 3) % 3)) * BX + (tap % 3); ntw = j + 1; }
+  for (int j = 0; j < NTW; ++j) {
+    const int tap = NTW == 1 ? 0 : min(wave + 4 * j, 26);
+    toff[j] = NTW == 1 ? 0 : (((tap / 9) * BY + ((tap / 3) % 3)) * BX + (tap % 3)) * 32;
   }
-  const int kstep0 = a.ntaps == 1 ? wave : 0, kstride = a.ntaps == 1 ? 4 : 1;
+  const int kstep0 = NTW == 1 ? wave : 0, kstride = NTW == 1 ? 4 : 1;
 
-  f32x16 acc[7];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int j = 0; j < 7; ++j)
+  for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
   float dbacc = 0.f;
@@ -137,31 +137,29 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
       }
     }
     __syncthreads();
-    // ---- MFMA: k = voxel pairs
+    // ---- MFMA: k = voxel pairs; straight-line body (reads of a step are independent of its MFMAs)
+#pragma unroll 2
     for (int kk = kstep0; kk < MT / 2; kk += kstride) {
       const int v = 2 * kk + h;
       const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
-      const int gidx = ((zl * a.si) * BY + yl * a.si) * BX + xl * a.si;
+      const int gaddr = (((zl * a.si) * BY + yl * a.si) * BX + xl * a.si) * 32 + r;
       const float b = dl[v * 32 + r];
+      float av[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) av[j] = gl[gaddr + toff[j]];
       dbacc += b;
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        if (j < ntw) {
-          const float av = gl[(gidx + toff[j]) * 32 + r];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[j], 0, 0, 0);
-        }
-      }
+      for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b, acc[j], 0, 0, 0);
     }
     __syncthreads();
   }
 
   // ---- flush partials
-  const int kw = a.ntaps == 1 ? 4 : 1;
-  const int sl = a.ntaps == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x;
+  const int sl = NTW == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x;
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    if (j < ntw) {
-      const int tap = a.ntaps == 1 ? 0 : wave + 4 * j;
+  for (int j = 0; j < NTW; ++j) {
+    const int tap = NTW == 1 ? 0 : wave + 4 * j;
+    if (tap < a.ntaps) {
       float* sb = a.slab + (((long long)sl * a.ntaps + tap) * a.CGp + cg0) * a.CDp + cd0 + r;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -170,80 +168,257 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
       }
     }
   }
-  if (a.dbpart != nullptr && blockIdx.y == 0 && (a.ntaps == 1 || wave == 0)) {
+  if (a.dbpart != nullptr && blockIdx.y == 0 && (NTW == 1 || wave == 0)) {
     dbacc += __shfl_xor(dbacc, 32, 64);
     if (h == 0) a.dbpart[(long long)sl * a.CDp + cd0 + r] = dbacc;
   }
-  (void)kw;
 }
 
-// dw[cd][cg][tap] (+)= sum_sl slab[sl][tap][cg][cd]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsl, int ntaps, int Cg,
-                                    int Cd, int CGp, int CDp, int accumulate) {
-  const long long total = (long long)ntaps * Cg * Cd;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cd = (int)(i % Cd);
-    const int cg = (int)((i / Cd) % Cg);
-    const int tap = (int)(i / ((long long)Cd * Cg));
+// dw[cd][cg][tap] (+)= sum_sl slab[sl][tap][cg][cd]   (torch weight layout out of the [tap][cg][cd] slabs)
+// The transpose goes through LDS so that both sides stay coalesced: reads run along cd, writes are runs of
+// `ntaps` consecutive floats per (cd, cg).  27 taps: one block = one cg x 64 cd;  1 tap: 32 cg x 32 cd.
+__global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                             int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate) {
+  __shared__ float tile[64][28];
+  const int cg = blockIdx.x, cd0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+    const int cdl = i & 63, tap = i >> 6;
+    const int cd = cd0 + cdl;
     float s = 0.f;
-    for (int sl = 0; sl < nsl; ++sl) s += slab[(((long long)sl * ntaps + tap) * CGp + cg) * CDp + cd];
-    float* o = dw + ((long long)cd * Cg + cg) * ntaps + tap;
+    if (cd < Cd) {
+      const float* p = slab + ((long long)tap * CGp + cg) * CDp + cd;
+      const long long st = (long long)27 * CGp * CDp;
+      int sl = 0;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (; sl + 4 <= nsl; sl += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += p[(sl + u) * st];
+      }
+      for (; sl < nsl; ++sl) s4[0] += p[sl * st];
+      s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+    tile[cdl][tap] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+    const int cdl = i / 27, tap = i % 27;
+    const int cd = cd0 + cdl;
+    if (cd < Cd) {
+      float* o = dw + ((long long)cd * Cg + cg) * 27 + tap;
+      const float v = tile[cdl][tap];
+      *o = accumulate ? (*o + v) : v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                            int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate) {
+  __shared__ float tile[32][33];
+  const int cg0 = blockIdx.x * 32, cd0 = blockIdx.y * 32;
+  for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+    const int cdl = i & 31, cgl = i >> 5;
+    float s = 0.f;
+    if (cg0 + cgl < Cg && cd0 + cdl < Cd)
+      for (int sl = 0; sl < nsl; ++sl) s += slab[((long long)sl * CGp + cg0 + cgl) * CDp + cd0 + cdl];
+    tile[cdl][cgl] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+    const int cgl = i & 31, cdl = i >> 5;
+    if (cg0 + cgl < Cg && cd0 + cdl < Cd) {
+      float* o = dw + (long long)(cd0 + cdl) * Cg + cg0 + cgl;
+      const float v = tile[cdl][cgl];
+      *o = accumulate ? (*o + v) : v;
+    }
+  }
+}
+
+// first reduction stage when many spatial splits exist: out[chunk][e] = sum of 32 consecutive slabs (coalesced)
+__global__ __launch_bounds__(256) void slab_prereduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                             int nsl, long long elems) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= elems) return;
+  const int s0 = blockIdx.y * 32, s1 = min(nsl, s0 + 32);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int sl = s0;
+  for (; sl + 4 <= s1; sl += 4) {
+    a0 += slab[(long long)sl * elems + e]; a1 += slab[(long long)(sl + 1) * elems + e];
+    a2 += slab[(long long)(sl + 2) * elems + e]; a3 += slab[(long long)(sl + 3) * elems + e];
+  }
+  for (; sl < s1; ++sl) a0 += slab[(long long)sl * elems + e];
+  out[(long long)blockIdx.y * elems + e] = (a0 + a1) + (a2 + a3);
+}
+
+// db[c] (+)= sum_sl part[sl*ld + c]: one wave per channel, lanes stride the partial rows
+__global__ __launch_bounds__(64) void db_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, int nsl,
+                                                       int C, int ld, int accumulate) {
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int sl = threadIdx.x; sl < nsl; sl += 64) s += part[(long long)sl * ld + c];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+}
+
+// ------------------------------------------------------------------ small-channel weight gradient
+// When one side of the layer has <= 4 channels (first layers: Cin = 1..4; last layers: Cout = 1..3) the
+// 32x32 (cg x cd) blocking above would pad it 8-32x.  Here the small tensor Q is the GATHERED one and its
+// (tap, channel) pairs are flattened into the MFMA row index (27*4 = 108 <= 128 rows = 4 waves x 32), the
+// big tensor P is dense:      S[row=(tap,cs)][col=cb] = sum_o T(Q[o*si + tap - 1][cs]) * T(P[o][cb])
+// One MFMA per voxel pair and wave instead of seven, and no padded channels.
+struct W2Args {
+  const float* q; long long qsn, qsd, qsh, qsw; int Cs, Dq, Hq, Wq; NL tq;
+  const float* p; long long psn, psd, psh, psw; int Cb, Dp, Hp, Wp; NL tp;
+  int si, ntaps;
+  float* slab;     // [nsl][128][CBp]
+  float* dbpart;   // [nsl][CBp] or null: per-channel sums of P (bias gradient when cb is the output channel)
+  int tz, ty, tx, tiles, tiles_per_split, CBp;
+  int qvec4, pvec4;
+};
+
+__global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
+  extern __shared__ float lds[];
+  constexpr int TZ = 4, TY = 4, TX = 8, MT = 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int ext = a.ntaps == 1 ? 0 : 2;
+  const int BZ = (TZ - 1) * a.si + ext + 1, BY = (TY - 1) * a.si + ext + 1, BX = (TX - 1) * a.si + ext + 1;
+  const int boxvox = BZ * BY * BX;
+  const int dmin = a.ntaps == 1 ? 0 : -1;
+  float* ql = lds;                  // [boxvox][4]
+  float* pl = lds + boxvox * 4;     // [MT][32]
+  const int cb0 = blockIdx.y * 32;
+  const int nrows = a.ntaps * a.Cs;
+  const int rowid = wave * 32 + r;
+  int toffl = 0;
+  if (rowid < nrows) {
+    const int tap = rowid / a.Cs, cs = rowid % a.Cs;
+    toffl = (a.ntaps == 1 ? 0 : (((tap / 9) * BY + ((tap / 3) % 3)) * BX + (tap % 3))) * 4 + cs;
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float dbacc = 0.f;
+  const int t0 = blockIdx.x * a.tiles_per_split;
+  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
+  const int tpn = a.tz * a.ty * a.tx;
+  for (int tile = t0; tile < t1; ++tile) {
+    const int n = tile / tpn;
+    int t = tile % tpn;
+    const int txi = t % a.tx; t /= a.tx;
+    const int tyi = t % a.ty;
+    const int tzi = t / a.ty;
+    const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
+    const int iz0 = oz0 * a.si + dmin, iy0 = oy0 * a.si + dmin, ix0 = ox0 * a.si + dmin;
+    {  // Q box: up to 4 channels per voxel
+      const float* qb = a.q + (long long)n * a.qsn;
+      float sc[4], sh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < a.Cs) nl_coeff(a.tq, n, a.Cs, j, sc[j], sh[j]);
+        else { sc[j] = 0.f; sh[j] = 0.f; }
+      }
+      for (int bv = tid; bv < boxvox; bv += 256) {
+        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iz < (unsigned)a.Dq && (unsigned)iy < (unsigned)a.Hq && (unsigned)ix < (unsigned)a.Wq) {
+          const float* src = qb + iz * a.qsd + iy * a.qsh + ix * a.qsw;
+          float xs[4] = {0.f, 0.f, 0.f, 0.f};
+          if (a.qvec4) { const float4 x4 = *reinterpret_cast<const float4*>(src); xs[0] = x4.x; xs[1] = x4.y; xs[2] = x4.z; xs[3] = x4.w; }
+          else { for (int j = 0; j < a.Cs; ++j) xs[j] = src[j]; }
+          v.x = nl_apply(xs[0], sc[0], sh[0], a.tq.relu);
+          v.y = a.Cs > 1 ? nl_apply(xs[1], sc[1], sh[1], a.tq.relu) : 0.f;
+          v.z = a.Cs > 2 ? nl_apply(xs[2], sc[2], sh[2], a.tq.relu) : 0.f;
+          v.w = a.Cs > 3 ? nl_apply(xs[3], sc[3], sh[3], a.tq.relu) : 0.f;
+        }
+        *reinterpret_cast<float4*>(ql + bv * 4) = v;
+      }
+    }
+    {  // P tile
+      const float* pb = a.p + (long long)n * a.psn;
+      if (a.pvec4) {
+        const int cv = tid & 7, c = cb0 + cv * 4;
+        float sc[4], sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (c + j < a.Cb) nl_coeff(a.tp, n, a.Cb, c + j, sc[j], sh[j]);
+          else { sc[j] = 0.f; sh[j] = 0.f; }
+        }
+        for (int v = tid >> 3; v < MT; v += 32) {
+          const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+          const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
+          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (oz < a.Dp && oy < a.Hp && ox < a.Wp && c < a.Cb) {
+            const float4 x4 = *reinterpret_cast<const float4*>(pb + oz * a.psd + oy * a.psh + ox * a.psw + c);
+            o.x = nl_apply(x4.x, sc[0], sh[0], a.tp.relu);
+            o.y = (c + 1 < a.Cb) ? nl_apply(x4.y, sc[1], sh[1], a.tp.relu) : 0.f;
+            o.z = (c + 2 < a.Cb) ? nl_apply(x4.z, sc[2], sh[2], a.tp.relu) : 0.f;
+            o.w = (c + 3 < a.Cb) ? nl_apply(x4.w, sc[3], sh[3], a.tp.relu) : 0.f;
+          }
+          *reinterpret_cast<float4*>(pl + v * 32 + cv * 4) = o;
+        }
+      } else {
+        const int cc = tid & 31, c = cb0 + cc;
+        float sc = 0.f, sh = 0.f;
+        if (c < a.Cb) nl_coeff(a.tp, n, a.Cb, c, sc, sh);
+        for (int v = tid >> 5; v < MT; v += 8) {
+          const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+          const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
+          float val = 0.f;
+          if (oz < a.Dp && oy < a.Hp && ox < a.Wp && c < a.Cb)
+            val = nl_apply(pb[oz * a.psd + oy * a.psh + ox * a.psw + c], sc, sh, a.tp.relu);
+          pl[v * 32 + cc] = val;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < MT / 2; ++kk) {
+      const int v = 2 * kk + h;
+      const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+      const int gaddr = (((zl * a.si) * BY + yl * a.si) * BX + xl * a.si) * 4;
+      const float av = ql[gaddr + toffl];
+      const float b = pl[v * 32 + r];
+      dbacc += b;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int sl = blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (row < nrows) a.slab[((long long)sl * 128 + row) * a.CBp + cb0 + r] = acc[i];
+  }
+  if (a.dbpart != nullptr && wave == 0) {
+    dbacc += __shfl_xor(dbacc, 32, 64);
+    if (h == 0) a.dbpart[(long long)sl * a.CBp + cb0 + r] = dbacc;
+  }
+}
+
+// small_is_cd == 0: dw[(cb*Cs + cs)*ntaps + tap]   (Conv3d with tiny Cin, ConvTranspose3d with tiny Cout)
+// small_is_cd == 1: dw[(cs*Cb + cb)*ntaps + tap]   (1x1x1 Conv3d with tiny Cout)
+__global__ void wgrad_small_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsl, int ntaps, int Cs,
+                                          int Cb, int CBp, int small_is_cd, int accumulate) {
+  const int total = ntaps * Cs * Cb;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int cb = i % Cb, row = i / Cb;
+    const int tap = row / Cs, cs = row % Cs;
+    float s = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) s += slab[((long long)sl * 128 + row) * CBp + cb];
+    float* o = dw + (small_is_cd ? ((long long)cs * Cb + cb) : ((long long)cb * Cs + cs)) * ntaps + tap;
     *o = accumulate ? (*o + s) : s;
   }
 }
 
-__global__ void db_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, int nsl, int C, int ld,
-                                 int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int sl = 0; sl < nsl; ++sl) s += part[(long long)sl * ld + c];
-  db[c] = accumulate ? db[c] + s : s;
-}
-
-// per-channel sum over all voxels of a channels-last tensor, stage 1: part[block][C]
-__global__ __launch_bounds__(256) void colsum_kernel(TV x, float* __restrict__ part, long long vox_per_block) {
-  // thread = (voxel lane, channel); channel fastest for coalescing; voxel lanes combined through LDS
-  __shared__ float red[256];
-  const int C = x.c;
-  int cpl = 1;
-  while (cpl < C && cpl < 256) cpl <<= 1;
-  const int nvl = 256 / cpl;
-  const int cl = threadIdx.x % cpl, vl = threadIdx.x / cpl;
-  const long long nvox = (long long)x.n * x.d * x.h * x.w;
-  const long long v0 = blockIdx.x * vox_per_block;
-  const long long v1 = (v0 + vox_per_block < nvox) ? v0 + vox_per_block : nvox;
-  for (int cb = 0; cb < C; cb += cpl) {
-    const int c = cb + cl;
-    float s = 0.f;
-    if (c < C)
-      for (long long v = v0 + vl; v < v1; v += nvl) {
-        long long t = v;
-        const int xx = (int)(t % x.w); t /= x.w;
-        const int yy = (int)(t % x.h); t /= x.h;
-        const int zz = (int)(t % x.d);
-        const int nn = (int)(t / x.d);
-        s += x.p[nn * x.sn + zz * x.sd + yy * x.sh + xx * x.sw + c];
-      }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (vl == 0 && c < C) {
-      float tsum = 0.f;
-      for (int j = 0; j < nvl; ++j) tsum += red[j * cpl + cl];
-      part[(long long)blockIdx.x * C + c] = tsum;
-    }
-    __syncthreads();
-  }
-}
-
-static inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
 struct WGeo {
+  bool small; int small_is_cd; const mmtta_tensor *q, *pb; bool q_is_x;
   const mmtta_tensor *g, *dn;
   int si, ntaps, TZ, TY, TX;
   int tz, ty, tx, tiles, S, tps, nsl, CGp, CDp;
-  int64_t slab_floats, db_floats, colsum_blocks;
+  int64_t slab_floats, db_floats, colsum_blocks, pre_floats; int pre_chunks;
   bool convt;
 };
 
@@ -268,6 +443,32 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     MMTTA_CHECK(dd[i] == want && (!w.convt || gd[i] % 2 == 0), MMTTA_ERR_INVALID,
                 "wgrad: spatial mismatch on axis %d (fine %d, coarse %d)", i, gd[i], dd[i]);
   }
+  // small-channel path: which tensor is the small gathered one (Q) and which the dense one (P)
+  w.small = false; w.small_is_cd = 0; w.q = w.pb = nullptr; w.q_is_x = false;
+  if (!w.convt && d->cin <= 4) { w.small = true; w.q = x; w.pb = dy; w.q_is_x = true; }
+  else if (!w.convt && d->cout <= 4 && d->ksize == 1) { w.small = true; w.q = dy; w.pb = x; w.small_is_cd = 1; }
+  else if (w.convt && d->cout <= 4) { w.small = true; w.q = dy; w.pb = x; }
+  if (w.small) {
+    w.TZ = 4; w.TY = 4; w.TX = 8;
+    w.tz = (w.pb->d + 3) / 4; w.ty = (w.pb->h + 3) / 4; w.tx = (w.pb->w + 7) / 8;
+    w.tiles = w.tz * w.ty * w.tx * x->n;
+    w.CGp = 128;
+    w.CDp = roundup(w.pb->c, 32);
+    int S = 1024 / (w.CDp / 32);
+    if (S < 1) S = 1;
+    if (S > w.tiles) S = w.tiles;
+    w.tps = (w.tiles + S - 1) / S;
+    w.S = (w.tiles + w.tps - 1) / w.tps;
+    w.nsl = w.S;
+    w.slab_floats = (int64_t)w.nsl * 128 * w.CDp;
+    w.pre_chunks = w.nsl > 32 ? (w.nsl + 31) / 32 : 0;
+    w.pre_floats = (int64_t)w.pre_chunks * 128 * w.CDp;
+    w.colsum_blocks = 0;
+    const bool bias_from_p = (w.pb == dy);           // P carries the output channels
+    if (bias_from_p) w.db_floats = (int64_t)w.nsl * w.CDp;
+    else { w.colsum_blocks = (int64_t)dy->n * channel_partial_rows(dy); w.db_floats = w.colsum_blocks * 2 * dy->c; }
+    return MMTTA_OK;
+  }
   if (w.si == 1) { w.TZ = 4; w.TY = 4; w.TX = 8; } else { w.TZ = 2; w.TY = 2; w.TX = 8; }
   w.tz = (w.dn->d + w.TZ - 1) / w.TZ;
   w.ty = (w.dn->h + w.TY - 1) / w.TY;
@@ -283,24 +484,24 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.S = (w.tiles + w.tps - 1) / w.tps;
   w.nsl = w.S * (w.ntaps == 1 ? 4 : 1);
   w.slab_floats = (int64_t)w.nsl * w.ntaps * w.CGp * w.CDp;
+  w.pre_chunks = w.nsl > 32 ? (w.nsl + 31) / 32 : 0;
+  w.pre_floats = (int64_t)w.pre_chunks * w.ntaps * w.CGp * w.CDp;
   w.colsum_blocks = 0;
   if (w.convt) {
-    const int64_t nvox = (int64_t)dy->n * dy->d * dy->h * dy->w;
-    w.colsum_blocks = nvox < 1024 ? 1 : (nvox + 1023) / 1024;
-    if (w.colsum_blocks > 2048) w.colsum_blocks = 2048;
-    w.db_floats = w.colsum_blocks * dy->c;
+    w.colsum_blocks = (int64_t)dy->n * channel_partial_rows(dy);
+    w.db_floats = w.colsum_blocks * 2 * dy->c;
   } else {
     w.db_floats = (int64_t)w.nsl * w.CDp;
   }
   return MMTTA_OK;
 }
 
-template <int TZ, int TY, int TX>
+template <int TZ, int TY, int TX, int NTW>
 static int launch_wgrad(const WArgs& a, int S, hipStream_t s) {
   const int ext = a.ntaps == 1 ? 0 : 2;
   const int BZ = (TZ - 1) * a.si + ext + 1, BY = (TY - 1) * a.si + ext + 1, BX = (TX - 1) * a.si + ext + 1;
   const size_t lds = ((size_t)BZ * BY * BX + TZ * TY * TX) * 32 * sizeof(float);
-  auto kern = wgrad_f32_kernel<TZ, TY, TX>;
+  auto kern = wgrad_f32_kernel<TZ, TY, TX, NTW>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -319,7 +520,7 @@ extern "C" int64_t mmtta_conv_wgrad_workspace_bytes(const mmtta_conv_desc* d, co
                                                     const mmtta_tensor* dy) {
   WGeo w;
   if (wgeometry(d, x, dy, w)) return -1;
-  return (w.slab_floats + w.db_floats) * (int64_t)sizeof(float);
+  return (w.slab_floats + w.db_floats + w.pre_floats) * (int64_t)sizeof(float);
 }
 
 extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
@@ -329,10 +530,63 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   int st = wgeometry(d, x, dy, w);
   if (st) return st;
   MMTTA_CHECK(dw != nullptr, MMTTA_ERR_INVALID, "wgrad: null dw");
-  const int64_t need = (w.slab_floats + w.db_floats) * 4;
+  const int64_t need = (w.slab_floats + w.db_floats + w.pre_floats) * 4;
   MMTTA_CHECK(workspace != nullptr && workspace_bytes >= need, MMTTA_ERR_WORKSPACE, "wgrad: workspace %lld bytes, need %lld",
               (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
+  if (w.small) {
+    W2Args b;
+    b.q = (const float*)w.q->ptr; b.qsn = w.q->sn; b.qsd = w.q->sd; b.qsh = w.q->sh; b.qsw = w.q->sw;
+    b.Cs = w.q->c; b.Dq = w.q->d; b.Hq = w.q->h; b.Wq = w.q->w;
+    b.p = (const float*)w.pb->ptr; b.psn = w.pb->sn; b.psd = w.pb->sd; b.psh = w.pb->sh; b.psw = w.pb->sw;
+    b.Cb = w.pb->c; b.Dp = w.pb->d; b.Hp = w.pb->h; b.Wp = w.pb->w;
+    b.tq = w.q_is_x ? nl(x_norm) : nl(nullptr);
+    b.tp = w.q_is_x ? nl(nullptr) : nl(x_norm);
+    b.si = w.si; b.ntaps = w.ntaps;
+    b.slab = (float*)workspace;
+    float* dbws2 = (float*)workspace + w.slab_floats;
+    const bool bias_from_p = (w.pb == dy);
+    b.dbpart = (db != nullptr && bias_from_p) ? dbws2 : nullptr;
+    b.tz = w.tz; b.ty = w.ty; b.tx = w.tx; b.tiles = w.tiles; b.tiles_per_split = w.tps; b.CBp = w.CDp;
+    auto al4 = [](const mmtta_tensor* t) {
+      return ((((uintptr_t)t->ptr) % 16 == 0) && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0) ? 1 : 0;
+    };
+    b.qvec4 = al4(w.q); b.pvec4 = al4(w.pb);
+    const int ext = w.ntaps == 1 ? 0 : 2;
+    const int BZ = 3 * w.si + ext + 1, BY = 3 * w.si + ext + 1, BX = 7 * w.si + ext + 1;
+    const size_t lds = ((size_t)BZ * BY * BX * 4 + 128 * 32) * sizeof(float);
+    hipLaunchKernelGGL(wgrad_small_kernel, dim3(w.S, w.CDp / 32), dim3(256), lds, s, b);
+    st = launch_status("wgrad small");
+    if (st) return st;
+    const int total = w.ntaps * b.Cs * b.Cb;
+    const float* rsrc = b.slab;
+    int rn = w.nsl;
+    if (w.pre_chunks > 0) {
+      float* pre = (float*)workspace + w.slab_floats + w.db_floats;
+      const long long elems = (long long)128 * w.CDp;
+      hipLaunchKernelGGL(slab_prereduce_kernel, dim3((unsigned)((elems + 255) / 256), w.pre_chunks), dim3(256), 0, s, b.slab,
+                         pre, w.nsl, elems);
+      st = launch_status("wgrad small prereduce");
+      if (st) return st;
+      rsrc = pre; rn = w.pre_chunks;
+    }
+    hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, rsrc, dw, rn, w.ntaps, b.Cs,
+                       b.Cb, w.CDp, w.small_is_cd, accumulate);
+    st = launch_status("wgrad small reduce");
+    if (st) return st;
+    if (db != nullptr) {
+      if (bias_from_p) {
+        hipLaunchKernelGGL(db_reduce_kernel, dim3(b.Cb), dim3(64), 0, s, dbws2, db, w.nsl, b.Cb, w.CDp, accumulate);
+      } else {
+        st = launch_channel_sums(dy, dbws2, s);
+        if (st) return st;
+        hipLaunchKernelGGL(db_reduce_kernel, dim3(dy->c), dim3(64), 0, s, dbws2, db, (int)w.colsum_blocks, dy->c, 2 * dy->c,
+                           accumulate);
+      }
+      st = launch_status("bias reduce");
+    }
+    return st;
+  }
   WArgs a;
   a.g = (const float*)w.g->ptr; a.gsn = w.g->sn; a.gsd = w.g->sd; a.gsh = w.g->sh; a.gsw = w.g->sw;
   a.Cg = w.g->c; a.Dgg = w.g->d; a.Hgg = w.g->h; a.Wgg = w.g->w;
@@ -351,28 +605,37 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   a.gvec4 = ((((uintptr_t)w.g->ptr) % 16 == 0) && w.g->sw % 4 == 0 && w.g->sh % 4 == 0 && w.g->sd % 4 == 0 &&
              w.g->sn % 4 == 0) ? 1 : 0;
   a.dvec4 = 0;
-  st = (w.si == 1) ? launch_wgrad<4, 4, 8>(a, w.S, s) : launch_wgrad<2, 2, 8>(a, w.S, s);
+  if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, w.S, s);
+  else st = (w.si == 1) ? launch_wgrad<4, 4, 8, 7>(a, w.S, s) : launch_wgrad<2, 2, 8, 7>(a, w.S, s);
   if (st) return st;
-  {
-    const long long total = (long long)w.ntaps * a.Cg * a.Cd;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.slab, dw, w.nsl, w.ntaps, a.Cg, a.Cd, w.CGp,
-                       w.CDp, accumulate);
-    st = launch_status("wgrad reduce");
+  const float* rsrc = a.slab;
+  int rn = w.nsl;
+  if (w.pre_chunks > 0) {
+    float* pre = (float*)workspace + w.slab_floats + w.db_floats;
+    const long long elems = (long long)w.ntaps * w.CGp * w.CDp;
+    hipLaunchKernelGGL(slab_prereduce_kernel, dim3((unsigned)((elems + 255) / 256), w.pre_chunks), dim3(256), 0, s, a.slab, pre,
+                       w.nsl, elems);
+    st = launch_status("wgrad prereduce");
     if (st) return st;
+    rsrc = pre; rn = w.pre_chunks;
   }
+  if (w.ntaps == 27)
+    hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3(a.Cg, (a.Cd + 63) / 64), dim3(256), 0, s, rsrc, dw, rn, a.Cg, a.Cd,
+                       w.CGp, w.CDp, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((a.Cg + 31) / 32, (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
+                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate);
+  st = launch_status("wgrad reduce");
+  if (st) return st;
   if (db != nullptr) {
     if (!w.convt) {
-      hipLaunchKernelGGL(db_reduce_kernel, dim3((a.Cd + 63) / 64), dim3(64), 0, s, dbws, db, w.nsl, a.Cd, w.CDp, accumulate);
+      hipLaunchKernelGGL(db_reduce_kernel, dim3(a.Cd), dim3(64), 0, s, dbws, db, w.nsl, a.Cd, w.CDp, accumulate);
     } else {
-      const int64_t nvox = (int64_t)dy->n * dy->d * dy->h * dy->w;
-      const long long vpb = (nvox + w.colsum_blocks - 1) / w.colsum_blocks;
-      hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)w.colsum_blocks), dim3(256), 0, s, tv(dy), dbws, vpb);
-      st = launch_status("bias colsum");
+      // ConvTranspose3d bias gradient = per-channel sum of dy over the fine grid
+      st = launch_channel_sums(dy, dbws, s);
       if (st) return st;
-      hipLaunchKernelGGL(db_reduce_kernel, dim3((dy->c + 63) / 64), dim3(64), 0, s, dbws, db, (int)w.colsum_blocks, dy->c,
-                         dy->c, accumulate);
+      hipLaunchKernelGGL(db_reduce_kernel, dim3(dy->c), dim3(64), 0, s, dbws, db, (int)w.colsum_blocks, dy->c,
+                         2 * dy->c, accumulate);
     }
     st = launch_status("bias reduce");
   }

@@ -54,54 +54,92 @@ struct RedArgs {
   long long vox_per_row;
 };
 
-template <int MODE>
+// VEC = 4: every thread owns 4 consecutive channels (16-byte loads); VEC = 1: scalar fallback.
+// `regular` tensors (dense voxel order: sh == W*sw, sd == H*sh) are addressed as voxel*sw, no div/mod.
+template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void channel_reduce_kernel(RedArgs a) {
-  __shared__ float red[2][256];
+  __shared__ float red[2][VEC][256];
   const int C = a.x.c;
+  const int CV = (C + VEC - 1) / VEC;          // channel vectors
   int cpl = 1;
-  while (cpl < C && cpl < 256) cpl <<= 1;
+  while (cpl < CV && cpl < 256) cpl <<= 1;
   const int nvl = 256 / cpl;
   const int cl = threadIdx.x % cpl, vl = threadIdx.x / cpl;
   const int n = blockIdx.x / a.rows_per_n, row = blockIdx.x % a.rows_per_n;
   const long long dhw = (long long)a.x.d * a.x.h * a.x.w;
   const long long v0 = row * a.vox_per_row;
   const long long v1 = (v0 + a.vox_per_row < dhw) ? v0 + a.vox_per_row : dhw;
-  for (int cb = 0; cb < C; cb += cpl) {
-    const int c = cb + cl;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < C) {
-      float mu = 0.f, rs = 1.f, g = 1.f, b = 0.f;
-      if (MODE == 1 && a.t.mean) {
-        mu = a.t.mean[n * C + c]; rs = a.t.rstd[n * C + c];
-        if (a.t.gamma) g = a.t.gamma[c];
-        if (a.t.beta) b = a.t.beta[c];
+  const bool regx = a.x.sh == (long long)a.x.w * a.x.sw && a.x.sd == (long long)a.x.h * a.x.sh;
+  const bool regd = a.dout.sh == (long long)a.dout.w * a.dout.sw && a.dout.sd == (long long)a.dout.h * a.dout.sh;
+  for (int cb = 0; cb < CV; cb += cpl) {
+    const int c0 = (cb + cl) * VEC;
+    float s0[VEC], s1[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    if (c0 < C) {
+      float mu[VEC], rs[VEC], g[VEC], b[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        mu[j] = 0.f; rs[j] = 1.f; g[j] = 1.f; b[j] = 0.f;
+        if (MODE == 1 && a.t.mean && c0 + j < C) {
+          mu[j] = a.t.mean[n * C + c0 + j]; rs[j] = a.t.rstd[n * C + c0 + j];
+          if (a.t.gamma) g[j] = a.t.gamma[c0 + j];
+          if (a.t.beta) b[j] = a.t.beta[c0 + j];
+        }
       }
       for (long long v = v0 + vl; v < v1; v += nvl) {
-        long long t = v;
-        const int xx = (int)(t % a.x.w); t /= a.x.w;
-        const int yy = (int)(t % a.x.h);
-        const int zz = (int)(t / a.x.h);
-        const float xv = a.x.p[vox_addr(a.x, n, zz, yy, xx) + c];
-        if (MODE == 0) {
-          s0 += xv;
-          s1 += xv * xv;
+        long long ax, ad;
+        if (regx && regd) {
+          ax = (long long)n * a.x.sn + v * a.x.sw;
+          ad = (long long)n * a.dout.sn + v * a.dout.sw;
         } else {
-          const float xhat = (xv - mu) * rs;
-          float dz = a.dout.p[vox_addr(a.dout, n, zz, yy, xx) + c];
-          if (a.t.relu && !(fmaf(g, xhat, b) > 0.f)) dz = 0.f;
-          s0 += dz;
-          s1 += dz * xhat;
+          long long t = v;
+          const int xx = (int)(t % a.x.w); t /= a.x.w;
+          const int yy = (int)(t % a.x.h);
+          const int zz = (int)(t / a.x.h);
+          ax = vox_addr(a.x, n, zz, yy, xx);
+          ad = vox_addr(a.dout, n, zz, yy, xx);
+        }
+        float xv[VEC], dv[VEC];
+        if (VEC == 4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(a.x.p + ax + c0);
+          xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w;
+          if (MODE == 1) {
+            const float4 d4 = *reinterpret_cast<const float4*>(a.dout.p + ad + c0);
+            dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+          }
+        } else {
+          xv[0] = a.x.p[ax + c0];
+          if (MODE == 1) dv[0] = a.dout.p[ad + c0];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if (MODE == 0) {
+            s0[j] += xv[j];
+            s1[j] += xv[j] * xv[j];
+          } else {
+            const float xhat = (xv[j] - mu[j]) * rs[j];
+            float dz = dv[j];
+            if (a.t.relu && !(fmaf(g[j], xhat, b[j]) > 0.f)) dz = 0.f;
+            s0[j] += dz;
+            s1[j] += dz * xhat;
+          }
         }
       }
     }
-    red[0][threadIdx.x] = s0;
-    red[1][threadIdx.x] = s1;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[0][j][threadIdx.x] = s0[j]; red[1][j][threadIdx.x] = s1[j]; }
     __syncthreads();
-    if (vl == 0 && c < C) {
-      float t0 = 0.f, t1 = 0.f;
-      for (int j = 0; j < nvl; ++j) { t0 += red[0][j * cpl + cl]; t1 += red[1][j * cpl + cl]; }
-      a.part[((long long)blockIdx.x * 2 + 0) * C + c] = t0;
-      a.part[((long long)blockIdx.x * 2 + 1) * C + c] = t1;
+    if (vl == 0 && c0 < C) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (c0 + j < C) {
+          float t0 = 0.f, t1 = 0.f;
+          for (int q = 0; q < nvl; ++q) { t0 += red[0][j][q * cpl + cl]; t1 += red[1][j][q * cpl + cl]; }
+          a.part[((long long)blockIdx.x * 2 + 0) * C + c0 + j] = t0;
+          a.part[((long long)blockIdx.x * 2 + 1) * C + c0 + j] = t1;
+        }
+      }
     }
     __syncthreads();
   }
@@ -411,11 +449,26 @@ static inline bool same_shape(const mmtta_tensor* a, const mmtta_tensor* b) {
 
 static void rows_geometry(const mmtta_tensor* t, int& rows_per_n, long long& vox_per_row) {
   const long long dhw = (long long)t->d * t->h * t->w;
-  long long vpr = (dhw + 511) / 512;
-  if (vpr < 1024) vpr = 1024;
+  long long vpr = (dhw + 1023) / 1024;     // at most 1024 rows per batch item
+  if (vpr < 32) vpr = 32;
   rows_per_n = (int)((dhw + vpr - 1) / vpr);
   if (rows_per_n < 1) rows_per_n = 1;
   vox_per_row = vpr;
+}
+
+int channel_partial_rows(const mmtta_tensor* t) {
+  int r; long long v;
+  rows_geometry(t, r, v);
+  return r;
+}
+
+int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s) {
+  RedArgs a;
+  a.x = tv(x); a.dout = tv(x); a.t = nl(nullptr); a.part = part;
+  rows_geometry(x, a.rows_per_n, a.vox_per_row);
+  if (vec4_ok(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4>), dim3(x->n * a.rows_per_n), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((channel_reduce_kernel<0, 1>), dim3(x->n * a.rows_per_n), dim3(256), 0, s, a);
+  return launch_status("channel sums");
 }
 
 }  // namespace mmtta
@@ -443,7 +496,8 @@ extern "C" int mmtta_channel_stats(const mmtta_tensor* x, float* part, void* str
   RedArgs a;
   a.x = tv(x); a.dout = tv(x); a.t = nl(nullptr); a.part = part;
   rows_geometry(x, a.rows_per_n, a.vox_per_row);
-  hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(x->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
+  if (vec4_ok(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4>), dim3(x->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((channel_reduce_kernel<0, 1>), dim3(x->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status("channel_stats");
 }
 
@@ -494,7 +548,8 @@ extern "C" int mmtta_norm_bwd_reduce(const mmtta_tensor* dout, const mmtta_tenso
   RedArgs a;
   a.x = tv(y); a.dout = tv(dout); a.t = nl(t); a.part = part;
   rows_geometry(y, a.rows_per_n, a.vox_per_row);
-  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(y->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
+  if (vec4_ok(y) && vec4_ok(dout)) hipLaunchKernelGGL((channel_reduce_kernel<1, 4>), dim3(y->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((channel_reduce_kernel<1, 1>), dim3(y->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status("norm bwd reduce");
 }
 

@@ -101,15 +101,20 @@ def from_cl(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor
 
 # ----------------------------------------------------------------------------- profiling hook
 IGEMM_KERNELS = ["igemm_f32_kernel<1,4,8,8,8,8>", "igemm_f32_kernel<2,4,4,8,8,16>", "igemm_f32_kernel<4,4,4,4,8,32>",
-                 "igemm_f32_kernel<1,1,4,4,8,8>", "igemm_f32_kernel<2,2,4,4,8,8>", "igemm_f32_kernel<4,4,4,4,8,8>"]
+                 "igemm_f32_kernel<1,1,4,4,8,8>", "igemm_f32_kernel<2,2,4,4,8,8>", "igemm_f32_kernel<4,4,4,4,8,8>",
+                 "direct_conv_kernel"]
 
 
 class KernelProfiler:
     """Brackets every conv launch with events on the launch stream and books its algorithmic FLOPs
     (bench.py roofline: FLOPs per launch / measured duration).  Off unless installed in ops.PROFILER."""
 
-    def __init__(self):
+    def __init__(self, reps: int = 1):
         self.records = []   # (kernel name, launches, flops, start event, end event)
+        # reps > 1: every profiled call is issued `reps` more times back to back between the two events, so the
+        # queue stays ahead of the GPU and the host's launch latency does not leak into the measured duration
+        # (outputs of accumulating calls are then wrong: use only in a throw-away pass)
+        self.reps = max(1, int(reps))
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -205,14 +210,20 @@ class ConvOp:
         if add is not None:
             keep = desc_cl(add)
             epi = ConvEpilogue(C.pointer(keep), add_nl.struct() if add_nl is not None else _lib.norm_on_load())
-        e0 = PROFILER.begin() if PROFILER is not None else None
-        check(
-            _lib.load().mmtta_conv_run(
-                C.byref(desc), C.byref(dx), nlr, ptr(packed), ptr(bias), C.byref(epi) if epi is not None else None,
-                C.byref(dy), 1 if accumulate else 0, ptr(stats), ptr(ws), int(p.workspace_bytes), stream_ptr()),
-            "conv_run")
-        if e0 is not None:
-            PROFILER.end(IGEMM_KERNELS[p.config], int(p.launches), self.flops(x, y, desc), e0)
+        def launch():
+            check(
+                _lib.load().mmtta_conv_run(
+                    C.byref(desc), C.byref(dx), nlr, ptr(packed), ptr(bias), C.byref(epi) if epi is not None else None,
+                    C.byref(dy), 1 if accumulate else 0, ptr(stats), ptr(ws), int(p.workspace_bytes), stream_ptr()),
+                "conv_run")
+
+        launch()
+        if PROFILER is not None:
+            e0 = PROFILER.begin()
+            for _ in range(PROFILER.reps):
+                launch()
+            PROFILER.end(IGEMM_KERNELS[p.config] + ("+splitk" if p.ksplit > 1 else ""), int(p.launches) * PROFILER.reps,
+                         self.flops(x, y, desc) * PROFILER.reps, e0)
 
     def flops(self, x: torch.Tensor, y: torch.Tensor, desc=None) -> float:
         """Algorithmic FLOPs (2 x MACs) of one forward / input-gradient / weight-gradient of this module for
@@ -237,12 +248,18 @@ class ConvOp:
             check(-1, "conv_wgrad_workspace_bytes")
         ws = Workspace.get(int(need), x.device)
         nls, nlr = _nl_ref(x_nl)
-        e0 = PROFILER.begin() if PROFILER is not None else None
-        check(lib.mmtta_conv_wgrad(C.byref(self.d_fwd), C.byref(tx), nlr, C.byref(tdy), ptr(dw), ptr(db),
-                                   1 if accumulate else 0, ptr(ws), int(need), stream_ptr()), "conv_wgrad")
-        if e0 is not None:
-            name = "wgrad_f32_kernel<4,4,8>" if self.stride == 1 else "wgrad_f32_kernel<2,2,8>"
-            PROFILER.end(name + "+reduce", 1, self.flops(x, dy), e0)
+        def launch():
+            check(lib.mmtta_conv_wgrad(C.byref(self.d_fwd), C.byref(tx), nlr, C.byref(tdy), ptr(dw), ptr(db),
+                                       1 if accumulate else 0, ptr(ws), int(need), stream_ptr()), "conv_wgrad")
+
+        launch()
+        if PROFILER is not None:
+            e0 = PROFILER.begin()
+            for _ in range(PROFILER.reps):
+                launch()
+            name = "wgrad_f32_kernel<4,4,8,1>" if self.k == 1 else (
+                "wgrad_f32_kernel<4,4,8,7>" if self.stride == 1 else "wgrad_f32_kernel<2,2,8,7>")
+            PROFILER.end(name + "+reduce", PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0)
 
 
 # ----------------------------------------------------------------------------- normalisation
