@@ -30,31 +30,42 @@ namespace mmtta {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct Taps {
+struct Taps {      // host-side description of one tap set
   int n;
-  int toff[27];   // box-relative voxel offset of the tap (filled at launch: depends on the tile template)
-  int slab[27];   // weight slab of the tap.  int32 so the kernel reads both tables with SCALAR loads
+  int slab[27];
   signed char dz[27], dy[27], dx[27];
   int zmin, ymin, xmin;
   int zext, yext, xext;
+};
+
+// One output parity class of a launch (a plain conv is a single class with all its taps).  The stride-2
+// transposed forms run their 8 classes in ONE launch: class = tile index / tiles_per_cls.
+struct ClassInfo {
+  int tap0, ntaps;
+  int oz, oy, ox;
+  int zmin, ymin, xmin;
+  int zext, yext, xext;
+  int Dg, Hg, Wg;
 };
 
 struct GArgs {
   const float* in; long long isn, isd, ish, isw; int Ci, Di, Hi, Wi;
   NL tin;
   float* out; long long osn, osd, osh, osw; int Co, Do, Ho, Wo;
-  int Dg, Hg, Wg;
-  int so, oz, oy, ox;
+  int so;
   int si;
   const float* wp; int Kp, Np;
   const float* bias;
   const float* add; long long asn, asd, ash, asw; NL tadd;
   int accumulate;
-  float* stats; int stats_rows_per_n, stats_row_off;
+  float* stats; int stats_rows_per_n;
   float* ws; int ksplit, stages_per_split, nstages;
   int tz, ty, tx;
   int vec4;
-  Taps taps;
+  int ncls, tiles_per_cls;
+  ClassInfo cls[8];
+  int toff[27];   // box-relative voxel offset of each tap (int32 tables: read with SCALAR loads)
+  int slab[27];   // weight slab of each tap
 };
 
 template <int TZ, int TY, int TX>
@@ -76,17 +87,20 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
   const int cb = wave % NB, mg = wave / NB;
   const int h = lane >> 5, r = lane & 31;
 
-  int t = blockIdx.x;
+  const int cidx = blockIdx.x / a.tiles_per_cls;
+  const ClassInfo ci = a.cls[cidx];
+  int t = blockIdx.x % a.tiles_per_cls;
+  const int tile_in_n = t % (a.tz * a.ty * a.tx);
   const int txi = t % a.tx; t /= a.tx;
   const int tyi = t % a.ty; t /= a.ty;
   const int tzi = t % a.tz;
   const int n = t / a.tz;
   const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;
-  const int BZ = (TZ - 1) * a.si + a.taps.zext + 1;
-  const int BY = (TY - 1) * a.si + a.taps.yext + 1;
-  const int BX = (TX - 1) * a.si + a.taps.xext + 1;
+  const int BZ = (TZ - 1) * a.si + ci.zext + 1;
+  const int BY = (TY - 1) * a.si + ci.yext + 1;
+  const int BX = (TX - 1) * a.si + ci.xext + 1;
   const int boxvox = BZ * BY * BX;
-  const int iz0 = gz0 * a.si + a.taps.zmin, iy0 = gy0 * a.si + a.taps.ymin, ix0 = gx0 * a.si + a.taps.xmin;
+  const int iz0 = gz0 * a.si + ci.zmin, iy0 = gy0 * a.si + ci.ymin, ix0 = gx0 * a.si + ci.xmin;
 
   const int colbase = (blockIdx.y * NB + cb) * 32;
   const bool colact = colbase < a.Np;
@@ -162,21 +176,23 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
       const float* wcol = a.wp + (long long)c0 * a.Np + colbase + r + (long long)h * a.Np;
       const long long slabsz = (long long)a.Kp * a.Np;
       const int np2 = 2 * a.Np;
-      const int ntap = a.taps.n;
+      const int ntap = ci.ntaps;
+      const int* tslab = a.slab + ci.tap0;
+      const int* ttoff = a.toff + ci.tap0;
       if (kreal == KCI) {
         // full stage: branch-free body, weight fragments one tap ahead
         float bcur[KK], bnxt[KK];
         {
-          const float* wb = wcol + a.taps.slab[0] * slabsz;
+          const float* wb = wcol + tslab[0] * slabsz;
 #pragma unroll
           for (int kk = 0; kk < KK; ++kk) bcur[kk] = wb[kk * np2];
         }
         for (int tp = 0; tp < ntap; ++tp) {
           const int tn = min(tp + 1, ntap - 1);
-          const float* wb = wcol + a.taps.slab[tn] * slabsz;
+          const float* wb = wcol + tslab[tn] * slabsz;
 #pragma unroll
           for (int kk = 0; kk < KK; ++kk) bnxt[kk] = wb[kk * np2];
-          const int ta = a.taps.toff[tp] * VS;
+          const int ta = ttoff[tp] * VS;
 #pragma unroll
           for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -192,8 +208,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
         // tail stage (Cin not a multiple of KCI): only the channel pairs that carry data
         const int kkn = (kreal + 1) >> 1;
         for (int tp = 0; tp < ntap; ++tp) {
-          const float* wb = wcol + a.taps.slab[tp] * slabsz;
-          const int ta = a.taps.toff[tp] * VS;
+          const float* wb = wcol + tslab[tp] * slabsz;
+          const int ta = ttoff[tp] * VS;
           for (int kk = 0; kk < kkn; ++kk) {
             const float b = wb[kk * np2];
 #pragma unroll
@@ -239,8 +255,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
       int zl, yl, xl;
       row_to_local<TZ, TY, TX>((mg * MB + mb) * 32 + row, zl, yl, xl);
       const int gz = gz0 + zl, gy = gy0 + yl, gx = gx0 + xl;
-      if (colok && gz < a.Dg && gy < a.Hg && gx < a.Wg) {
-        const int oz = gz * a.so + a.oz, oy = gy * a.so + a.oy, ox = gx * a.so + a.ox;
+      if (colok && gz < ci.Dg && gy < ci.Hg && gx < ci.Wg) {
+        const int oz = gz * a.so + ci.oz, oy = gy * a.so + ci.oy, ox = gx * a.so + ci.ox;
         if (oz < a.Do && oy < a.Ho && ox < a.Wo) {
           float v = acc[mb][i] + bias;
           if (a.add)
@@ -271,8 +287,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
         ts += red[((g * NB + cb) * 2 + 0) * 32 + r];
         tq += red[((g * NB + cb) * 2 + 1) * 32 + r];
       }
-      const int tile_in_n = blockIdx.x % (a.tz * a.ty * a.tx);
-      const long long row = (long long)n * a.stats_rows_per_n + a.stats_row_off + tile_in_n;
+      const long long row = (long long)n * a.stats_rows_per_n + cidx * (a.tz * a.ty * a.tx) + tile_in_n;
       a.stats[(row * 2 + 0) * a.Co + col] = ts;
       a.stats[(row * 2 + 1) * a.Co + col] = tq;
     }
@@ -289,7 +304,10 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
   constexpr int RB = MT / 32;
   const int tid = threadIdx.x, r = tid & 31, rg = tid >> 5;
   const int tile = blockIdx.x / RB, rb = blockIdx.x % RB;
-  int t = tile;
+  const int cidx = tile / a.tiles_per_cls;
+  const ClassInfo ci = a.cls[cidx];
+  int t = tile % a.tiles_per_cls;
+  const int tile_in_n = t % (a.tz * a.ty * a.tx);
   const int txi = t % a.tx; t /= a.tx;
   const int tyi = t % a.ty; t /= a.ty;
   const int tzi = t % a.tz;
@@ -308,8 +326,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
     int zl, yl, xl;
     row_to_local<TZ, TY, TX>(v, zl, yl, xl);
     const int gz = tzi * TZ + zl, gy = tyi * TY + yl, gx = txi * TX + xl;
-    if (!(colok && gz < a.Dg && gy < a.Hg && gx < a.Wg)) continue;
-    const int oz = gz * a.so + a.oz, oy = gy * a.so + a.oy, ox = gx * a.so + a.ox;
+    if (!(colok && gz < ci.Dg && gy < ci.Hg && gx < ci.Wg)) continue;
+    const int oz = gz * a.so + ci.oz, oy = gy * a.so + ci.oy, ox = gx * a.so + ci.ox;
     if (!(oz < a.Do && oy < a.Ho && ox < a.Wo)) continue;
     const float* wsp = a.ws + ((long long)tile * MT + v) * a.Np + col;
     const long long kstride = (long long)tiles * MT * a.Np;
@@ -338,8 +356,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
       float ts = 0.f, tq = 0.f;
 #pragma unroll
       for (int g = 0; g < 8; ++g) { ts += red[0][g][r]; tq += red[1][g][r]; }
-      const int tile_in_n = tile % (a.tz * a.ty * a.tx);
-      const long long row = (long long)n * a.stats_rows_per_n + a.stats_row_off + tile_in_n * RB + rb;
+      const long long row = (long long)n * a.stats_rows_per_n + (cidx * (a.tz * a.ty * a.tx) + tile_in_n) * RB + rb;
       a.stats[(row * 2 + 0) * a.Co + col] = ts;
       a.stats[(row * 2 + 1) * a.Co + col] = tq;
     }
@@ -415,7 +432,7 @@ struct Geometry {
   int K, N, Kp, Np, si;
   bool classes;
   Config cfg;
-  int tz, ty, tx, tiles_per_n, tiles;
+  int tz, ty, tx, tiles_per_n, tiles, ncls;
   int nstages, ksplit, sps;
   int launches;
 };
@@ -456,14 +473,15 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   g.Np = roundup(g.N, 32);
   int Dg = y->d, Hg = y->h, Wg = y->w;
   if (g.classes) { Dg = (y->d + 1) / 2; Hg = (y->h + 1) / 2; Wg = (y->w + 1) / 2; }
-  g.cfg = pick_config(g.Np, g.si, (long long)x->n * Dg * Hg * Wg, g.K);
+  g.cfg = pick_config(g.Np, g.si, (long long)x->n * Dg * Hg * Wg * (g.classes ? 8 : 1), g.K);
   g.tz = (Dg + g.cfg.TZ - 1) / g.cfg.TZ;
   g.ty = (Hg + g.cfg.TY - 1) / g.cfg.TY;
   g.tx = (Wg + g.cfg.TX - 1) / g.cfg.TX;
   g.tiles_per_n = g.tz * g.ty * g.tx;
-  g.tiles = g.tiles_per_n * x->n;
+  g.ncls = g.classes ? 8 : 1;
+  g.tiles = g.tiles_per_n * x->n * g.ncls;     // the parity classes share one launch
   g.nstages = (g.K + g.cfg.KCI - 1) / g.cfg.KCI;
-  g.launches = g.classes ? 8 : 1;
+  g.launches = 1;
   const int ncolgroups = (g.Np + 32 * g.cfg.NB - 1) / (32 * g.cfg.NB);
   const int wgs = g.tiles * ncolgroups;
   g.ksplit = 1;
@@ -515,14 +533,19 @@ static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t
 }
 
 template <int NB, int MB, int TZ, int TY, int TX, int KCI>
-static int launch_cfg(const GArgs& a_in, int tiles, hipStream_t s) {
+static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t s) {
   GArgs a = a_in;
-  const int BZ = (TZ - 1) * a.si + a.taps.zext + 1, BY = (TY - 1) * a.si + a.taps.yext + 1,
-            BX = (TX - 1) * a.si + a.taps.xext + 1;
-  for (int t = 0; t < a.taps.n; ++t)
-    a.taps.toff[t] = ((a.taps.dz[t] - a.taps.zmin) * BY + (a.taps.dy[t] - a.taps.ymin)) * BX +
-                     (a.taps.dx[t] - a.taps.xmin);
-  size_t lds = (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
+  size_t lds = 0;
+  for (int c = 0; c < a.ncls; ++c) {
+    const Taps& tp = ht[c];
+    const int BZ = (TZ - 1) * a.si + tp.zext + 1, BY = (TY - 1) * a.si + tp.yext + 1, BX = (TX - 1) * a.si + tp.xext + 1;
+    for (int t = 0; t < tp.n; ++t) {
+      a.toff[a.cls[c].tap0 + t] = ((tp.dz[t] - tp.zmin) * BY + (tp.dy[t] - tp.ymin)) * BX + (tp.dx[t] - tp.xmin);
+      a.slab[a.cls[c].tap0 + t] = tp.slab[t];
+    }
+    const size_t need = (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
+    if (need > lds) lds = need;
+  }
   if (lds < 4 * 2 * 32 * sizeof(float)) lds = 4 * 2 * 32 * sizeof(float);
   MMTTA_CHECK(lds <= 160 * 1024, MMTTA_ERR_UNSUPPORTED, "conv: LDS box of %zu bytes exceeds 160 KiB", lds);
   auto kern = igemm_f32_kernel<NB, MB, TZ, TY, TX, KCI>;
@@ -549,14 +572,14 @@ static int config_id(const Config& c) {
   return c.KCI == 32 ? 2 : 5;
 }
 
-static int launch_any(const Config& c, const GArgs& a, int tiles, hipStream_t s) {
+static int launch_any(const Config& c, const GArgs& a, const Taps* ht, int tiles, hipStream_t s) {
   switch (config_id(c)) {
-    case 0: return launch_cfg<1, 4, 8, 8, 8, 8>(a, tiles, s);
-    case 1: return launch_cfg<2, 4, 4, 8, 8, 16>(a, tiles, s);
-    case 2: return launch_cfg<4, 4, 4, 4, 8, 32>(a, tiles, s);
-    case 3: return launch_cfg<1, 1, 4, 4, 8, 8>(a, tiles, s);
-    case 4: return launch_cfg<2, 2, 4, 4, 8, 8>(a, tiles, s);
-    default: return launch_cfg<4, 4, 4, 4, 8, 8>(a, tiles, s);
+    case 0: return launch_cfg<1, 4, 8, 8, 8, 8>(a, ht, tiles, s);
+    case 1: return launch_cfg<2, 4, 4, 8, 8, 16>(a, ht, tiles, s);
+    case 2: return launch_cfg<4, 4, 4, 4, 8, 32>(a, ht, tiles, s);
+    case 3: return launch_cfg<1, 1, 4, 4, 8, 8>(a, ht, tiles, s);
+    case 4: return launch_cfg<2, 2, 4, 4, 8, 8>(a, ht, tiles, s);
+    default: return launch_cfg<4, 4, 4, 4, 8, 8>(a, ht, tiles, s);
   }
 }
 
@@ -613,7 +636,7 @@ extern "C" int mmtta_conv_plan(const mmtta_conv_desc* d, const mmtta_tensor* x, 
   plan->tiles = g.tiles;
   plan->launches = g.launches;
   plan->ksplit = g.ksplit;
-  plan->stats_rows = g.launches * g.tiles * stats_rows_per_tile(g);
+  plan->stats_rows = g.tiles * stats_rows_per_tile(g);
   plan->config = config_id(g.cfg);
   plan->_pad = 0;
   plan->workspace_bytes =
@@ -652,26 +675,30 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   }
   a.accumulate = accumulate;
   const int srt = stats_rows_per_tile(g);
-  a.stats = stats; a.stats_rows_per_n = g.launches * g.tiles_per_n * srt;
+  a.stats = stats; a.stats_rows_per_n = g.ncls * g.tiles_per_n * srt;
   a.ws = (float*)workspace; a.ksplit = g.ksplit; a.stages_per_split = g.sps; a.nstages = g.nstages;
   a.tz = g.tz; a.ty = g.ty; a.tx = g.tx;
   const bool al = (((uintptr_t)x->ptr) % 16 == 0) && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0;
   a.vec4 = al ? 1 : 0;
-  if (!g.classes) {
-    build_taps(d, 0, 0, 0, a.taps);
-    a.so = 1; a.oz = a.oy = a.ox = 0;
-    a.Dg = y->d; a.Hg = y->h; a.Wg = y->w;
-    a.stats_row_off = 0;
-    return launch_any(g.cfg, a, g.tiles, (hipStream_t)stream);
-  }
-  for (int cls = 0; cls < 8; ++cls) {
+  Taps ht[8];
+  a.ncls = g.classes ? 8 : 1;
+  a.tiles_per_cls = g.tiles_per_n * x->n;
+  a.so = g.classes ? 2 : 1;
+  int tap0 = 0;
+  for (int cls = 0; cls < a.ncls; ++cls) {
     const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
-    build_taps(d, pz, py, px, a.taps);
-    a.so = 2; a.oz = pz; a.oy = py; a.ox = px;
-    a.Dg = (y->d - pz + 1) / 2; a.Hg = (y->h - py + 1) / 2; a.Wg = (y->w - px + 1) / 2;
-    a.stats_row_off = cls * g.tiles_per_n * srt;
-    st = launch_any(g.cfg, a, g.tiles, (hipStream_t)stream);
-    if (st) return st;
+    build_taps(d, pz, py, px, ht[cls]);
+    ClassInfo& ci = a.cls[cls];
+    ci.tap0 = tap0; ci.ntaps = ht[cls].n; tap0 += ht[cls].n;
+    ci.zmin = ht[cls].zmin; ci.ymin = ht[cls].ymin; ci.xmin = ht[cls].xmin;
+    ci.zext = ht[cls].zext; ci.yext = ht[cls].yext; ci.xext = ht[cls].xext;
+    if (g.classes) {
+      ci.oz = pz; ci.oy = py; ci.ox = px;
+      ci.Dg = (y->d - pz + 1) / 2; ci.Hg = (y->h - py + 1) / 2; ci.Wg = (y->w - px + 1) / 2;
+    } else {
+      ci.oz = ci.oy = ci.ox = 0;
+      ci.Dg = y->d; ci.Hg = y->h; ci.Wg = y->w;
+    }
   }
-  return MMTTA_OK;
+  return launch_any(g.cfg, a, ht, g.tiles, (hipStream_t)stream);
 }
