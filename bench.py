@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--task", default="brats", choices=["brats", "hecktor21"])
     ap.add_argument("--tta-steps", type=int, default=10)
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="D H W (default: 128^3 brats, 48x144x144 hecktor)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="bf16 (BASELINE configs[1]): bf16 MFMA operands, fp32 accumulate/storage; fp32: exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -52,7 +54,7 @@ def parse():
 def build_cfg(args):
     from multimodal_tta_amd.config import compose
     ov = [f"task={args.task}", f"dataset={args.task}", f"model={args.model}", "method=tta_entmin",
-          f"method.steps={args.tta_steps}"]
+          f"method.steps={args.tta_steps}", f"method.precision={args.precision}"]
     if args.task == "hecktor21" and args.model != "unet":
         ov += ["model.num_modalities=2", "model.num_classes=1"]
     if args.no_graph:
@@ -169,13 +171,15 @@ def main():
         "metric": "adapted volumes/sec", "value": args.steps * world / elapsed, "unit": "volumes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
         "post_tta_dice": post_dice,
         "config": {
             "workload": f"{cfg['model']['name']} {C}x{shape[0]}x{shape[1]}x{shape[2]} {args.task}-shaped volume: "
                         f"S={args.tta_steps} entropy-min steps (fwd+bwd+Adam, all parameters) + final forward + Dice",
             "tta_steps": args.tta_steps, "volume": [C, *shape], "adapted_params": str(cfg["method"]["params"]),
-            "precision": "fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32)", "weights": "seeded default init (no checkpoint offline)",
+            "precision": ("bf16 MFMA operands (v_mfma_f32_32x32x16_bf16) for forward/input-gradient convs, fp32 accumulate; "
+                          "fp32 storage, norms, loss, weight gradients, Adam") if args.precision == "bf16"
+            else "fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32)", "weights": "seeded default init (no checkpoint offline)",
             "parallelism": f"{world} rank(s), one per GPU, volumes sharded round-robin, one all_gather of the Dice table",
             "graph": bool(plug.use_graph),
         },

@@ -98,6 +98,18 @@ int64_t mmtta_conv_packed_bytes(const mmtta_conv_desc* desc);
  * Runs once per optimizer step. */
 int mmtta_conv_pack_weights(const mmtta_conv_desc* desc, const float* w_master, void* packed, void* stream);
 
+/* The same for MANY images in one launch (every conv of a model, both orientations): the caller builds the
+ * table once on the host (pointers are stable: arena + packed buffers), copies it to the device and then calls
+ * mmtta_conv_pack_batched once per optimizer step. */
+typedef struct {
+  mmtta_conv_desc desc;
+  const float* w_master;  /* device */
+  void* packed;           /* device */
+} mmtta_pack_item;
+int64_t mmtta_conv_pack_table_bytes(int count);
+int mmtta_conv_pack_table_build(const mmtta_pack_item* items, int count, void* table_host, int64_t* total_elements);
+int mmtta_conv_pack_batched(const void* table_dev, int count, int64_t total_elements, void* stream);
+
 /* Launch geometry chosen for a problem; filled by mmtta_conv_plan. */
 typedef struct {
   int32_t tiles;         /* M tiles (over n and space) per launch                           */

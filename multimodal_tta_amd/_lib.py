@@ -45,6 +45,10 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("desc", ConvDesc), ("w_master", C.c_void_p), ("packed", C.c_void_p)]
+
+
 class ConvPlan(C.Structure):
     _fields_ = [
         ("tiles", C.c_int32), ("launches", C.c_int32), ("ksplit", C.c_int32), ("stats_rows", C.c_int32),
@@ -63,6 +67,9 @@ _SIGNATURES = {
     "mmtta_copy_strided": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p]),
     "mmtta_conv_packed_bytes": (C.c_int64, [_P(ConvDesc)]),
     "mmtta_conv_pack_weights": (C.c_int, [_P(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmtta_conv_pack_table_bytes": (C.c_int64, [C.c_int]),
+    "mmtta_conv_pack_table_build": (C.c_int, [_P(PackItem), C.c_int, C.c_void_p, _P(C.c_int64)]),
+    "mmtta_conv_pack_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "mmtta_conv_plan": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(Tensor), _P(ConvPlan)]),
     "mmtta_conv_run": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(NormOnLoad), C.c_void_p, C.c_void_p, _P(ConvEpilogue),
                                  _P(Tensor), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -26,6 +26,24 @@ struct DArgs {
   float* stats; int blocks_per_n;
 };
 
+// valid taps of one axis for output coordinate o: (k, input coordinate) pairs
+__device__ __forceinline__ int axis_taps(int o, int ksize, int stride, int transposed, int in_extent, int* ks, int* is) {
+  const int pad = (ksize - 1) / 2;
+  int cnt = 0;
+  for (int k = 0; k < ksize; ++k) {
+    int i;
+    if (!transposed) i = o * stride + k - pad;
+    else {
+      const int t = o + pad - k;
+      if (t < 0 || (stride == 2 && (t & 1))) continue;
+      i = stride == 2 ? (t >> 1) : t;
+    }
+    if ((unsigned)i < (unsigned)in_extent) { ks[cnt] = k; is[cnt] = i; ++cnt; }
+  }
+  return cnt;
+}
+
+template <bool HAS_T>
 __global__ __launch_bounds__(256) void direct_conv_kernel(DArgs a) {
   extern __shared__ float lds[];
   const int T = a.ksize * a.ksize * a.ksize;
@@ -34,11 +52,12 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DArgs a) {
   float* red = coef + 2 * a.K;           // [sum|sq][wave][channel] = 32 floats
   const int n = blockIdx.y;
   for (int i = threadIdx.x; i < T * a.K * 4; i += 256) wl[i] = a.w[i];
-  for (int k = threadIdx.x; k < a.K; k += 256) {
-    float sc, sh;
-    nl_coeff(a.tin, n, a.K, k, sc, sh);
-    coef[2 * k] = sc; coef[2 * k + 1] = sh;
-  }
+  if (HAS_T)
+    for (int k = threadIdx.x; k < a.K; k += 256) {
+      float sc, sh;
+      nl_coeff(a.tin, n, a.K, k, sc, sh);
+      coef[2 * k] = sc; coef[2 * k + 1] = sh;
+    }
   __syncthreads();
   const long long dhw = (long long)a.out.d * a.out.h * a.out.w;
   const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -50,34 +69,25 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DArgs a) {
     ox = (int)(t % a.out.w); t /= a.out.w;
     oy = (int)(t % a.out.h);
     oz = (int)(t / a.out.h);
-    const int pad = (a.ksize - 1) / 2;
     const float* inb = a.in.p + (long long)n * a.in.sn;
     const bool vec = (a.K % 4 == 0) && (a.in.sw % 4 == 0) && (a.in.sh % 4 == 0) && (a.in.sd % 4 == 0) &&
                      (a.in.sn % 4 == 0) && (((uintptr_t)a.in.p) % 16 == 0);
-    for (int kz = 0; kz < a.ksize; ++kz) {
-      int iz;
-      if (!a.transposed) iz = oz * a.stride + kz - pad;
-      else { const int tz = oz + pad - kz; if (tz % a.stride != 0) continue; iz = tz / a.stride; }
-      if ((unsigned)iz >= (unsigned)a.in.d) continue;
-      for (int ky = 0; ky < a.ksize; ++ky) {
-        int iy;
-        if (!a.transposed) iy = oy * a.stride + ky - pad;
-        else { const int ty = oy + pad - ky; if (ty % a.stride != 0) continue; iy = ty / a.stride; }
-        if ((unsigned)iy >= (unsigned)a.in.h) continue;
-        for (int kx = 0; kx < a.ksize; ++kx) {
-          int ix;
-          if (!a.transposed) ix = ox * a.stride + kx - pad;
-          else { const int tx = ox + pad - kx; if (tx % a.stride != 0) continue; ix = tx / a.stride; }
-          if ((unsigned)ix >= (unsigned)a.in.w) continue;
-          const float* ip = inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw;
-          const float* wt = wl + ((kz * a.ksize + ky) * a.ksize + kx) * a.K * 4;
+    int kzs[3], izs[3], kys[3], iys[3], kxs[3], ixs[3];
+    const int nz = axis_taps(oz, a.ksize, a.stride, a.transposed, a.in.d, kzs, izs);
+    const int ny = axis_taps(oy, a.ksize, a.stride, a.transposed, a.in.h, kys, iys);
+    const int nx = axis_taps(ox, a.ksize, a.stride, a.transposed, a.in.w, kxs, ixs);
+    for (int az = 0; az < nz; ++az)
+      for (int ay = 0; ay < ny; ++ay)
+        for (int ax = 0; ax < nx; ++ax) {
+          const float* ip = inb + (long long)izs[az] * a.in.sd + (long long)iys[ay] * a.in.sh + (long long)ixs[ax] * a.in.sw;
+          const float* wt = wl + ((kzs[az] * a.ksize + kys[ay]) * a.ksize + kxs[ax]) * a.K * 4;
           if (vec) {
             for (int k = 0; k < a.K; k += 4) {
               const float4 x4 = *reinterpret_cast<const float4*>(ip + k);
               const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const float xv = nl_apply(xs[j], coef[2 * (k + j)], coef[2 * (k + j) + 1], a.tin.relu);
+                const float xv = HAS_T ? nl_apply(xs[j], coef[2 * (k + j)], coef[2 * (k + j) + 1], a.tin.relu) : xs[j];
                 const float4 w4 = *reinterpret_cast<const float4*>(wt + (k + j) * 4);
                 acc[0] = fmaf(xv, w4.x, acc[0]); acc[1] = fmaf(xv, w4.y, acc[1]);
                 acc[2] = fmaf(xv, w4.z, acc[2]); acc[3] = fmaf(xv, w4.w, acc[3]);
@@ -85,15 +95,13 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DArgs a) {
             }
           } else {
             for (int k = 0; k < a.K; ++k) {
-              const float xv = nl_apply(ip[k], coef[2 * k], coef[2 * k + 1], a.tin.relu);
+              const float xv = HAS_T ? nl_apply(ip[k], coef[2 * k], coef[2 * k + 1], a.tin.relu) : ip[k];
               const float4 w4 = *reinterpret_cast<const float4*>(wt + k * 4);
               acc[0] = fmaf(xv, w4.x, acc[0]); acc[1] = fmaf(xv, w4.y, acc[1]);
               acc[2] = fmaf(xv, w4.z, acc[2]); acc[3] = fmaf(xv, w4.w, acc[3]);
             }
           }
         }
-      }
-    }
   }
   // ---- epilogue
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -175,11 +183,14 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   const size_t lds = (size_t)T * a.K * 16 + (size_t)a.K * 8 + 32 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)direct_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)direct_conv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)direct_conv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     MMTTA_CHECK(e == hipSuccess, MMTTA_ERR_LAUNCH, "direct conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(direct_conv_kernel, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
+  if (a.tin.mean != nullptr) hipLaunchKernelGGL(direct_conv_kernel<true>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL(direct_conv_kernel<false>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
   return launch_status("direct conv");
 }
 

@@ -29,6 +29,15 @@
 namespace mmtta {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;   // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round to nearest even, NaN preserved)
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned int, v);
+}
 
 struct Taps {      // host-side description of one tap set
   int n;
@@ -75,10 +84,17 @@ __device__ __forceinline__ void row_to_local(int v, int& zl, int& yl, int& xl) {
   zl = v / (TX * TY);
 }
 
-template <int NB, int MB, int TZ, int TY, int TX, int KCI>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
+// BF == false: fp32 operands, v_mfma_f32_32x32x2_f32 (bit-exact fp32 products, the parity path).
+// BF == true : activations are rounded to bf16 while they are staged, weights come from a bf16 image,
+//              v_mfma_f32_32x32x16_bf16 with fp32 accumulation (16x the matrix rate: these layers turn
+//              HBM/LDS bound).  Storage, statistics, epilogue stay fp32 in both modes.
+template <int NB, int MB, int TZ, int TY, int TX, int KCI, bool BF>
+__global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
   extern __shared__ float lds[];
-  constexpr int VS = KCI + 1;
+  // LDS voxel stride: fp32: KCI+1 words (odd: the 32 rows of a fragment hit distinct banks);
+  // bf16: KCI+8 halfwords (16-byte slots stay aligned for ds_read_b128)
+  constexpr int VS = BF ? (KCI + 8) : (KCI + 1);
+  static_assert(!BF || KCI % 16 == 0, "bf16 stages are multiples of the MFMA K=16");
   constexpr int MT = TZ * TY * TX;
   constexpr int MG = 4 / NB;
   static_assert(MT == 32 * MB * MG, "tile rows must equal 32*MB*(4/NB)");
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
   for (int mb = 0; mb < MB; ++mb) {
     int zl, yl, xl;
     row_to_local<TZ, TY, TX>((mg * MB + mb) * 32 + r, zl, yl, xl);
-    rowaddr[mb] = (((zl * a.si) * BY + yl * a.si) * BX + xl * a.si) * VS + h;
+    rowaddr[mb] = (((zl * a.si) * BY + yl * a.si) * BX + xl * a.si) * VS + (BF ? 8 * h : h);
   }
 
   f32x16 acc[MB];
@@ -126,6 +142,54 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
   for (int ks = ks0; ks < ks1; ++ks) {
     const int c0 = ks * KCI;
     // ---------------- stage the input box (KCI channels) into LDS ----------------
+    if constexpr (BF) {
+      unsigned short* lh = reinterpret_cast<unsigned short*>(lds);
+      if (a.vec4) {
+        constexpr int CV8 = KCI / 8;
+        const int cv = tid % CV8;          // 256 % CV8 == 0
+        const int c = c0 + cv * 8;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (c + j < a.Ci) nl_coeff(a.tin, n, a.Ci, c + j, sc[j], sh[j]);
+          else { sc[j] = 0.f; sh[j] = 0.f; }
+        }
+        for (int bv = tid / CV8; bv < boxvox; bv += 256 / CV8) {
+          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+          const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+          uint4 pk = make_uint4(0u, 0u, 0u, 0u);
+          const bool ok = (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
+                          (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
+          if (ok) {
+            const float* src = inb + iz * a.isd + iy * a.ish + ix * a.isw + c;
+            const float4 x0 = *reinterpret_cast<const float4*>(src);
+            float4 x1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c + 4 < a.Ci) x1 = *reinterpret_cast<const float4*>(src + 4);
+            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (c + j < a.Ci) ? nl_apply(xs[j], sc[j], sh[j], a.tin.relu) : 0.f;
+            pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+            pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+          }
+          *reinterpret_cast<uint4*>(lh + bv * VS + cv * 8) = pk;
+        }
+      } else {
+        const int cc = tid % KCI;
+        const int c = c0 + cc;
+        float sc = 0.f, sh = 0.f;
+        if (c < a.Ci) nl_coeff(a.tin, n, a.Ci, c, sc, sh);
+        for (int bv = tid / KCI; bv < boxvox; bv += 256 / KCI) {
+          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+          const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+          float v = 0.f;
+          if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi &&
+              c < a.Ci)
+            v = nl_apply(inb[iz * a.isd + iy * a.ish + ix * a.isw + c], sc, sh, a.tin.relu);
+          lh[bv * VS + cc] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        }
+      }
+    } else {
     if (a.vec4) {
       constexpr int CV = KCI / 4;
       const int cv = tid % CV;           // 256 % CV == 0: fixed channel group per thread
@@ -167,8 +231,64 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
         lds[bv * VS + cc] = v;
       }
     }
+    }
     __syncthreads();
 
+    // ---------------- MFMA over taps x channel blocks ----------------
+    if constexpr (BF) {
+      if (colact) {
+        constexpr int KS = KCI / 16;
+        const unsigned short* lh = reinterpret_cast<const unsigned short*>(lds);
+        const int kreal = min(KCI, a.Ci - c0);
+        const int nks = (kreal + 15) >> 4;         // 16-channel steps that carry data
+        const uint4* wq = reinterpret_cast<const uint4*>(a.wp);   // image [tap][Kp/8][Np][8 bf16]
+        const long long slabsz8 = (long long)(a.Kp / 8) * a.Np;
+        const uint4* wcol = wq + (long long)(c0 / 8 + h) * a.Np + colbase + r;
+        const int np2 = 2 * a.Np;
+        const int ntap = ci.ntaps;
+        const int* tslab = a.slab + ci.tap0;
+        const int* ttoff = a.toff + ci.tap0;
+        if (nks == KS) {
+          uint4 bcur[KS], bnxt[KS];
+          {
+            const uint4* wb = wcol + tslab[0] * slabsz8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bcur[ks] = wb[ks * np2];
+          }
+          for (int tp = 0; tp < ntap; ++tp) {
+            const int tn = min(tp + 1, ntap - 1);
+            const uint4* wb = wcol + tslab[tn] * slabsz8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bnxt[ks] = wb[ks * np2];
+            const int ta = ttoff[tp] * VS;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bcur[ks]);
+#pragma unroll
+              for (int mb = 0; mb < MB; ++mb) {
+                const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + ks * 16);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag, acc[mb], 0, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnxt[ks];
+          }
+        } else {
+          for (int tp = 0; tp < ntap; ++tp) {
+            const uint4* wb = wcol + tslab[tp] * slabsz8;
+            const int ta = ttoff[tp] * VS;
+            for (int ks = 0; ks < nks; ++ks) {
+              const bf16x8 bfrag = __builtin_bit_cast(bf16x8, wb[ks * np2]);
+#pragma unroll
+              for (int mb = 0; mb < MB; ++mb) {
+                const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + ks * 16);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag, acc[mb], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    } else {
     // ---------------- MFMA over taps x channel pairs ----------------
     if (colact) {
       constexpr int KK = KCI / 2;
@@ -220,6 +340,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(GArgs a) {
           }
         }
       }
+    }
     }
     __syncthreads();
   }
@@ -385,8 +506,70 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// bf16 image [T][Kp/8][Np][8]: a lane's MFMA B fragment (8 consecutive k for one column) is one 16-byte load
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int A, int B, int T,
+                                         int Kp, int Np, int kn_is_ba) {
+  const long long total = (long long)T * Kp * Np;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    const int nn = (int)((i >> 3) % Np);
+    const int k8 = (int)((i / (8LL * Np)) % (Kp / 8));
+    const int tp = (int)(i / ((long long)Kp * Np));
+    const int k = k8 * 8 + j;
+    const int K = kn_is_ba ? B : A, N = kn_is_ba ? A : B;
+    float v = 0.f;
+    if (k < K && nn < N) {
+      const int ai = kn_is_ba ? nn : k, bi = kn_is_ba ? k : nn;
+      v = w[((long long)ai * B + bi) * T + tp];
+    }
+    p[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+  }
+}
+
+// All packed images of a model in ONE launch: a device table of entries, global element index -> entry by
+// binary search over the prefix sums (the per-layer launches cost ~8 us each, 46 per step for the U-Net).
+struct PackEntry {
+  const float* w; void* p;
+  int A, B, T, Kp, Np, kn_is_ba, bf16, _pad;
+  long long start;
+};
+
+__global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __restrict__ tab, int count, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const PackEntry e = tab[lo];
+    const long long li = i - e.start;
+    int nn, k, tp;
+    if (e.bf16) {
+      const int j = (int)(li & 7);
+      nn = (int)((li >> 3) % e.Np);
+      const int k8 = (int)((li / (8LL * e.Np)) % (e.Kp / 8));
+      tp = (int)(li / ((long long)e.Kp * e.Np));
+      k = k8 * 8 + j;
+    } else {
+      nn = (int)(li % e.Np);
+      k = (int)((li / e.Np) % e.Kp);
+      tp = (int)(li / ((long long)e.Np * e.Kp));
+    }
+    const int K = e.kn_is_ba ? e.B : e.A, N = e.kn_is_ba ? e.A : e.B;
+    float v = 0.f;
+    if (k < K && nn < N) {
+      const int ai = e.kn_is_ba ? nn : k, bi = e.kn_is_ba ? k : nn;
+      v = e.w[((long long)ai * e.B + bi) * e.T + tp];
+    }
+    if (e.bf16) ((unsigned short*)e.p)[li] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    else ((float*)e.p)[li] = v;
+  }
+}
+
 // ---------------------------------------------------------------- host side
-struct Config { int NB, MB, TZ, TY, TX, KCI; };
+struct Config { int NB, MB, TZ, TY, TX, KCI; bool bf; };
 
 static inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -399,19 +582,26 @@ static void op_dims(const mmtta_conv_desc* d, int& K, int& N, int& si, bool& cla
   }
 }
 
-static Config pick_config(int Np, int si, long long voxels, int K) {
+static Config pick_config(int Np, int si, long long voxels, int K, bool bf) {
+  // fp32 stage depth / bf16 stage depth (bf16 stages are multiples of the MFMA K = 16)
   if (si == 1) {
-    if (Np == 32) return {1, 4, 8, 8, 8, 8};
-    if (Np == 64) return {2, 4, 4, 8, 8, 16};
-    // wide layers on a small grid (the 8^3 / 16^3 levels): 8-channel stages so that split-K can reach
+    if (Np == 32) return {1, 4, 8, 8, 8, bf ? 16 : 8, bf};
+    if (Np == 64) return {2, 4, 4, 8, 8, bf ? 32 : 16, bf};
+    // wide layers on a small grid (the 8^3 / 16^3 levels): shallow stages so that split-K can reach
     // >= 256 workgroups; otherwise 32-channel stages (fewer barriers, fewer weight fetches)
     const long long tiles = (voxels + 127) / 128, colgroups = (Np + 127) / 128;
-    if (tiles * colgroups * ((K + 31) / 32) < 384) return {4, 4, 4, 4, 8, 8};
-    return {4, 4, 4, 4, 8, 32};
+    if (tiles * colgroups * ((K + 31) / 32) < 384) return {4, 4, 4, 4, 8, bf ? 16 : 8, bf};
+    return {4, 4, 4, 4, 8, 32, bf};
   }
-  if (Np == 32) return {1, 1, 4, 4, 8, 8};
-  if (Np == 64) return {2, 2, 4, 4, 8, 8};
-  return {4, 4, 4, 4, 8, 8};
+  if (Np == 32) return {1, 1, 4, 4, 8, bf ? 16 : 8, bf};
+  if (Np == 64) return {2, 2, 4, 4, 8, bf ? 16 : 8, bf};
+  return {4, 4, 4, 4, 8, bf ? 16 : 8, bf};
+}
+
+// bf16 operands only where the reduction is deep enough for the K=16 MFMA and the layer is not on the
+// direct (<= 4 produced channels) path; everything else computes in fp32 whatever desc.dtype says.
+static bool use_bf16(const mmtta_conv_desc* d, int K) {
+  return d->dtype == MMTTA_BF16 && K >= 16 && !direct_applicable(d);
 }
 
 static int validate_desc(const mmtta_conv_desc* d) {
@@ -421,7 +611,7 @@ static int validate_desc(const mmtta_conv_desc* d) {
   MMTTA_CHECK(d->stride == 1 || d->stride == 2, MMTTA_ERR_UNSUPPORTED, "conv: stride %d (1 or 2)", d->stride);
   MMTTA_CHECK(!(d->ksize == 1 && d->stride != 1), MMTTA_ERR_UNSUPPORTED, "conv: 1x1x1 with stride 2");
   MMTTA_CHECK(d->cin > 0 && d->cout > 0, MMTTA_ERR_INVALID, "conv: channels must be positive");
-  MMTTA_CHECK(d->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "conv: dtype %d (this build: fp32)", d->dtype);
+  MMTTA_CHECK(d->dtype == MMTTA_F32 || d->dtype == MMTTA_BF16, MMTTA_ERR_UNSUPPORTED, "conv: dtype %d", d->dtype);
   if (d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONVT_DGRAD)
     MMTTA_CHECK(d->ksize == 3 && d->stride == 2, MMTTA_ERR_UNSUPPORTED,
                 "conv_transpose: only k3 s2 p1 op1 (the monai UNet up layer)");
@@ -473,7 +663,7 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   g.Np = roundup(g.N, 32);
   int Dg = y->d, Hg = y->h, Wg = y->w;
   if (g.classes) { Dg = (y->d + 1) / 2; Hg = (y->h + 1) / 2; Wg = (y->w + 1) / 2; }
-  g.cfg = pick_config(g.Np, g.si, (long long)x->n * Dg * Hg * Wg * (g.classes ? 8 : 1), g.K);
+  g.cfg = pick_config(g.Np, g.si, (long long)x->n * Dg * Hg * Wg * (g.classes ? 8 : 1), g.K, use_bf16(d, g.K));
   g.tz = (Dg + g.cfg.TZ - 1) / g.cfg.TZ;
   g.ty = (Hg + g.cfg.TY - 1) / g.cfg.TY;
   g.tx = (Wg + g.cfg.TX - 1) / g.cfg.TX;
@@ -532,7 +722,7 @@ static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t
   t.zext = zmx - zmn; t.yext = ymx - ymn; t.xext = xmx - xmn;
 }
 
-template <int NB, int MB, int TZ, int TY, int TX, int KCI>
+template <int NB, int MB, int TZ, int TY, int TX, int KCI, bool BF>
 static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t s) {
   GArgs a = a_in;
   size_t lds = 0;
@@ -543,12 +733,12 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
       a.toff[a.cls[c].tap0 + t] = ((tp.dz[t] - tp.zmin) * BY + (tp.dy[t] - tp.ymin)) * BX + (tp.dx[t] - tp.xmin);
       a.slab[a.cls[c].tap0 + t] = tp.slab[t];
     }
-    const size_t need = (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
+    const size_t need = BF ? (size_t)BZ * BY * BX * (KCI + 8) * 2 : (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
     if (need > lds) lds = need;
   }
   if (lds < 4 * 2 * 32 * sizeof(float)) lds = 4 * 2 * 32 * sizeof(float);
   MMTTA_CHECK(lds <= 160 * 1024, MMTTA_ERR_UNSUPPORTED, "conv: LDS box of %zu bytes exceeds 160 KiB", lds);
-  auto kern = igemm_f32_kernel<NB, MB, TZ, TY, TX, KCI>;
+  auto kern = igemm_kernel<NB, MB, TZ, TY, TX, KCI, BF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -567,19 +757,27 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
 }
 
 static int config_id(const Config& c) {
-  if (c.NB == 1) return c.MB == 4 ? 0 : 3;
-  if (c.NB == 2) return c.MB == 4 ? 1 : 4;
-  return c.KCI == 32 ? 2 : 5;
+  int id;
+  if (c.NB == 1) id = c.MB == 4 ? 0 : 3;
+  else if (c.NB == 2) id = c.MB == 4 ? 1 : 4;
+  else id = c.KCI == 32 ? 2 : 5;
+  return c.bf ? id + 7 : id;      // 6 = direct kernel; 7..12 = bf16 variants
 }
 
 static int launch_any(const Config& c, const GArgs& a, const Taps* ht, int tiles, hipStream_t s) {
   switch (config_id(c)) {
-    case 0: return launch_cfg<1, 4, 8, 8, 8, 8>(a, ht, tiles, s);
-    case 1: return launch_cfg<2, 4, 4, 8, 8, 16>(a, ht, tiles, s);
-    case 2: return launch_cfg<4, 4, 4, 4, 8, 32>(a, ht, tiles, s);
-    case 3: return launch_cfg<1, 1, 4, 4, 8, 8>(a, ht, tiles, s);
-    case 4: return launch_cfg<2, 2, 4, 4, 8, 8>(a, ht, tiles, s);
-    default: return launch_cfg<4, 4, 4, 4, 8, 8>(a, ht, tiles, s);
+    case 0: return launch_cfg<1, 4, 8, 8, 8, 8, false>(a, ht, tiles, s);
+    case 1: return launch_cfg<2, 4, 4, 8, 8, 16, false>(a, ht, tiles, s);
+    case 2: return launch_cfg<4, 4, 4, 4, 8, 32, false>(a, ht, tiles, s);
+    case 3: return launch_cfg<1, 1, 4, 4, 8, 8, false>(a, ht, tiles, s);
+    case 4: return launch_cfg<2, 2, 4, 4, 8, 8, false>(a, ht, tiles, s);
+    case 5: return launch_cfg<4, 4, 4, 4, 8, 8, false>(a, ht, tiles, s);
+    case 7: return launch_cfg<1, 4, 8, 8, 8, 16, true>(a, ht, tiles, s);
+    case 8: return launch_cfg<2, 4, 4, 8, 8, 32, true>(a, ht, tiles, s);
+    case 9: return launch_cfg<4, 4, 4, 4, 8, 32, true>(a, ht, tiles, s);
+    case 10: return launch_cfg<1, 1, 4, 4, 8, 16, true>(a, ht, tiles, s);
+    case 11: return launch_cfg<2, 2, 4, 4, 8, 16, true>(a, ht, tiles, s);
+    default: return launch_cfg<4, 4, 4, 4, 8, 16, true>(a, ht, tiles, s);
   }
 }
 
@@ -593,7 +791,7 @@ extern "C" int64_t mmtta_conv_packed_bytes(const mmtta_conv_desc* d) {
   op_dims(d, K, N, si, cl);
   const int T = d->ksize * d->ksize * d->ksize;
   if (direct_applicable(d)) return (int64_t)T * K * 4 * (int64_t)sizeof(float);
-  return (int64_t)T * roundup(K, 32) * roundup(N, 32) * (int64_t)sizeof(float);
+  return (int64_t)T * roundup(K, 32) * roundup(N, 32) * (int64_t)(use_bf16(d, K) ? 2 : sizeof(float));
 }
 
 extern "C" int mmtta_conv_pack_weights(const mmtta_conv_desc* d, const float* w, void* packed, void* stream) {
@@ -612,9 +810,56 @@ extern "C" int mmtta_conv_pack_weights(const mmtta_conv_desc* d, const float* w,
   const long long total = (long long)T * Kp * Np;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, A, B, T,
-                     Kp, Np, kn_is_ba);
+  if (use_bf16(d, K))
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed,
+                       A, B, T, Kp, Np, kn_is_ba);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, A, B, T,
+                       Kp, Np, kn_is_ba);
   return launch_status("pack weights");
+}
+
+static int fill_pack_entry(const mmtta_conv_desc* d, const float* w, void* packed, PackEntry& e) {
+  int st = validate_desc(d);
+  if (st) return st;
+  MMTTA_CHECK(w && packed, MMTTA_ERR_INVALID, "pack: null pointer");
+  int K, N, si; bool cl;
+  op_dims(d, K, N, si, cl);
+  const bool convt = d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONVT_DGRAD;
+  const bool direct = direct_applicable(d);
+  e.w = w; e.p = packed;
+  e.A = convt ? d->cin : d->cout; e.B = convt ? d->cout : d->cin;
+  e.T = d->ksize * d->ksize * d->ksize;
+  e.Kp = direct ? K : roundup(K, 32); e.Np = direct ? 4 : roundup(N, 32);
+  e.kn_is_ba = (d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_DGRAD) ? 1 : 0;
+  e.bf16 = use_bf16(d, K) ? 1 : 0; e._pad = 0;
+  e.start = 0;
+  return MMTTA_OK;
+}
+
+extern "C" int64_t mmtta_conv_pack_table_bytes(int count) { return count < 0 ? -1 : (int64_t)count * (int64_t)sizeof(PackEntry); }
+
+extern "C" int mmtta_conv_pack_table_build(const mmtta_pack_item* items, int count, void* table_host, int64_t* total) {
+  MMTTA_CHECK(items && table_host && total && count > 0, MMTTA_ERR_INVALID, "pack table: bad argument");
+  PackEntry* tab = (PackEntry*)table_host;
+  long long run = 0;
+  for (int i = 0; i < count; ++i) {
+    int st = fill_pack_entry(&items[i].desc, items[i].w_master, items[i].packed, tab[i]);
+    if (st) return st;
+    tab[i].start = run;
+    run += (long long)tab[i].T * tab[i].Kp * tab[i].Np;
+  }
+  *total = run;
+  return MMTTA_OK;
+}
+
+extern "C" int mmtta_conv_pack_batched(const void* table_dev, int count, int64_t total, void* stream) {
+  MMTTA_CHECK(table_dev && count > 0 && total > 0, MMTTA_ERR_INVALID, "pack batched: bad argument");
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev,
+                     count, (long long)total);
+  return launch_status("pack batched");
 }
 
 extern "C" int mmtta_conv_plan(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y,

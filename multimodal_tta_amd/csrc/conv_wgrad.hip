@@ -428,7 +428,9 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
               "wgrad: desc.op must name the module (CONV_FWD or CONVT_FWD)");
   MMTTA_CHECK(d->ksize == 1 || d->ksize == 3, MMTTA_ERR_UNSUPPORTED, "wgrad: ksize %d", d->ksize);
   MMTTA_CHECK(d->stride == 1 || d->stride == 2, MMTTA_ERR_UNSUPPORTED, "wgrad: stride %d", d->stride);
-  MMTTA_CHECK(d->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "wgrad: dtype %d (this build: fp32)", d->dtype);
+  // desc.dtype selects the operand type of the data-path convolutions; weight gradients always accumulate
+  // fp32 products of fp32 operands
+  MMTTA_CHECK(d->dtype == MMTTA_F32 || d->dtype == MMTTA_BF16, MMTTA_ERR_UNSUPPORTED, "wgrad: dtype %d", d->dtype);
   MMTTA_CHECK(is_cl(x) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "wgrad: tensors must be channels-last");
   MMTTA_CHECK(x->c == d->cin && dy->c == d->cout && x->n == dy->n, MMTTA_ERR_INVALID, "wgrad: channel/batch mismatch");
   w.convt = d->op == MMTTA_CONVT_FWD;

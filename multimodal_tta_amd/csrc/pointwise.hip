@@ -162,6 +162,46 @@ __global__ __launch_bounds__(64) void rows_reduce_kernel(const float* part, int 
   }
 }
 
+// InstanceNorm fast path: one wave per (n,c) reduces the partial rows AND finishes the statistics
+// (no cross-(n,c) coupling), one launch instead of two.
+__global__ __launch_bounds__(64) void instance_stats_kernel(const float* part, int rows_per_n, int C, double count, float eps,
+                                                            float* mean, float* rstd) {
+  const int n = blockIdx.x / C, c = blockIdx.x % C;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = threadIdx.x; r < rows_per_n; r += 64) {
+    const long long row = (long long)n * rows_per_n + r;
+    s0 += (double)part[(row * 2 + 0) * C + c];
+    s1 += (double)part[(row * 2 + 1) * C + c];
+  }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  if (threadIdx.x == 0) {
+    const double mu = s0 / count;
+    double var = s1 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[blockIdx.x] = (float)mu;
+    rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+__global__ __launch_bounds__(64) void instance_bwd_kernel(const float* part, int rows_per_n, int C, double count,
+                                                          const float* gamma, float* m1, float* m2) {
+  const int n = blockIdx.x / C, c = blockIdx.x % C;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = threadIdx.x; r < rows_per_n; r += 64) {
+    const long long row = (long long)n * rows_per_n + r;
+    s0 += (double)part[(row * 2 + 0) * C + c];
+    s1 += (double)part[(row * 2 + 1) * C + c];
+  }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  if (threadIdx.x == 0) {
+    const double g = gamma ? (double)gamma[c] : 1.0;
+    m1[blockIdx.x] = (float)(g * s0 / count);
+    m2[blockIdx.x] = (float)(g * s1 / count);
+  }
+}
+
 struct StatFinArgs {
   int kind, groups, N, C;
   double count;
@@ -512,6 +552,11 @@ extern "C" int mmtta_norm_stats_finalize(int kind, int groups, const float* part
   if (kind == MMTTA_NORM_GROUP) MMTTA_CHECK(groups > 0 && c % groups == 0, MMTTA_ERR_INVALID, "group norm: C %% groups != 0");
   if (kind == MMTTA_NORM_BATCH && !training) MMTTA_CHECK(running_mean && running_var, MMTTA_ERR_INVALID, "batch norm eval needs running stats");
   hipStream_t s = (hipStream_t)stream;
+  if (kind == MMTTA_NORM_INSTANCE) {
+    MMTTA_CHECK(part != nullptr && rows_per_n > 0, MMTTA_ERR_INVALID, "norm finalize: null partials");
+    hipLaunchKernelGGL(instance_stats_kernel, dim3(n * c), dim3(64), 0, s, part, rows_per_n, c, (double)count, eps, mean, rstd);
+    return launch_status("instance norm stats");
+  }
   const bool need_rows = !(kind == MMTTA_NORM_BATCH && !training);
   if (need_rows) {
     MMTTA_CHECK(part != nullptr && rows_per_n > 0, MMTTA_ERR_INVALID, "norm finalize: null partials");
@@ -562,6 +607,10 @@ extern "C" int mmtta_norm_bwd_finalize(int kind, int groups, const float* part, 
   double* g_tot = scratch;
   if (kind == MMTTA_NORM_GROUP) MMTTA_CHECK(groups > 0 && c % groups == 0, MMTTA_ERR_INVALID, "group norm: C %% groups != 0");
   hipStream_t s = (hipStream_t)stream;
+  if (kind == MMTTA_NORM_INSTANCE && dgamma == nullptr) {
+    hipLaunchKernelGGL(instance_bwd_kernel, dim3(n * c), dim3(64), 0, s, part, rows_per_n, c, (double)count, gamma, m1, m2);
+    return launch_status("instance norm bwd finalize");
+  }
   hipLaunchKernelGGL(rows_reduce_kernel, dim3(n * c), dim3(64), 0, s, part, rows_per_n, c, g_tot);
   int st = launch_status("norm bwd rows reduce");
   if (st) return st;

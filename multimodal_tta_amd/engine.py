@@ -301,8 +301,9 @@ class ResidualUnitBlock(Block):
 class Runtime:
     """Owns the arena, the buffer pool and the conv layers of one model instance on one device."""
 
-    def __init__(self, device: torch.device):
+    def __init__(self, device: torch.device, conv_dtype: int = ops.F32):
         self.device = device
+        self.conv_dtype = conv_dtype   # ops.F32: exact fp32 MFMA; ops.BF16: bf16 operands / fp32 accumulate
         self.pool = Pool(device)
         self.training = False
         self.convs: List[ConvLayer] = []
@@ -321,7 +322,7 @@ class Runtime:
         k = module.kernel_size[0]
         s = module.stride[0]
         cin, cout = module.in_channels, module.out_channels
-        op = ConvOp(cin, cout, k, s, transposed, self.device)
+        op = ConvOp(cin, cout, k, s, transposed, self.device, dtype=self.conv_dtype)
         w = self.make_ref(name + ".weight", module.weight)
         b = self.make_ref(name + ".bias", module.bias) if module.bias is not None else None
         layer = ConvLayer(op, w, b)
@@ -348,8 +349,20 @@ class Runtime:
         return self.arena
 
     def pack_all(self) -> None:
-        for c in self.convs:
-            c.pack()
+        """Refresh every packed weight image from the arena (one launch)."""
+        if getattr(self, "_packer", None) is None or self._packer_base != self.arena.params.data_ptr():
+            items = []
+            seen = set()
+            for c in self.convs:
+                if id(c.op) in seen:
+                    continue
+                seen.add(id(c.op))
+                items.append((c.op.d_fwd, c.weight.data, c.op.packed_fwd))
+                if c.op.need_dgrad:
+                    items.append((c.op.d_dgrad, c.weight.data, c.op.packed_dgrad))
+            self._packer = ops.BatchedPacker(items, self.device)
+            self._packer_base = self.arena.params.data_ptr()
+        self._packer.run()
 
     def snapshot_buffers(self) -> None:
         """Source values of the running statistics (BatchNorm), restored with the weights per volume."""

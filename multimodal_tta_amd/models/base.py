@@ -53,8 +53,20 @@ class HipSegModel(nn.Module):
         self._trainable: Optional[Set[str]] = None
         self._no_decay_keys: Sequence[str] = DEFAULT_NO_DECAY_KEYS
         self._treat_1d = True
+        self.conv_dtype = ops.F32
 
     # ---- engine binding
+    def set_precision(self, precision: str) -> None:
+        """'fp32': exact fp32 MFMA everywhere (the parity path).  'bf16': forward / input-gradient convolutions
+        round their operands to bf16 and accumulate in fp32; storage, norms, loss, weight gradients and the
+        optimizer stay fp32."""
+        if precision not in ops.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(ops.PRECISIONS)}, got {precision!r}")
+        dt = ops.PRECISIONS[precision]
+        if dt != self.conv_dtype:
+            self.conv_dtype = dt
+            self._rt = None
+
     def configure_training(self, trainable: Optional[Set[str]] = None,
                            no_decay_keys: Sequence[str] = DEFAULT_NO_DECAY_KEYS, treat_1d: bool = True) -> None:
         """Choose which parameters adapt (None = all) and the decay / no-decay split

@@ -60,7 +60,7 @@ class DeepFusionRuntime(Runtime):
     supports_present = True
 
     def __init__(self, model: "MultimodalUNetDeepFusion", device: torch.device):
-        super().__init__(device)
+        super().__init__(device, model.conv_dtype)
         self.M = model.num_modalities
         self.in_channels = self.M
         self.channels = list(model.channels)

@@ -15,10 +15,11 @@ from typing import Dict, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (CONV_DGRAD, CONV_FWD, CONVT_DGRAD, CONVT_FWD, F32, NORM_BATCH, NORM_GROUP, NORM_INSTANCE,
+from ._lib import (BF16, CONV_DGRAD, CONV_FWD, CONVT_DGRAD, CONVT_FWD, F32, NORM_BATCH, NORM_GROUP, NORM_INSTANCE,
                    ConvDesc, ConvEpilogue, ConvPlan, MmttaError, check, desc_cl, desc_ncdhw, ptr, stream_ptr)
 
 NORM_KINDS = {"INSTANCE": NORM_INSTANCE, "BATCH": NORM_BATCH, "GROUP": NORM_GROUP}
+PRECISIONS = {"fp32": F32, "f32": F32, "bf16": BF16}
 
 
 def _require_cuda() -> None:
@@ -102,7 +103,9 @@ def from_cl(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor
 # ----------------------------------------------------------------------------- profiling hook
 IGEMM_KERNELS = ["igemm_f32_kernel<1,4,8,8,8,8>", "igemm_f32_kernel<2,4,4,8,8,16>", "igemm_f32_kernel<4,4,4,4,8,32>",
                  "igemm_f32_kernel<1,1,4,4,8,8>", "igemm_f32_kernel<2,2,4,4,8,8>", "igemm_f32_kernel<4,4,4,4,8,8>",
-                 "direct_conv_kernel"]
+                 "direct_conv_kernel",
+                 "igemm_kernel<1,4,8,8,8,16,bf16>", "igemm_kernel<2,4,4,8,8,32,bf16>", "igemm_kernel<4,4,4,4,8,32,bf16>",
+                 "igemm_kernel<1,1,4,4,8,16,bf16>", "igemm_kernel<2,2,4,4,8,16,bf16>", "igemm_kernel<4,4,4,4,8,16,bf16>"]
 
 
 class KernelProfiler:
@@ -260,6 +263,32 @@ class ConvOp:
             name = "wgrad_f32_kernel<4,4,8,1>" if self.k == 1 else (
                 "wgrad_f32_kernel<4,4,8,7>" if self.stride == 1 else "wgrad_f32_kernel<2,2,8,7>")
             PROFILER.end(name + "+reduce", PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0)
+
+
+class BatchedPacker:
+    """Every packed weight image of a model refreshed by ONE kernel launch (the table is built once: parameter
+    and image addresses are stable while the arena lives)."""
+
+    def __init__(self, items, device):
+        """items: list of (ConvDesc, master weight tensor, packed image tensor)."""
+        lib = _lib.load()
+        n = len(items)
+        arr = (_lib.PackItem * n)()
+        for i, (desc, w, packed) in enumerate(items):
+            arr[i].desc = desc
+            arr[i].w_master = ptr(w)
+            arr[i].packed = ptr(packed)
+        nbytes = int(lib.mmtta_conv_pack_table_bytes(n))
+        host = (C.c_uint8 * nbytes)()
+        total = C.c_int64(0)
+        check(lib.mmtta_conv_pack_table_build(arr, n, host, C.byref(total)), "conv_pack_table_build")
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+        self.count, self.total = n, int(total.value)
+        self._keep = [t for it in items for t in it[1:]]
+
+    def run(self) -> None:
+        check(_lib.load().mmtta_conv_pack_batched(ptr(self.table), self.count, self.total, stream_ptr()),
+              "conv_pack_batched")
 
 
 # ----------------------------------------------------------------------------- normalisation

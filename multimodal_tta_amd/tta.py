@@ -101,8 +101,8 @@ class EntropyMinimizationTTA:
         self.treat_1d = bool(get_config(rules, "treat_1d_as_no_decay", True))
         crit = get_config(tr, "criterion", {}) or {}
         self.softmax = bool(get_config(crit, "softmax", False))
-        if self.precision not in ("fp32",):
-            raise NotImplementedError(f"method.precision={self.precision}: this build computes in fp32 (fp32 MFMA)")
+        if self.precision not in ops.PRECISIONS:
+            raise ValueError(f"method.precision={self.precision}: expected one of {sorted(ops.PRECISIONS)}")
         self.model: Optional[HipSegModel] = None
         self.rt = None
         self._graphs: Dict[Tuple, torch.cuda.CUDAGraph] = {}
@@ -116,6 +116,7 @@ class EntropyMinimizationTTA:
         device = torch.device(device)
         self.model = model
         names = select_params(model, self.params_spec)
+        model.set_precision(self.precision)
         model.configure_training(set(names), self.no_decay_keys, self.treat_1d)
         model.to(device)
         self.rt = model.runtime(device)

@@ -167,3 +167,62 @@ def test_conv_channel_slices():
     torch.cuda.synchronize()
     close("slice forward", ncdhw(out[..., 32:64]), y_ref)
     assert out[..., :32].abs().max().item() == 0 and out[..., 64:].abs().max().item() == 0
+
+
+BF16_CASES = [
+    (32, 32, 3, 1, False, (1, 16, 16, 16)),
+    (33, 32, 3, 1, False, (1, 8, 8, 16)),        # 16-channel tail step
+    (64, 64, 3, 1, False, (1, 8, 8, 8)),
+    (128, 136, 3, 1, False, (2, 4, 6, 8)),
+    (32, 64, 3, 2, False, (1, 8, 8, 16)),
+    (64, 128, 3, 2, False, (1, 5, 6, 7)),
+    (512, 512, 3, 1, False, (1, 4, 4, 4)),       # split-K
+    (256, 512, 1, 1, False, (1, 4, 4, 4)),
+    (64, 32, 3, 2, True, (1, 4, 4, 8)),
+    (768, 128, 3, 2, True, (1, 2, 2, 2)),
+    (4, 32, 3, 2, False, (1, 16, 16, 16)),       # K < 16: stays on the fp32 kernel
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", BF16_CASES)
+def test_conv_bf16_operands(cin, cout, k, stride, transposed, shape):
+    """dtype=BF16: operands rounded to bf16 (8 significant bits), fp32 accumulation.  Against the fp32 torch
+    result the error of a K-term dot product is ~2^-8 * rms(terms) * sqrt(K) / ... : stated bound
+    |err| <= 1.5e-2 * max|ref| (forward and input gradient); the weight gradient stays fp32-exact."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(99 + cin + cout)
+    n, d, h, w = shape
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = torch.randn(n, cin, d, h, w, requires_grad=True)
+    y_ref = mod(x)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+    wt = mod.weight.detach().cuda().contiguous()
+    op.pack(wt)
+    x_cl, gy_cl = cl(x.detach()), cl(gy)
+    y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda")
+    rows = op.stats_rows(x_cl, y_cl)
+    stats = torch.empty((rows, 2, cout), device="cuda")
+    op.forward(x_cl, None, mod.bias.detach().cuda(), y_cl, stats=stats)
+    dx_cl = ops.new_cl(n, d, h, w, cin, "cuda")
+    op.dgrad(gy_cl, dx_cl)
+    dw = torch.empty_like(wt)
+    op.wgrad(x_cl, None, gy_cl, dw, None)
+    torch.cuda.synchronize()
+
+    def bf_close(name, got, ref):
+        err = (got.cpu() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert err <= 1.5e-2 * scale + 1e-5, f"{name}: max|err|={err:.3e} (max|ref|={scale:.3e})"
+        return err / scale
+
+    e1 = bf_close("bf16 forward", ncdhw(y_cl), y_ref.detach())
+    e2 = bf_close("bf16 dgrad", ncdhw(dx_cl), x.grad)
+    if cin >= 16 and cout > 4:
+        assert e1 > 1e-5, "bf16 path not taken (result is fp32-exact)"
+    close("wgrad stays fp32", dw, mod.weight.grad)
+    st = stats.view(n, rows // n, 2, cout).double().sum(1).cpu()
+    got_sum = ncdhw(y_cl).double().sum(dim=(2, 3, 4))
+    assert torch.allclose(st[:, 0], got_sum, rtol=1e-3, atol=1e-2 * max(1.0, got_sum.abs().max().item()))

@@ -184,3 +184,37 @@ def test_seg_tta_eval_single_rank():
     m = get_evaluation_strategy("seg_tta_eval")(cfg).evaluate_epoch(hip, loader, torch.device("cuda"))
     assert {"et_dc", "tc_dc", "wt_dc", "avg_dc", "miou", "jc", "loss", "dom/synth/avg_dc"} <= set(m)
     assert 0.0 <= m["avg_dc"] <= 1.0 and m["loss"] > 0.0
+
+
+@pytest.mark.parametrize("lr", [1e-5, 1e-3])
+def test_bf16_precision_tracks_the_fp32_oracle(lr):
+    """method.precision=bf16 (BASELINE configs[1]): forward / input-gradient convolutions use bf16 operands with
+    fp32 accumulation; everything else stays fp32.  Stated tolerance against the fp32 CPU oracle after S=3 steps
+    at the reference's learning rate (1e-5, configs/training/default.yaml:31): per-step loss within 1e-2 relative,
+    logits within 3e-2 of max|logits|, at most 1 % of mask voxels differ, Dice within 2e-2.  At lr=1e-3 Adam's
+    sign-like updates amplify the bf16 rounding of small gradients, so only the losses (1e-2) and the Dice (5e-2)
+    are bounded there; the logits deviation is printed."""
+    import oracle
+    from multimodal_tta_amd.registry import get_plugin
+
+    cfg = root_cfg(SMALL, steps=3, lr=lr, precision="bf16")
+    ref, hip = build_pair(SMALL)
+    x, y = volume(5)
+    out_ref = oracle.adapt_volume(ref, x, cfg["training"], steps=3)
+    plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    res = plug.adapt_volume(x.cuda())
+    for a, b in zip(res["losses"].cpu().tolist(), out_ref["losses"]):
+        assert abs(a - b) <= 1e-2 * abs(b), (a, b)
+    z_hip, z_ref = plug.logits(res).cpu(), out_ref["logits"]
+    err = (z_hip - z_ref).abs().max().item() / z_ref.abs().max().item()
+    m_hip, m_ref = torch.sigmoid(z_hip) >= 0.5, torch.sigmoid(z_ref) >= 0.5
+    mism = (m_hip != m_ref).float().mean().item()
+    d_ref, _, _ = oracle.binary_dice_iou(m_ref.to(torch.uint8), (y > 0.5).to(torch.uint8))
+    d_hip, _, _ = oracle.binary_dice_iou(m_hip.to(torch.uint8), (y > 0.5).to(torch.uint8))
+    ddice = (d_hip - d_ref).abs().max().item()
+    print(f"bf16 lr={lr}: logits rel err {err:.3e}, mask mismatch {mism:.3e}, dDice {ddice:.3e}")
+    assert err > 1e-6, "bf16 path not taken"
+    if lr <= 1e-5:
+        assert err < 3e-2 and mism <= 1e-2 and ddice <= 2e-2
+    else:
+        assert ddice <= 5e-2
