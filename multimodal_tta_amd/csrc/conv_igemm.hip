@@ -249,29 +249,38 @@ __global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
         const int* tslab = a.slab + ci.tap0;
         const int* ttoff = a.toff + ci.tap0;
         if (nks == KS) {
-          uint4 bcur[KS], bnxt[KS];
-          {
-            const uint4* wb = wcol + tslab[0] * slabsz8;
+          // A tap is only MB*KS MFMAs of 32 cycles: far less than an L2 round trip, so the weight fragments
+          // run through a ring of D taps in flight (static register indices: the tap loop is unrolled by D).
+          constexpr int D = 4;
+          uint4 ring[D][KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) bcur[ks] = wb[ks * np2];
+          for (int d = 0; d < D; ++d) {
+            const uint4* wb = wcol + tslab[min(d, ntap - 1)] * slabsz8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) ring[d][ks] = wb[ks * np2];
           }
-          for (int tp = 0; tp < ntap; ++tp) {
-            const int tn = min(tp + 1, ntap - 1);
-            const uint4* wb = wcol + tslab[tn] * slabsz8;
+          for (int tp0 = 0; tp0 < ntap; tp0 += D) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) bnxt[ks] = wb[ks * np2];
-            const int ta = ttoff[tp] * VS;
+            for (int d = 0; d < D; ++d) {
+              const int tp = tp0 + d;
+              if (tp < ntap) {
+                bf16x8 bfrag[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-              const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bcur[ks]);
+                for (int ks = 0; ks < KS; ++ks) bfrag[ks] = __builtin_bit_cast(bf16x8, ring[d][ks]);
+                const uint4* wb = wcol + tslab[min(tp + D, ntap - 1)] * slabsz8;
 #pragma unroll
-              for (int mb = 0; mb < MB; ++mb) {
-                const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + ks * 16);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag, acc[mb], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) ring[d][ks] = wb[ks * np2];
+                const int ta = ttoff[tp] * VS;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                  for (int mb = 0; mb < MB; ++mb) {
+                    const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + ks * 16);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag[ks], acc[mb], 0, 0, 0);
+                  }
+                }
               }
             }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnxt[ks];
           }
         } else {
           for (int tp = 0; tp < ntap; ++tp) {
@@ -536,6 +545,9 @@ struct PackEntry {
 };
 
 __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __restrict__ tab, int count, long long total) {
+  // one thread per (k, n) position of an image; it walks the T taps: the master reads are T contiguous floats
+  // (torch keeps the taps innermost), the image writes are coalesced across n for every tap.
+  // `start` / `total` count (k, n) positions.
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     int lo = 0, hi = count - 1;
@@ -545,26 +557,17 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __re
     }
     const PackEntry e = tab[lo];
     const long long li = i - e.start;
-    int nn, k, tp;
-    if (e.bf16) {
-      const int j = (int)(li & 7);
-      nn = (int)((li >> 3) % e.Np);
-      const int k8 = (int)((li / (8LL * e.Np)) % (e.Kp / 8));
-      tp = (int)(li / ((long long)e.Kp * e.Np));
-      k = k8 * 8 + j;
-    } else {
-      nn = (int)(li % e.Np);
-      k = (int)((li / e.Np) % e.Kp);
-      tp = (int)(li / ((long long)e.Np * e.Kp));
-    }
+    const int nn = (int)(li % e.Np), k = (int)(li / e.Np);
     const int K = e.kn_is_ba ? e.B : e.A, N = e.kn_is_ba ? e.A : e.B;
-    float v = 0.f;
-    if (k < K && nn < N) {
-      const int ai = e.kn_is_ba ? nn : k, bi = e.kn_is_ba ? k : nn;
-      v = e.w[((long long)ai * e.B + bi) * e.T + tp];
+    const bool live = k < K && nn < N;
+    const int ai = e.kn_is_ba ? nn : k, bi = e.kn_is_ba ? k : nn;
+    const float* src = e.w + ((long long)ai * e.B + bi) * e.T;
+    const long long slab = (long long)e.Kp * e.Np;
+    for (int tp = 0; tp < e.T; ++tp) {
+      const float v = live ? src[tp] : 0.f;
+      if (e.bf16) ((unsigned short*)e.p)[tp * slab + ((long long)(k >> 3) * e.Np + nn) * 8 + (k & 7)] = __builtin_bit_cast(unsigned short, (__bf16)v);
+      else ((float*)e.p)[tp * slab + (long long)k * e.Np + nn] = v;
     }
-    if (e.bf16) ((unsigned short*)e.p)[li] = __builtin_bit_cast(unsigned short, (__bf16)v);
-    else ((float*)e.p)[li] = v;
   }
 }
 
@@ -847,7 +850,7 @@ extern "C" int mmtta_conv_pack_table_build(const mmtta_pack_item* items, int cou
     int st = fill_pack_entry(&items[i].desc, items[i].w_master, items[i].packed, tab[i]);
     if (st) return st;
     tab[i].start = run;
-    run += (long long)tab[i].T * tab[i].Kp * tab[i].Np;
+    run += (long long)tab[i].Kp * tab[i].Np;
   }
   *total = run;
   return MMTTA_OK;
