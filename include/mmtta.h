@@ -60,6 +60,11 @@ typedef struct {
   const float* beta;  /* [C] or NULL */
   int32_t relu;
   int32_t _pad;
+  /* optional precombined form written by mmtta_norm_stats_finalize: v = x*scale[n*C+c] + shift[n*C+c].
+   * When given, consumers read ONLY these two arrays (one branch-free vector load per thread instead of four
+   * dependent ones); mean / rstd / gamma / beta are still what the backward kernels use. */
+  const float* scale; /* [N*C] or NULL */
+  const float* shift; /* [N*C] or NULL */
 } mmtta_norm_on_load;
 
 const char* mmtta_last_error(void);   /* thread-local text for the last non-zero status */
@@ -180,10 +185,13 @@ typedef enum {
  *   running_mean/var, momentum: BatchNorm only.  training != 0: batch statistics are used and
  *            the running buffers get the EMA update (unbiased variance), the "norm-stat
  *            update" of the adaptation step; training == 0: running statistics are used.
- *   mean, rstd   fp32 [N*C] outputs */
+ *   mean, rstd   fp32 [N*C] outputs
+ *   gamma, beta  [C] affine parameters or NULL; scale, shift  fp32 [N*C] outputs or NULL:
+ *                scale = rstd*gamma, shift = beta - mean*scale (the precombined norm-on-load form) */
 int mmtta_norm_stats_finalize(int kind, int groups, const float* part, int rows_per_n, int n, int c,
                               int64_t count, float eps, int training, float* running_mean,
                               float* running_var, float momentum, float* mean, float* rstd,
+                              const float* gamma, const float* beta, float* scale, float* shift,
                               double* scratch, void* stream);
 
 /* Rows per batch item of the partial slabs written by mmtta_channel_stats and

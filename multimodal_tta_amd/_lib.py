@@ -34,7 +34,7 @@ class Tensor(C.Structure):
 class NormOnLoad(C.Structure):
     _fields_ = [
         ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-        ("relu", C.c_int32), ("_pad", C.c_int32),
+        ("relu", C.c_int32), ("_pad", C.c_int32), ("scale", C.c_void_p), ("shift", C.c_void_p),
     ]
 
 
@@ -78,7 +78,8 @@ _SIGNATURES = {
                                    C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "mmtta_norm_stats_finalize": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
                                             C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
-                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     "mmtta_reduce_rows_per_n": (C.c_int, [_P(Tensor)]),
     "mmtta_channel_stats": (C.c_int, [_P(Tensor), C.c_void_p, C.c_void_p]),
     "mmtta_combine": (C.c_int, [_P(Tensor), _P(NormOnLoad), _P(Tensor), _P(NormOnLoad), _P(Tensor), C.c_void_p]),
@@ -161,5 +162,5 @@ def desc_ncdhw(t: torch.Tensor) -> Tensor:
     return Tensor(t.data_ptr(), n, c, d, h, w, sn, sc, sd, sh, sw, F32, 0)
 
 
-def norm_on_load(mean=None, rstd=None, gamma=None, beta=None, relu=False) -> NormOnLoad:
-    return NormOnLoad(ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), 1 if relu else 0, 0)
+def norm_on_load(mean=None, rstd=None, gamma=None, beta=None, relu=False, scale=None, shift=None) -> NormOnLoad:
+    return NormOnLoad(ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), 1 if relu else 0, 0, ptr(scale), ptr(shift))

@@ -53,17 +53,21 @@ struct NL {
   const float* gamma;
   const float* beta;
   int relu;
+  const float* scale;
+  const float* shift;
 };
 
 inline NL nl(const mmtta_norm_on_load* t) {
   NL r;
-  if (t == nullptr) { r.mean = r.rstd = r.gamma = r.beta = nullptr; r.relu = 0; return r; }
+  if (t == nullptr) { r.mean = r.rstd = r.gamma = r.beta = r.scale = r.shift = nullptr; r.relu = 0; return r; }
   r.mean = t->mean; r.rstd = t->rstd; r.gamma = t->gamma; r.beta = t->beta; r.relu = t->relu;
+  r.scale = t->scale; r.shift = t->scale ? t->shift : nullptr;
   return r;
 }
 
 // scale/shift of channel c of batch item n for a norm-on-load (identity when mean == nullptr)
 __device__ __forceinline__ void nl_coeff(const NL& t, int n, int C, int c, float& sc, float& sh) {
+  if (t.scale != nullptr) { sc = t.scale[n * C + c]; sh = t.shift[n * C + c]; return; }   // precombined: two loads
   if (t.mean == nullptr) { sc = 1.f; sh = 0.f; return; }
   float mu = t.mean[n * C + c], rs = t.rstd[n * C + c];
   float g = t.gamma ? t.gamma[c] : 1.f;

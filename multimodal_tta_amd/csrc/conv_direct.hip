@@ -189,7 +189,7 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
     MMTTA_CHECK(e == hipSuccess, MMTTA_ERR_LAUNCH, "direct conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  if (a.tin.mean != nullptr) hipLaunchKernelGGL(direct_conv_kernel<true>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
+  if (a.tin.mean != nullptr || a.tin.scale != nullptr) hipLaunchKernelGGL(direct_conv_kernel<true>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL(direct_conv_kernel<false>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
   return launch_status("direct conv");
 }

@@ -154,25 +154,47 @@ __global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
           if (c + j < a.Ci) nl_coeff(a.tin, n, a.Ci, c + j, sc[j], sh[j]);
           else { sc[j] = 0.f; sh[j] = 0.f; }
         }
-        for (int bv = tid / CV8; bv < boxvox; bv += 256 / CV8) {
-          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
-          const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
-          uint4 pk = make_uint4(0u, 0u, 0u, 0u);
-          const bool ok = (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
-                          (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
-          if (ok) {
-            const float* src = inb + iz * a.isd + iy * a.ish + ix * a.isw + c;
-            const float4 x0 = *reinterpret_cast<const float4*>(src);
-            float4 x1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c + 4 < a.Ci) x1 = *reinterpret_cast<const float4*>(src + 4);
-            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            float v[8];
+        // U items per trip: all their global loads are issued before the first use (one exposed latency per
+        // trip instead of one per item)
+        constexpr int U = 4, STEP = 256 / CV8;
+        const bool tail = (a.Ci & 7) != 0;       // only then can lanes beyond Ci hold uninitialised padding
+        for (int bv0 = tid / CV8; bv0 < boxvox; bv0 += U * STEP) {
+          float4 x0[U], x1[U];
+          bool ok[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (c + j < a.Ci) ? nl_apply(xs[j], sc[j], sh[j], a.tin.relu) : 0.f;
-            pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-            pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+          for (int u = 0; u < U; ++u) {
+            const int bv = bv0 + u * STEP;
+            const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+            const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+            ok[u] = bv < boxvox && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
+                    (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
+            x0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            x1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) {
+              const float* src = inb + iz * a.isd + iy * a.ish + ix * a.isw + c;
+              x0[u] = *reinterpret_cast<const float4*>(src);
+              if (c + 4 < a.Ci) x1[u] = *reinterpret_cast<const float4*>(src + 4);
+            }
           }
-          *reinterpret_cast<uint4*>(lh + bv * VS + cv * 8) = pk;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int bv = bv0 + u * STEP;
+            if (bv < boxvox) {
+              uint4 pk = make_uint4(0u, 0u, 0u, 0u);
+              if (ok[u]) {
+                const float xs[8] = {x0[u].x, x0[u].y, x0[u].z, x0[u].w, x1[u].x, x1[u].y, x1[u].z, x1[u].w};
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  v[j] = nl_apply(xs[j], sc[j], sh[j], a.tin.relu);
+                  if (tail && c + j >= a.Ci) v[j] = 0.f;
+                }
+                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+              }
+              *reinterpret_cast<uint4*>(lh + bv * VS + cv * 8) = pk;
+            }
+          }
         }
       } else {
         const int cc = tid % KCI;
@@ -200,21 +222,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
         if (c + j < a.Ci) nl_coeff(a.tin, n, a.Ci, c + j, sc[j], sh[j]);
         else { sc[j] = 0.f; sh[j] = 0.f; }
       }
-      for (int bv = tid / CV; bv < boxvox; bv += 256 / CV) {
-        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
-        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool ok = (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
-                        (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
-        if (ok) {
-          const float4 x = *reinterpret_cast<const float4*>(inb + iz * a.isd + iy * a.ish + ix * a.isw + c);
-          v.x = nl_apply(x.x, sc[0], sh[0], a.tin.relu);
-          v.y = (c + 1 < a.Ci) ? nl_apply(x.y, sc[1], sh[1], a.tin.relu) : 0.f;
-          v.z = (c + 2 < a.Ci) ? nl_apply(x.z, sc[2], sh[2], a.tin.relu) : 0.f;
-          v.w = (c + 3 < a.Ci) ? nl_apply(x.w, sc[3], sh[3], a.tin.relu) : 0.f;
+      constexpr int U = 4, STEP = 256 / CV;
+      for (int bv0 = tid / CV; bv0 < boxvox; bv0 += U * STEP) {
+        float4 xin[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int bv = bv0 + u * STEP;
+          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+          const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+          ok[u] = bv < boxvox && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
+                  (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
+          xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok[u]) xin[u] = *reinterpret_cast<const float4*>(inb + iz * a.isd + iy * a.ish + ix * a.isw + c);
         }
-        float* d = lds + bv * VS + cv * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int bv = bv0 + u * STEP;
+          if (bv < boxvox) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) {
+              v.x = nl_apply(xin[u].x, sc[0], sh[0], a.tin.relu);
+              v.y = (c + 1 < a.Ci) ? nl_apply(xin[u].y, sc[1], sh[1], a.tin.relu) : 0.f;
+              v.z = (c + 2 < a.Ci) ? nl_apply(xin[u].z, sc[2], sh[2], a.tin.relu) : 0.f;
+              v.w = (c + 3 < a.Ci) ? nl_apply(xin[u].w, sc[3], sh[3], a.tin.relu) : 0.f;
+            }
+            float* d = lds + bv * VS + cv * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+          }
+        }
       }
     } else {
       const int cc = tid % KCI;          // 256 % KCI == 0
@@ -557,7 +593,11 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __re
     }
     const PackEntry e = tab[lo];
     const long long li = i - e.start;
-    const int nn = (int)(li % e.Np), k = (int)(li / e.Np);
+    // position order follows the image's own memory order so that the stores of a wave stay contiguous:
+    // fp32 [k][n]; bf16 [k/8][n][k%8]
+    int nn, k;
+    if (e.bf16) { nn = (int)((li >> 3) % e.Np); k = (int)(li / (8LL * e.Np)) * 8 + (int)(li & 7); }
+    else { nn = (int)(li % e.Np); k = (int)(li / e.Np); }
     const int K = e.kn_is_ba ? e.B : e.A, N = e.kn_is_ba ? e.A : e.B;
     const bool live = k < K && nn < N;
     const int ai = e.kn_is_ba ? nn : k, bi = e.kn_is_ba ? k : nn;

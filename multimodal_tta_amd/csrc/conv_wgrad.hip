@@ -90,19 +90,34 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
           if (c + j < a.Cg) nl_coeff(a.tg, n, a.Cg, c + j, sc[j], sh[j]);
           else { sc[j] = 0.f; sh[j] = 0.f; }
         }
-        for (int bv = tid >> 3; bv < boxvox; bv += 32) {
-          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
-          const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if ((unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg && (unsigned)ix < (unsigned)a.Wgg &&
-              c < a.Cg) {
-            const float4 x = *reinterpret_cast<const float4*>(gb + iz * a.gsd + iy * a.gsh + ix * a.gsw + c);
-            v.x = nl_apply(x.x, sc[0], sh[0], a.tg.relu);
-            v.y = (c + 1 < a.Cg) ? nl_apply(x.y, sc[1], sh[1], a.tg.relu) : 0.f;
-            v.z = (c + 2 < a.Cg) ? nl_apply(x.z, sc[2], sh[2], a.tg.relu) : 0.f;
-            v.w = (c + 3 < a.Cg) ? nl_apply(x.w, sc[3], sh[3], a.tg.relu) : 0.f;
+        constexpr int U = 4;       // 4 box voxels per trip: loads first, then transform + LDS store
+        for (int bv0 = tid >> 3; bv0 < boxvox; bv0 += 32 * U) {
+          float4 xin[U];
+          bool ok[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int bv = bv0 + 32 * u;
+            const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+            const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+            ok[u] = bv < boxvox && (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg &&
+                    (unsigned)ix < (unsigned)a.Wgg && c < a.Cg;
+            xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) xin[u] = *reinterpret_cast<const float4*>(gb + iz * a.gsd + iy * a.gsh + ix * a.gsw + c);
           }
-          *reinterpret_cast<float4*>(gl + bv * 32 + cv * 4) = v;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int bv = bv0 + 32 * u;
+            if (bv < boxvox) {
+              float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (ok[u]) {
+                v.x = nl_apply(xin[u].x, sc[0], sh[0], a.tg.relu);
+                v.y = (c + 1 < a.Cg) ? nl_apply(xin[u].y, sc[1], sh[1], a.tg.relu) : 0.f;
+                v.z = (c + 2 < a.Cg) ? nl_apply(xin[u].z, sc[2], sh[2], a.tg.relu) : 0.f;
+                v.w = (c + 3 < a.Cg) ? nl_apply(xin[u].w, sc[3], sh[3], a.tg.relu) : 0.f;
+              }
+              *reinterpret_cast<float4*>(gl + bv * 32 + cv * 4) = v;
+            }
+          }
         }
       } else {
         const int cc = tid & 31;
@@ -257,6 +272,178 @@ __global__ __launch_bounds__(64) void db_reduce_kernel(const float* __restrict__
   for (int sl = threadIdx.x; sl < nsl; sl += 64) s += part[(long long)sl * ld + c];
   s = wave_sum(s);
   if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+}
+
+// ------------------------------------------------------------------ bf16-operand weight gradient (27 taps)
+// Same decomposition as wgrad_f32_kernel, on v_mfma_f32_32x32x16_bf16.  The reduction index is the voxel, and a
+// bf16 fragment holds 8 CONSECUTIVE k per lane, so the LDS images are channel-major with 8-voxel x-rows:
+//   D tile  Dl[cd][xrow][8 x]                       (xrow = z*TY + y of the coarse tile)
+//   G box   Gl[dx][cg][(bz,by) row][8 x]            three x-shifted (and, for stride 2, de-interleaved) copies,
+//                                                   so that the 8 voxels a tap needs start 16-byte aligned
+// k16 step ks covers the two x-rows 2ks (lanes 0-31) and 2ks+1 (lanes 32-63).  Channel strides are an odd
+// number of 16-byte slots: the 16 lanes of a ds_read_b128 group hit 16 distinct slots.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int wpack2(float lo, float hi) {
+  wbf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned int, v);
+}
+
+template <int TZ, int TY, int SI>
+struct WBGeo {
+  static constexpr int TX = 8;
+  static constexpr int NXR = TZ * TY;                    // x-rows of the coarse tile
+  static constexpr int BZr = (TZ - 1) * SI + 3, BYr = (TY - 1) * SI + 3;
+  static constexpr int RG = BZr * BYr;                   // (z,y) rows of the gathered box
+  static constexpr int NX = 7 * SI + 3;                  // fine x positions a row needs
+  static constexpr int SLG = (RG + 1) | 1;               // slots per channel, odd
+  static constexpr int SLD = (NXR + 1) | 1;
+  static constexpr int CHS_G = SLG * 16, CHS_D = SLD * 16;     // bytes
+  static constexpr int COPY = 32 * CHS_G;
+  static constexpr int LDS_BYTES = 3 * COPY + 32 * CHS_D + 256 * 4;
+};
+
+template <int TZ, int TY, int SI>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WArgs a) {
+  using G = WBGeo<TZ, TY, SI>;
+  extern __shared__ float lds[];
+  unsigned char* lb = reinterpret_cast<unsigned char*>(lds);
+  unsigned char* gl = lb;                       // 3 copies
+  unsigned char* dl = lb + 3 * G::COPY;
+  float* dbred = reinterpret_cast<float*>(lb + 3 * G::COPY + 32 * G::CHS_D);   // [256]
+  constexpr int MT = G::NXR * 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int cg0 = blockIdx.y * 32, cd0 = blockIdx.z * 32;
+  const int cs = tid & 31;                      // staging channel of this thread (256 % 32 == 0)
+
+  int toffb[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = min(wave + 4 * j, 26);
+    toffb[j] = (tap % 3) * G::COPY + ((tap / 9) * G::BYr + ((tap / 3) % 3)) * 16;
+  }
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  float dbsum = 0.f;
+
+  const int t0 = blockIdx.x * a.tiles_per_split;
+  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
+  const int tpn = a.tz * a.ty * a.tx;
+  for (int tile = t0; tile < t1; ++tile) {
+    const int n = tile / tpn;
+    int t = tile % tpn;
+    const int txi = t % a.tx; t /= a.tx;
+    const int tyi = t % a.ty;
+    const int tzi = t / a.ty;
+    const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * 8;
+    const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
+    {  // ---- G box: thread = (channel, box row); builds the three x-shifted 8-voxel copies
+      const int c = cg0 + cs;
+      float sc = 0.f, sh = 0.f;
+      const bool cok = c < a.Cg;
+      if (cok) nl_coeff(a.tg, n, a.Cg, c, sc, sh);
+      const float* gb = a.g + (long long)n * a.gsn + c;
+      for (int row = tid >> 5; row < G::RG; row += 8) {
+        const int bz = row / G::BYr, by = row % G::BYr;
+        const int iz = iz0 + bz, iy = iy0 + by;
+        const bool rok = cok && (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg;
+        const float* rp = gb + (long long)iz * a.gsd + (long long)iy * a.gsh;
+        float v[G::NX];
+#pragma unroll
+        for (int x = 0; x < G::NX; ++x) {
+          const int ix = ix0 + x;
+          v[x] = (rok && (unsigned)ix < (unsigned)a.Wgg) ? nl_apply(rp[(long long)ix * a.gsw], sc, sh, a.tg.relu) : 0.f;
+        }
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+          uint4 pk;
+          pk.x = wpack2(v[0 * SI + dxi], v[1 * SI + dxi]); pk.y = wpack2(v[2 * SI + dxi], v[3 * SI + dxi]);
+          pk.z = wpack2(v[4 * SI + dxi], v[5 * SI + dxi]); pk.w = wpack2(v[6 * SI + dxi], v[7 * SI + dxi]);
+          *reinterpret_cast<uint4*>(gl + dxi * G::COPY + cs * G::CHS_G + row * 16) = pk;
+        }
+      }
+    }
+    {  // ---- D tile: thread = (channel, x-row)
+      const int c = cd0 + cs;
+      float sc = 0.f, sh = 0.f;
+      const bool cok = c < a.Cd;
+      if (cok) nl_coeff(a.td, n, a.Cd, c, sc, sh);
+      const float* db = a.dn + (long long)n * a.dsn + c;
+      for (int xr = tid >> 5; xr < G::NXR; xr += 8) {
+        const int oz = oz0 + xr / TY, oy = oy0 + xr % TY;
+        const bool rok = cok && oz < a.Dd && oy < a.Hd;
+        const float* rp = db + (long long)oz * a.dsd + (long long)oy * a.dsh;
+        float v[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          v[x] = (rok && ox0 + x < a.Wd) ? nl_apply(rp[(long long)(ox0 + x) * a.dsw], sc, sh, a.td.relu) : 0.f;
+          dbsum += v[x];
+        }
+        uint4 pk;
+        pk.x = wpack2(v[0], v[1]); pk.y = wpack2(v[2], v[3]); pk.z = wpack2(v[4], v[5]); pk.w = wpack2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(dl + cs * G::CHS_D + xr * 16) = pk;
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ks = 0; ks < G::NXR / 2; ++ks) {
+      const int xr = 2 * ks + h;
+      const int z = xr / TY, y = xr % TY;
+      const uint4 bq = *reinterpret_cast<const uint4*>(dl + r * G::CHS_D + xr * 16);
+      const unsigned char* ga = gl + r * G::CHS_G + ((z * SI) * G::BYr + y * SI) * 16;
+      uint4 aq[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) aq[j] = *reinterpret_cast<const uint4*>(ga + toffb[j]);
+      const wbf16x8 bfrag = __builtin_bit_cast(wbf16x8, bq);
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, aq[j]), bfrag, acc[j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  (void)MT;
+  const int sl = blockIdx.x;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = wave + 4 * j;
+    if (tap < 27) {
+      float* sb = a.slab + (((long long)sl * 27 + tap) * a.CGp + cg0) * a.CDp + cd0 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        sb[(long long)row * a.CDp] = acc[j][i];
+      }
+    }
+  }
+  if (a.dbpart != nullptr && blockIdx.y == 0) {     // bias gradient from the fp32 values seen while staging
+    dbred[tid] = dbsum;
+    __syncthreads();
+    if (tid < 32) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += dbred[q * 32 + tid];
+      a.dbpart[(long long)sl * a.CDp + cd0 + tid] = s;
+    }
+  }
+}
+
+template <int TZ, int TY, int SI>
+static int launch_wgrad_bf16(const WArgs& a, int S, hipStream_t s) {
+  using G = WBGeo<TZ, TY, SI>;
+  auto kern = wgrad_bf16_kernel<TZ, TY, SI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(S, a.CGp / 32, a.CDp / 32);
+  hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, s, a);
+  return launch_status("conv wgrad bf16");
 }
 
 // ------------------------------------------------------------------ small-channel weight gradient
@@ -414,7 +601,7 @@ __global__ void wgrad_small_reduce_kernel(const float* __restrict__ slab, float*
 
 
 struct WGeo {
-  bool small; int small_is_cd; const mmtta_tensor *q, *pb; bool q_is_x;
+  bool bf16; bool small; int small_is_cd; const mmtta_tensor *q, *pb; bool q_is_x;
   const mmtta_tensor *g, *dn;
   int si, ntaps, TZ, TY, TX;
   int tz, ty, tx, tiles, S, tps, nsl, CGp, CDp;
@@ -446,7 +633,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
                 "wgrad: spatial mismatch on axis %d (fine %d, coarse %d)", i, gd[i], dd[i]);
   }
   // small-channel path: which tensor is the small gathered one (Q) and which the dense one (P)
-  w.small = false; w.small_is_cd = 0; w.q = w.pb = nullptr; w.q_is_x = false;
+  w.small = false; w.bf16 = false; w.small_is_cd = 0; w.q = w.pb = nullptr; w.q_is_x = false;
   if (!w.convt && d->cin <= 4) { w.small = true; w.q = x; w.pb = dy; w.q_is_x = true; }
   else if (!w.convt && d->cout <= 4 && d->ksize == 1) { w.small = true; w.q = dy; w.pb = x; w.small_is_cd = 1; }
   else if (w.convt && d->cout <= 4) { w.small = true; w.q = dy; w.pb = x; }
@@ -471,7 +658,10 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     else { w.colsum_blocks = (int64_t)dy->n * channel_partial_rows(dy); w.db_floats = w.colsum_blocks * 2 * dy->c; }
     return MMTTA_OK;
   }
-  if (w.si == 1) { w.TZ = 4; w.TY = 4; w.TX = 8; } else { w.TZ = 2; w.TY = 2; w.TX = 8; }
+  w.bf16 = d->dtype == MMTTA_BF16 && w.ntaps == 27;
+  if (w.si == 1) { w.TZ = 4; w.TY = 4; w.TX = 8; }
+  else if (w.bf16) { w.TZ = 2; w.TY = 4; w.TX = 8; }
+  else { w.TZ = 2; w.TY = 2; w.TX = 8; }
   w.tz = (w.dn->d + w.TZ - 1) / w.TZ;
   w.ty = (w.dn->h + w.TY - 1) / w.TY;
   w.tx = (w.dn->w + w.TX - 1) / w.TX;
@@ -607,7 +797,8 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   a.gvec4 = ((((uintptr_t)w.g->ptr) % 16 == 0) && w.g->sw % 4 == 0 && w.g->sh % 4 == 0 && w.g->sd % 4 == 0 &&
              w.g->sn % 4 == 0) ? 1 : 0;
   a.dvec4 = 0;
-  if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, w.S, s);
+  if (w.bf16) st = (w.si == 1) ? launch_wgrad_bf16<4, 4, 1>(a, w.S, s) : launch_wgrad_bf16<2, 4, 2>(a, w.S, s);
+  else if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, w.S, s);
   else st = (w.si == 1) ? launch_wgrad<4, 4, 8, 7>(a, w.S, s) : launch_wgrad<2, 2, 8, 7>(a, w.S, s);
   if (st) return st;
   const float* rsrc = a.slab;

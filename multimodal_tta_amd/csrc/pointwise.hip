@@ -165,7 +165,8 @@ __global__ __launch_bounds__(64) void rows_reduce_kernel(const float* part, int 
 // InstanceNorm fast path: one wave per (n,c) reduces the partial rows AND finishes the statistics
 // (no cross-(n,c) coupling), one launch instead of two.
 __global__ __launch_bounds__(64) void instance_stats_kernel(const float* part, int rows_per_n, int C, double count, float eps,
-                                                            float* mean, float* rstd) {
+                                                            float* mean, float* rstd, const float* gamma, const float* beta,
+                                                            float* scale, float* shift) {
   const int n = blockIdx.x / C, c = blockIdx.x % C;
   double s0 = 0.0, s1 = 0.0;
   for (int r = threadIdx.x; r < rows_per_n; r += 64) {
@@ -179,8 +180,14 @@ __global__ __launch_bounds__(64) void instance_stats_kernel(const float* part, i
     const double mu = s0 / count;
     double var = s1 / count - mu * mu;
     if (var < 0.0) var = 0.0;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
     mean[blockIdx.x] = (float)mu;
-    rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    rstd[blockIdx.x] = rs;
+    if (scale != nullptr) {
+      const float sc = rs * (gamma ? gamma[c] : 1.f);
+      scale[blockIdx.x] = sc;
+      shift[blockIdx.x] = (beta ? beta[c] : 0.f) - (float)mu * sc;
+    }
   }
 }
 
@@ -209,6 +216,7 @@ struct StatFinArgs {
   int training;
   float* running_mean; float* running_var; float momentum;
   float* mean; float* rstd;
+  const float* gamma; const float* beta; float* scale; float* shift;
   const double* tot;
 };
 
@@ -223,6 +231,11 @@ __global__ void stats_finalize_kernel(StatFinArgs a) {
     if (!a.training) {
       a.mean[i] = a.running_mean[c];
       a.rstd[i] = (float)(1.0 / sqrt((double)a.running_var[c] + (double)a.eps));
+      if (a.scale != nullptr) {
+        const float sc = a.rstd[i] * (a.gamma ? a.gamma[c] : 1.f);
+        a.scale[i] = sc;
+        a.shift[i] = (a.beta ? a.beta[c] : 0.f) - a.mean[i] * sc;
+      }
       return;
     }
     for (int m = 0; m < a.N; ++m) { S += a.tot[((long long)m * a.C + c) * 2]; Q += a.tot[((long long)m * a.C + c) * 2 + 1]; }
@@ -237,6 +250,11 @@ __global__ void stats_finalize_kernel(StatFinArgs a) {
   if (var < 0.0) var = 0.0;
   a.mean[i] = (float)mu;
   a.rstd[i] = (float)(1.0 / sqrt(var + (double)a.eps));
+  if (a.scale != nullptr) {
+    const float sc = a.rstd[i] * (a.gamma ? a.gamma[c] : 1.f);
+    a.scale[i] = sc;
+    a.shift[i] = (a.beta ? a.beta[c] : 0.f) - a.mean[i] * sc;
+  }
   if (a.kind == MMTTA_NORM_BATCH && a.training && n == 0 && a.running_mean != nullptr) {
     const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
     a.running_mean[c] = (float)((1.0 - a.momentum) * a.running_mean[c] + a.momentum * mu);
@@ -544,9 +562,11 @@ extern "C" int mmtta_channel_stats(const mmtta_tensor* x, float* part, void* str
 extern "C" int mmtta_norm_stats_finalize(int kind, int groups, const float* part, int rows_per_n, int n, int c,
                                          int64_t count, float eps, int training, float* running_mean,
                                          float* running_var, float momentum, float* mean, float* rstd,
+                                         const float* gamma, const float* beta, float* scale, float* shift,
                                          double* scratch, void* stream) {
   MMTTA_CHECK(kind >= 0 && kind <= 2, MMTTA_ERR_INVALID, "norm: bad kind %d", kind);
   MMTTA_CHECK(mean && rstd && n > 0 && c > 0 && count > 0, MMTTA_ERR_INVALID, "norm finalize: bad argument");
+  MMTTA_CHECK((scale == nullptr) == (shift == nullptr), MMTTA_ERR_INVALID, "norm finalize: scale and shift go together");
   MMTTA_CHECK(scratch != nullptr, MMTTA_ERR_INVALID, "norm finalize: null scratch");
   double* g_tot = scratch;
   if (kind == MMTTA_NORM_GROUP) MMTTA_CHECK(groups > 0 && c % groups == 0, MMTTA_ERR_INVALID, "group norm: C %% groups != 0");
@@ -554,7 +574,8 @@ extern "C" int mmtta_norm_stats_finalize(int kind, int groups, const float* part
   hipStream_t s = (hipStream_t)stream;
   if (kind == MMTTA_NORM_INSTANCE) {
     MMTTA_CHECK(part != nullptr && rows_per_n > 0, MMTTA_ERR_INVALID, "norm finalize: null partials");
-    hipLaunchKernelGGL(instance_stats_kernel, dim3(n * c), dim3(64), 0, s, part, rows_per_n, c, (double)count, eps, mean, rstd);
+    hipLaunchKernelGGL(instance_stats_kernel, dim3(n * c), dim3(64), 0, s, part, rows_per_n, c, (double)count, eps, mean, rstd,
+                       gamma, beta, scale, shift);
     return launch_status("instance norm stats");
   }
   const bool need_rows = !(kind == MMTTA_NORM_BATCH && !training);
@@ -567,6 +588,7 @@ extern "C" int mmtta_norm_stats_finalize(int kind, int groups, const float* part
   StatFinArgs a;
   a.kind = kind; a.groups = groups; a.N = n; a.C = c; a.count = (double)count; a.eps = eps; a.training = training;
   a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.mean = mean; a.rstd = rstd;
+  a.gamma = gamma; a.beta = beta; a.scale = scale; a.shift = shift;
   a.tot = g_tot;
   hipLaunchKernelGGL(stats_finalize_kernel, dim3((n * c + 63) / 64), dim3(64), 0, s, a);
   return launch_status("norm stats finalize");

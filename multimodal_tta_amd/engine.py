@@ -152,15 +152,19 @@ class NormLayer:
     def finalize(self, pool: Pool, key, part, rows_per_n: int, n: int, count: int, training: bool) -> NL:
         mean = pool.flat((key, "mean"), n * self.C)
         rstd = pool.flat((key, "rstd"), n * self.C)
+        scale = pool.flat((key, "scale"), n * self.C)
+        shift = pool.flat((key, "shift"), n * self.C)
         scratch = pool.flat((key, "tot"), n * self.C * 2, dtype=torch.float64)
         use_batch = training or self.kind != ops.NORM_BATCH
         rm = self.bn.running_mean if self.bn is not None else None
         rv = self.bn.running_var if self.bn is not None else None
+        g = self.gamma.data if self.gamma else None
+        b = self.beta.data if self.beta else None
         ops.norm_stats_finalize(self.kind, self.groups, part, rows_per_n, n, self.C, count, self.eps,
-                                use_batch, rm, rv, self.momentum, mean, rstd, scratch)
+                                use_batch, rm, rv, self.momentum, mean, rstd, scratch, g, b, scale, shift)
         if self.bn is not None and training and self.bn.num_batches_tracked is not None:
             self.bn.num_batches_tracked.add_(1)
-        return NL(mean, rstd, self.gamma.data if self.gamma else None, self.beta.data if self.beta else None, True)
+        return NL(mean, rstd, g, b, True, scale, shift)
 
     def backward(self, pool: Pool, key, dT: torch.Tensor, y: torch.Tensor, nl: NL, dy: torch.Tensor,
                  training: bool, accumulate: bool = False) -> None:

@@ -56,9 +56,11 @@ class NL:
     gamma: Optional[torch.Tensor] = None
     beta: Optional[torch.Tensor] = None
     relu: bool = True
+    scale: Optional[torch.Tensor] = None     # precombined rstd*gamma and beta - mean*rstd*gamma (fast consumer path)
+    shift: Optional[torch.Tensor] = None
 
     def struct(self) -> _lib.NormOnLoad:
-        return _lib.norm_on_load(self.mean, self.rstd, self.gamma, self.beta, self.relu)
+        return _lib.norm_on_load(self.mean, self.rstd, self.gamma, self.beta, self.relu, self.scale, self.shift)
 
 
 def _nl_ref(nl: Optional[NL]):
@@ -304,10 +306,12 @@ def channel_stats(x: torch.Tensor, part: torch.Tensor) -> None:
 
 def norm_stats_finalize(kind: int, groups: int, part: Optional[torch.Tensor], rows_per_n: int, n: int, c: int,
                         count: int, eps: float, training: bool, running_mean, running_var, momentum: float,
-                        mean: torch.Tensor, rstd: torch.Tensor, scratch: torch.Tensor) -> None:
+                        mean: torch.Tensor, rstd: torch.Tensor, scratch: torch.Tensor, gamma=None, beta=None,
+                        scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None) -> None:
     check(_lib.load().mmtta_norm_stats_finalize(kind, groups, ptr(part), rows_per_n, n, c, count, eps,
                                                 1 if training else 0, ptr(running_mean), ptr(running_var),
-                                                momentum, ptr(mean), ptr(rstd), ptr(scratch), stream_ptr()),
+                                                momentum, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(scale),
+                                                ptr(shift), ptr(scratch), stream_ptr()),
           "norm_stats_finalize")
 
 

@@ -48,6 +48,14 @@ CASES = [
     (8, 3, 3, 2, True, (1, 5, 6, 4)),
     (64, 32, 3, 2, True, (1, 4, 4, 8)),
     (768, 128, 3, 2, True, (1, 2, 2, 2)),
+    # the narrow layers of small deep-fusion decoders (1x1 pre-convs, 5-channel concat inputs)
+    (8, 4, 1, 1, False, (1, 16, 16, 16)),
+    (5, 4, 3, 1, False, (1, 16, 16, 16)),
+    (5, 4, 1, 1, False, (1, 16, 16, 16)),
+    (12, 8, 3, 1, False, (1, 8, 8, 8)),
+    (16, 8, 1, 1, False, (1, 8, 8, 8)),
+    (1, 4, 3, 2, False, (1, 16, 16, 16)),
+    (4, 8, 3, 2, False, (1, 8, 8, 8)),
 ]
 
 
@@ -188,7 +196,7 @@ BF16_CASES = [
 def test_conv_bf16_operands(cin, cout, k, stride, transposed, shape):
     """dtype=BF16: operands rounded to bf16 (8 significant bits), fp32 accumulation.  Against the fp32 torch
     result the error of a K-term dot product is ~2^-8 * rms(terms) * sqrt(K) / ... : stated bound
-    |err| <= 1.5e-2 * max|ref| (forward and input gradient); the weight gradient stays fp32-exact."""
+    |err| <= 1.5e-2 * max|ref| (forward, input gradient and weight gradient)."""
     from multimodal_tta_amd import ops
 
     torch.manual_seed(99 + cin + cout)
@@ -209,7 +217,8 @@ def test_conv_bf16_operands(cin, cout, k, stride, transposed, shape):
     dx_cl = ops.new_cl(n, d, h, w, cin, "cuda")
     op.dgrad(gy_cl, dx_cl)
     dw = torch.empty_like(wt)
-    op.wgrad(x_cl, None, gy_cl, dw, None)
+    dbias = torch.empty(cout, device="cuda")
+    op.wgrad(x_cl, None, gy_cl, dw, dbias)
     torch.cuda.synchronize()
 
     def bf_close(name, got, ref):
@@ -222,7 +231,10 @@ def test_conv_bf16_operands(cin, cout, k, stride, transposed, shape):
     e2 = bf_close("bf16 dgrad", ncdhw(dx_cl), x.grad)
     if cin >= 16 and cout > 4:
         assert e1 > 1e-5, "bf16 path not taken (result is fp32-exact)"
-    close("wgrad stays fp32", dw, mod.weight.grad)
+    # 27-tap weight gradients also take bf16 operands (fp32 accumulation over voxels); 1x1x1 and the
+    # small-channel paths stay fp32.  The bias gradient is summed from the fp32 values in every mode.
+    bf_close("bf16 wgrad", dw, mod.weight.grad)
+    close("bias gradient stays fp32", dbias, mod.bias.grad)
     st = stats.view(n, rows // n, 2, cout).double().sum(1).cpu()
     got_sum = ncdhw(y_cl).double().sum(dim=(2, 3, 4))
     assert torch.allclose(st[:, 0], got_sum, rtol=1e-3, atol=1e-2 * max(1.0, got_sum.abs().max().item()))

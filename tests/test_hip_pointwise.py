@@ -139,7 +139,24 @@ def test_combine_two_sources_and_slices():
     assert wide[..., :4].abs().max().item() == 0 and wide[..., 10:].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 3, 4, 5), (2, 8, 4, 4, 4), (1, 4, 1, 2, 3)])
+def test_upsample_backward_from_a_channel_slice():
+    """The adjoint reads its gradient out of a channel slice of the concat gradient (deep-fusion decoder)."""
+    from multimodal_tta_amd import ops
+    torch.manual_seed(12)
+    x = torch.randn(1, 4, 16, 16, 16, requires_grad=True)
+    up = torch.nn.Upsample(scale_factor=(2.0, 2.0, 2.0), mode="trilinear", align_corners=True)
+    ref = up(x)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    wide = torch.randn(1, 32, 32, 32, 8, device="cuda")
+    ops.to_cl(g.cuda(), out=wide[..., :4])
+    dx = ops.new_cl(1, 16, 16, 16, 4, "cuda")
+    ops.upsample2x_bwd(wide[..., :4], dx)
+    torch.cuda.synchronize()
+    close("upsample bwd from slice", ncdhw(dx), x.grad, rel=1e-5, abs_=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 3, 4, 5), (2, 8, 4, 4, 4), (1, 4, 1, 2, 3), (1, 4, 16, 16, 16), (1, 2, 8, 24, 24)])
 def test_upsample_trilinear(shape):
     from multimodal_tta_amd import ops
     torch.manual_seed(2)
