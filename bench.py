@@ -13,7 +13,8 @@ volumes (weak scaling); the only collective is the all_gather of the per-volume 
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline     - the dominant kernel (by measured time), algorithmic FLOPs per launch over its
-                 measured launch duration (events on the launch stream), against the fp32 MFMA peak
+                 measured launch duration (events on the launch stream), against the dense MFMA peak of
+                 the operand type that kernel uses (bf16 2.5 PF, fp32 157.3 TF)
   cpu_baseline - the oracle (torch CPU restatement of the reference path) timed on this host on a
                  bounded sample of the same workload.
 """
@@ -31,7 +32,13 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA": ~2.5 PF dense (not the 2:1-sparsity figure)
 PEAK_HBM_GBPS = 8000.0
+
+
+def mfma_peak(kernel_name: str) -> float:
+    """Dense MFMA peak of the operand type the named kernel feeds the matrix cores with."""
+    return PEAK_BF16_MFMA_TFLOPS if "bf16" in kernel_name else PEAK_FP32_MFMA_TFLOPS
 
 
 def parse():
@@ -198,14 +205,16 @@ def main():
         total_ms = sum(d["ms"] for d in summ.values())
         name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        peak = mfma_peak(name)
         out["roofline"] = {
-            "bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "traffic": None,
             "avg_launch_us": 1000.0 * d["ms"] / d["launches"], "launches": d["launches"],
             "flops_per_launch": d["flops"] / d["launches"],
             "share_of_conv_time": d["ms"] / total_ms,
-            "all_conv_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "ms": v["ms"], "launches": v["launches"]}
-                                 for k, v in sorted(summ.items())},
+            "all_conv_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                     "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / mfma_peak(k), "ms": v["ms"],
+                                     "launches": v["launches"]} for k, v in sorted(summ.items())},
             "conv_tflops_overall": sum(v["flops"] for v in summ.values()) / (total_ms * 1e-3) / 1e12,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

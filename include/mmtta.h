@@ -112,8 +112,9 @@ typedef struct {
   void* packed;           /* device */
 } mmtta_pack_item;
 int64_t mmtta_conv_pack_table_bytes(int count);
-int mmtta_conv_pack_table_build(const mmtta_pack_item* items, int count, void* table_host, int64_t* total_elements);
-int mmtta_conv_pack_batched(const void* table_dev, int count, int64_t total_elements, void* stream);
+/* `total` is an opaque work count produced by _table_build and handed back to _pack_batched. */
+int mmtta_conv_pack_table_build(const mmtta_pack_item* items, int count, void* table_host, int64_t* total);
+int mmtta_conv_pack_batched(const void* table_dev, int count, int64_t total, void* stream);
 
 /* Launch geometry chosen for a problem; filled by mmtta_conv_plan. */
 typedef struct {
@@ -165,6 +166,11 @@ int mmtta_conv_run(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmt
  *   db       fp32 [cout] or NULL */
 int64_t mmtta_conv_wgrad_workspace_bytes(const mmtta_conv_desc* desc, const mmtta_tensor* x,
                                          const mmtta_tensor* dy);
+/* Which weight-gradient kernel mmtta_conv_wgrad picks for this problem (profiling / roofline bookkeeping):
+ *   0 fp32 MFMA k3 s1   1 fp32 MFMA k3 s2 (and conv_transpose)   2 fp32 MFMA k1
+ *   3 small-channel (<= 4 channels on one side, fp32 MFMA)       4 bf16 MFMA k3 s1   5 bf16 MFMA k3 s2
+ * or a negative mmtta error code. */
+int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_tensor* dy);
 int mmtta_conv_wgrad(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
                      const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
                      int64_t workspace_bytes, void* stream);

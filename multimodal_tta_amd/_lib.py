@@ -74,6 +74,7 @@ _SIGNATURES = {
     "mmtta_conv_run": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(NormOnLoad), C.c_void_p, C.c_void_p, _P(ConvEpilogue),
                                  _P(Tensor), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mmtta_conv_wgrad_workspace_bytes": (C.c_int64, [_P(ConvDesc), _P(Tensor), _P(Tensor)]),
+    "mmtta_conv_wgrad_kernel": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(Tensor)]),
     "mmtta_conv_wgrad": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(NormOnLoad), _P(Tensor), C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "mmtta_norm_stats_finalize": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,

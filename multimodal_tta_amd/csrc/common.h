@@ -98,7 +98,7 @@ int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s);  // 
 
 // direct path for layers producing <= 4 channels (conv_direct.hip)
 bool direct_applicable(const mmtta_conv_desc* d);
-int direct_blocks_per_n(const mmtta_tensor* y);
+int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);
 int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed,
                     const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
                     hipStream_t stream);

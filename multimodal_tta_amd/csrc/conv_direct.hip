@@ -144,21 +144,203 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DArgs a) {
   }
 }
 
-bool direct_applicable(const mmtta_conv_desc* d) {
-  int N;
-  switch (d->op) {
-    case MMTTA_CONV_FWD: case MMTTA_CONVT_FWD: N = d->cout; break;
-    default: N = d->cin; break;
+// ------------------------------------------------------------------ lanes along K (K = 32 or 64)
+// The thread-per-voxel form above reads a 16-byte piece of 64 different cache lines with every load once K is
+// wide (the full-resolution ConvTranspose3d 64->R of the U-Net, the 1x1 final conv 32->R of the deep-fusion
+// net).  Here KL = K/4 adjacent lanes own one voxel's channels (one 16-byte load each: a voxel is one contiguous
+// K*4-byte run), a wave walks 64 voxels of one output row in KL passes, and the taps are the OUTER
+// loop so a tap's 4x4 weights are read from LDS once per wave, not once per voxel.  Stride-2 transposed taps
+// depend on the output parity, so a wave takes voxels of one x parity: its tap list is wave-uniform.
+// Partial sums (KL lanes x NO outputs x KL passes) are combined by a halving exchange: log2(KL) steps, each lane
+// ends with the NO outputs of one voxel.
+template <int KL, int NO, bool HAS_T>
+__global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
+  extern __shared__ float lds[];
+  constexpr int VW = 64 / KL;            // voxels per pass
+  constexpr int NP = KL;                 // passes: 64 voxels per wave
+  const int T = a.ksize * a.ksize * a.ksize;
+  float* wl = lds;                       // [T][K][4]
+  float* red = lds + T * a.K * 4;        // [sum|sq][wave][channel]
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < T * a.K; i += 256)
+    *reinterpret_cast<float4*>(wl + 4 * i) = *reinterpret_cast<const float4*>(a.w + 4 * i);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kl = lane % KL, g = lane / KL, k0 = kl * 4;
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (HAS_T) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nl_coeff(a.tin, n, a.K, k0 + j, sc[j], sh[j]);
   }
-  int K = (N == d->cout) ? d->cin : d->cout;
+  const int pad = (a.ksize - 1) / 2;
+  const bool s2t = a.transposed && a.stride == 2;
+  const int xstep = s2t ? 2 : 1;
+  const int rowlen = (a.out.w + xstep - 1) / xstep;
+  const int chunks = (rowlen + 63) / 64;
+  const long long units = (long long)a.out.d * a.out.h * xstep * chunks;
+  long long u = (long long)blockIdx.x * 4 + wave;
+  const bool wave_on = u < units;
+  int chunk = 0, px = 0, oy = 0, oz = 0;
+  if (wave_on) {
+    chunk = (int)(u % chunks); u /= chunks;
+    px = (int)(u % xstep); u /= xstep;
+    oy = (int)(u % a.out.h);
+    oz = (int)(u / a.out.h);
+  }
+  float acc[NP * NO];
+#pragma unroll
+  for (int i = 0; i < NP * NO; ++i) acc[i] = 0.f;
+  if (wave_on) {
+    const float* inb = a.in.p + (long long)n * a.in.sn + k0;
+    for (int kz = 0; kz < a.ksize; ++kz) {
+      int iz;
+      if (!a.transposed) iz = oz * a.stride + kz - pad;
+      else {
+        const int t = oz + pad - kz;
+        if (t < 0 || (a.stride == 2 && (t & 1))) continue;
+        iz = a.stride == 2 ? (t >> 1) : t;
+      }
+      if ((unsigned)iz >= (unsigned)a.in.d) continue;
+      for (int ky = 0; ky < a.ksize; ++ky) {
+        int iy;
+        if (!a.transposed) iy = oy * a.stride + ky - pad;
+        else {
+          const int t = oy + pad - ky;
+          if (t < 0 || (a.stride == 2 && (t & 1))) continue;
+          iy = a.stride == 2 ? (t >> 1) : t;
+        }
+        if ((unsigned)iy >= (unsigned)a.in.h) continue;
+        const float* row = inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh;
+        for (int kx = 0; kx < a.ksize; ++kx) {
+          if (s2t && ((px + pad - kx) & 1)) continue;
+          const float* wt = wl + (((kz * a.ksize + ky) * a.ksize + kx) * a.K + k0) * 4;
+          float w[4][4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 t4 = *reinterpret_cast<const float4*>(wt + 4 * j);
+            w[j][0] = t4.x; w[j][1] = t4.y; w[j][2] = t4.z; w[j][3] = t4.w;
+          }
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const int ox = px + xstep * (chunk * 64 + p * VW + g);
+            int ix;
+            if (!a.transposed) ix = ox * a.stride + kx - pad;
+            else { const int t = ox + pad - kx; ix = a.stride == 2 ? (t >> 1) : t; }
+            const bool ok = ox < a.out.w && (unsigned)ix < (unsigned)a.in.w;
+            const float4 x4 = *reinterpret_cast<const float4*>(row + (long long)(ok ? ix : 0) * a.in.sw);
+            float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float xv = HAS_T ? nl_apply(xs[j], sc[j], sh[j], a.tin.relu) : xs[j];
+              xv = ok ? xv : 0.f;
+#pragma unroll
+              for (int c = 0; c < NO; ++c) acc[p * NO + c] = fmaf(xv, w[j][c], acc[p * NO + c]);
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- halving exchange inside each KL-lane group: lane kl ends with pass kl's NO sums
+#pragma unroll
+  for (int m = KL / 2, h = NP * NO / 2; m >= 1; m >>= 1, h >>= 1) {
+    const bool hi = (kl & m) != 0;
+#pragma unroll
+    for (int i = 0; i < NP * NO / 2; ++i) {
+      if (i < h) {
+        const float send = hi ? acc[i] : acc[i + h];
+        const float keep = hi ? acc[i + h] : acc[i];
+        acc[i] = keep + __shfl_xor(send, m, 64);
+      }
+    }
+  }
+  // ---- epilogue: this lane owns voxel (chunk*64 + kl*VW + g) of the wave's row
+  const int ox = px + xstep * (chunk * 64 + kl * VW + g);
+  const bool active = wave_on && ox < a.out.w;
+  float ssum[NO], ssq[NO];
+#pragma unroll
+  for (int c = 0; c < NO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+  if (active) {
+    float* op = a.out.p + (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh +
+                (long long)ox * a.out.sw;
+    const float* ap = a.add ? a.add + (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash +
+                                  (long long)ox * a.asw : nullptr;
+#pragma unroll
+    for (int c = 0; c < NO; ++c) {
+      float val = acc[c] + (a.bias ? a.bias[c] : 0.f);
+      if (ap) {
+        float s1, h1;
+        nl_coeff(a.tadd, n, a.N, c, s1, h1);
+        val += nl_apply(ap[c], s1, h1, a.tadd.relu);
+      }
+      if (a.accumulate) val += op[c];
+      op[c] = val;
+      ssum[c] = val; ssq[c] = val * val;
+    }
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int c = 0; c < NO; ++c) {
+      const float s = wave_sum(ssum[c]), q = wave_sum(ssq[c]);
+      if (lane == 0) { red[(0 * 4 + wave) * 4 + c] = s; red[(1 * 4 + wave) * 4 + c] = q; }
+    }
+    __syncthreads();
+    if (threadIdx.x < NO) {
+      const int c = threadIdx.x;
+      const float s = red[0 * 4 + c] + red[1 * 4 + c] + red[2 * 4 + c] + red[3 * 4 + c];
+      const float q = red[16 + 0 * 4 + c] + red[16 + 1 * 4 + c] + red[16 + 2 * 4 + c] + red[16 + 3 * 4 + c];
+      const long long rrow = (long long)n * a.blocks_per_n + blockIdx.x;
+      a.stats[(rrow * 2 + 0) * a.N + c] = s;
+      a.stats[(rrow * 2 + 1) * a.N + c] = q;
+    }
+  }
+}
+
+static void direct_dims(const mmtta_conv_desc* d, int& K, int& N) {
+  switch (d->op) {
+    case MMTTA_CONV_FWD: case MMTTA_CONVT_FWD: N = d->cout; K = d->cin; break;
+    default: N = d->cin; K = d->cout; break;
+  }
+}
+
+bool direct_applicable(const mmtta_conv_desc* d) {
+  int K, N;
+  direct_dims(d, K, N);
   const int T = d->ksize * d->ksize * d->ksize;
   // weights + coefficients must fit in LDS next to nothing else: T*K*16 + K*8 bytes
   return N <= 4 && (size_t)T * K * 16 + (size_t)K * 8 + 128 <= 96 * 1024;
 }
 
-int direct_blocks_per_n(const mmtta_tensor* y) {
+// lanes-along-K form: K = 32 or 64 and 16-byte addressable input
+static bool klane_ok(const mmtta_conv_desc* d, const mmtta_tensor* x) {
+  int K, N;
+  direct_dims(d, K, N);
+  return (K == 32 || K == 64) && x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0 &&
+         ((uintptr_t)x->ptr) % 16 == 0;
+}
+
+int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y) {
+  if (klane_ok(d, x)) {
+    const bool s2t = (d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONV_DGRAD) && d->stride == 2;
+    const int xstep = s2t ? 2 : 1;
+    const int rowlen = (y->w + xstep - 1) / xstep;
+    const long long units = (long long)y->d * y->h * xstep * ((rowlen + 63) / 64);
+    return (int)((units + 3) / 4);
+  }
   const long long dhw = (long long)y->d * y->h * y->w;
   return (int)((dhw + 255) / 256);
+}
+
+template <int KL, bool HAS_T>
+static void launch_klane(const DArgs& a, int n, size_t lds, hipStream_t stream) {
+  const dim3 grid(a.blocks_per_n, n), block(256);
+  switch (a.N) {
+    case 1: hipLaunchKernelGGL((direct_klane_kernel<KL, 1, HAS_T>), grid, block, lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((direct_klane_kernel<KL, 2, HAS_T>), grid, block, lds, stream, a); break;
+    case 3: hipLaunchKernelGGL((direct_klane_kernel<KL, 3, HAS_T>), grid, block, lds, stream, a); break;
+    default: hipLaunchKernelGGL((direct_klane_kernel<KL, 4, HAS_T>), grid, block, lds, stream, a); break;
+  }
 }
 
 int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed,
@@ -178,7 +360,7 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   a.K = x->c; a.N = y->c; a.ksize = d->ksize; a.stride = d->stride;
   a.transposed = (d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONV_DGRAD) ? 1 : 0;
   a.accumulate = accumulate;
-  a.stats = stats; a.blocks_per_n = direct_blocks_per_n(y);
+  a.stats = stats; a.blocks_per_n = direct_blocks_per_n(d, x, y);
   const int T = d->ksize * d->ksize * d->ksize;
   const size_t lds = (size_t)T * a.K * 16 + (size_t)a.K * 8 + 32 * sizeof(float);
   static bool attr_set = false;
@@ -189,7 +371,14 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
     MMTTA_CHECK(e == hipSuccess, MMTTA_ERR_LAUNCH, "direct conv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  if (a.tin.mean != nullptr || a.tin.scale != nullptr) hipLaunchKernelGGL(direct_conv_kernel<true>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
+  const bool has_t = a.tin.mean != nullptr || a.tin.scale != nullptr;
+  if (klane_ok(d, x)) {
+    const size_t kl_lds = (size_t)T * a.K * 16 + 32 * sizeof(float);
+    if (a.K == 64) { if (has_t) launch_klane<16, true>(a, y->n, kl_lds, stream); else launch_klane<16, false>(a, y->n, kl_lds, stream); }
+    else { if (has_t) launch_klane<8, true>(a, y->n, kl_lds, stream); else launch_klane<8, false>(a, y->n, kl_lds, stream); }
+    return launch_status("direct conv (lanes along K)");
+  }
+  if (has_t) hipLaunchKernelGGL(direct_conv_kernel<true>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL(direct_conv_kernel<false>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
   return launch_status("direct conv");
 }

@@ -572,43 +572,91 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned s
   }
 }
 
-// All packed images of a model in ONE launch: a device table of entries, global element index -> entry by
-// binary search over the prefix sums (the per-layer launches cost ~8 us each, 46 per step for the U-Net).
+// All packed images of a model in ONE launch: a device table of entries; a workgroup finds its entry by
+// binary search over the prefix sums of the entries' workgroup counts (uniform, scalar).
+//
+// A packed image is a transpose of the torch weight (taps innermost there, outermost here), so a workgroup
+// moves one 8 (k) x 32 (n) x T tile through LDS: coalesced runs of the master in, 128-byte (fp32: one n row)
+// or 512-byte (bf16: 32 n x 8 k) runs of the image out.  ~155 MB per U-Net repack: HBM-bound.
 struct PackEntry {
   const float* w; void* p;
-  int A, B, T, Kp, Np, kn_is_ba, bf16, _pad;
-  long long start;
+  int A, B, T, Kp, Np, kn_is_ba, bf16, direct;
+  long long start;   // first workgroup of this entry
 };
 
-__global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __restrict__ tab, int count, long long total) {
-  // one thread per (k, n) position of an image; it walks the T taps: the master reads are T contiguous floats
-  // (torch keeps the taps innermost), the image writes are coalesced across n for every tap.
-  // `start` / `total` count (k, n) positions.
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    int lo = 0, hi = count - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (tab[mid].start <= i) lo = mid; else hi = mid - 1;
+constexpr int PK = 8, PN = 32;
+
+template <int T>
+__device__ __forceinline__ void pack_tile(const PackEntry& e, int lb, float* tile) {
+  const int tiles_n = e.Np / PN;
+  const int k0 = (lb / tiles_n) * PK, n0 = (lb % tiles_n) * PN;
+  const int K = e.kn_is_ba ? e.B : e.A, N = e.kn_is_ba ? e.A : e.B;
+  constexpr int RS = PK * T + 1;                 // row stride of the [n][k*T+tap] staging (odd: no bank conflicts)
+  if (e.kn_is_ba) {                              // a = n, b = k: per n a run of PK*T contiguous floats
+    for (int idx = threadIdx.x; idx < PN * PK * T; idx += 256) {
+      const int nn = idx / (PK * T), r = idx % (PK * T);
+      const int kk = r / T;
+      float v = 0.f;
+      if (n0 + nn < N && k0 + kk < K) v = e.w[((long long)(n0 + nn) * e.B + k0) * T + r];
+      tile[nn * RS + r] = v;
     }
-    const PackEntry e = tab[lo];
-    const long long li = i - e.start;
-    // position order follows the image's own memory order so that the stores of a wave stay contiguous:
-    // fp32 [k][n]; bf16 [k/8][n][k%8]
-    int nn, k;
-    if (e.bf16) { nn = (int)((li >> 3) % e.Np); k = (int)(li / (8LL * e.Np)) * 8 + (int)(li & 7); }
-    else { nn = (int)(li % e.Np); k = (int)(li / e.Np); }
-    const int K = e.kn_is_ba ? e.B : e.A, N = e.kn_is_ba ? e.A : e.B;
-    const bool live = k < K && nn < N;
-    const int ai = e.kn_is_ba ? nn : k, bi = e.kn_is_ba ? k : nn;
-    const float* src = e.w + ((long long)ai * e.B + bi) * e.T;
-    const long long slab = (long long)e.Kp * e.Np;
-    for (int tp = 0; tp < e.T; ++tp) {
-      const float v = live ? src[tp] : 0.f;
-      if (e.bf16) ((unsigned short*)e.p)[tp * slab + ((long long)(k >> 3) * e.Np + nn) * 8 + (k & 7)] = __builtin_bit_cast(unsigned short, (__bf16)v);
-      else ((float*)e.p)[tp * slab + (long long)k * e.Np + nn] = v;
+  } else {                                       // a = k, b = n: per k a run of PN*T contiguous floats
+    for (int idx = threadIdx.x; idx < PK * PN * T; idx += 256) {
+      const int kk = idx / (PN * T), r = idx % (PN * T);
+      const int nn = r / T;
+      float v = 0.f;
+      if (k0 + kk < K && n0 + nn < N) v = e.w[((long long)(k0 + kk) * e.B + n0) * T + r];
+      tile[kk * (PN * T) + r] = v;
     }
   }
+  __syncthreads();
+  const long long slab = (long long)e.Kp * e.Np;
+  if (e.bf16) {
+    for (int o = threadIdx.x; o < T * PN; o += 256) {
+      const int nn = o % PN, tp = o / PN;
+      unsigned short h[8];
+#pragma unroll
+      for (int kk = 0; kk < PK; ++kk) {
+        const float v = e.kn_is_ba ? tile[nn * RS + kk * T + tp] : tile[kk * (PN * T) + nn * T + tp];
+        h[kk] = __builtin_bit_cast(unsigned short, (__bf16)v);
+      }
+      uint4 q;
+      q.x = h[0] | ((unsigned)h[1] << 16); q.y = h[2] | ((unsigned)h[3] << 16);
+      q.z = h[4] | ((unsigned)h[5] << 16); q.w = h[6] | ((unsigned)h[7] << 16);
+      *reinterpret_cast<uint4*>((unsigned short*)e.p + tp * slab + ((long long)(k0 >> 3) * e.Np + n0 + nn) * 8) = q;
+    }
+  } else {
+    for (int o = threadIdx.x; o < T * PK * PN; o += 256) {
+      const int nn = o % PN, kk = (o / PN) % PK, tp = o / (PN * PK);
+      const float v = e.kn_is_ba ? tile[nn * RS + kk * T + tp] : tile[kk * (PN * T) + nn * T + tp];
+      ((float*)e.p)[tp * slab + (long long)(k0 + kk) * e.Np + n0 + nn] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __restrict__ tab, int count) {
+  __shared__ float tile[PN * (PK * 27 + 1)];
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].start <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackEntry e = tab[lo];
+  const int lb = (int)(blockIdx.x - e.start);
+  if (e.direct) {
+    // [T][K][4] fp32 image of a direct-convolution layer: a few KB, one position per thread
+    const int li = lb * 256 + threadIdx.x;
+    if (li >= e.Kp * e.Np) return;
+    const int nn = li % e.Np, k = li / e.Np;
+    const int N = e.kn_is_ba ? e.A : e.B;
+    const int ai = e.kn_is_ba ? nn : k, bi = e.kn_is_ba ? k : nn;
+    const float* src = e.w + ((long long)ai * e.B + bi) * e.T;
+    for (int tp = 0; tp < e.T; ++tp)
+      ((float*)e.p)[(long long)tp * e.Kp * e.Np + li] = nn < N ? src[tp] : 0.f;
+    return;
+  }
+  if (e.T == 27) pack_tile<27>(e, lb, tile);
+  else pack_tile<1>(e, lb, tile);
 }
 
 // ---------------------------------------------------------------- host side
@@ -875,7 +923,8 @@ static int fill_pack_entry(const mmtta_conv_desc* d, const float* w, void* packe
   e.T = d->ksize * d->ksize * d->ksize;
   e.Kp = direct ? K : roundup(K, 32); e.Np = direct ? 4 : roundup(N, 32);
   e.kn_is_ba = (d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_DGRAD) ? 1 : 0;
-  e.bf16 = use_bf16(d, K) ? 1 : 0; e._pad = 0;
+  e.bf16 = use_bf16(d, K) ? 1 : 0; e.direct = direct ? 1 : 0;
+  MMTTA_CHECK(e.T == 1 || e.T == 27, MMTTA_ERR_UNSUPPORTED, "pack: ksize %d", d->ksize);
   e.start = 0;
   return MMTTA_OK;
 }
@@ -890,7 +939,8 @@ extern "C" int mmtta_conv_pack_table_build(const mmtta_pack_item* items, int cou
     int st = fill_pack_entry(&items[i].desc, items[i].w_master, items[i].packed, tab[i]);
     if (st) return st;
     tab[i].start = run;
-    run += (long long)tab[i].Kp * tab[i].Np;
+    run += tab[i].direct ? ((long long)tab[i].Kp * tab[i].Np + 255) / 256
+                         : (long long)(tab[i].Kp / PK) * (tab[i].Np / PN);
   }
   *total = run;
   return MMTTA_OK;
@@ -898,10 +948,9 @@ extern "C" int mmtta_conv_pack_table_build(const mmtta_pack_item* items, int cou
 
 extern "C" int mmtta_conv_pack_batched(const void* table_dev, int count, int64_t total, void* stream) {
   MMTTA_CHECK(table_dev && count > 0 && total > 0, MMTTA_ERR_INVALID, "pack batched: bad argument");
-  long long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev,
-                     count, (long long)total);
+  MMTTA_CHECK(total < (1LL << 31), MMTTA_ERR_UNSUPPORTED, "pack batched: %lld workgroups", (long long)total);
+  hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev,
+                     count);
   return launch_status("pack batched");
 }
 
@@ -912,7 +961,7 @@ extern "C" int mmtta_conv_plan(const mmtta_conv_desc* d, const mmtta_tensor* x, 
   int st = geometry(d, x, y, g);
   if (st) return st;
   if (direct_applicable(d)) {
-    plan->tiles = direct_blocks_per_n(y) * y->n;
+    plan->tiles = direct_blocks_per_n(d, x, y) * y->n;
     plan->launches = 1;
     plan->ksplit = 1;
     plan->stats_rows = plan->tiles;

@@ -615,8 +615,8 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
               "wgrad: desc.op must name the module (CONV_FWD or CONVT_FWD)");
   MMTTA_CHECK(d->ksize == 1 || d->ksize == 3, MMTTA_ERR_UNSUPPORTED, "wgrad: ksize %d", d->ksize);
   MMTTA_CHECK(d->stride == 1 || d->stride == 2, MMTTA_ERR_UNSUPPORTED, "wgrad: stride %d", d->stride);
-  // desc.dtype selects the operand type of the data-path convolutions; weight gradients always accumulate
-  // fp32 products of fp32 operands
+  // desc.dtype selects the MFMA operand type (fp32, or bf16 for the 27-tap layers); accumulation, slabs and the
+  // reduced gradient are fp32 either way
   MMTTA_CHECK(d->dtype == MMTTA_F32 || d->dtype == MMTTA_BF16, MMTTA_ERR_UNSUPPORTED, "wgrad: dtype %d", d->dtype);
   MMTTA_CHECK(is_cl(x) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "wgrad: tensors must be channels-last");
   MMTTA_CHECK(x->c == d->cin && dy->c == d->cout && x->n == dy->n, MMTTA_ERR_INVALID, "wgrad: channel/batch mismatch");
@@ -713,6 +713,16 @@ extern "C" int64_t mmtta_conv_wgrad_workspace_bytes(const mmtta_conv_desc* d, co
   WGeo w;
   if (wgeometry(d, x, dy, w)) return -1;
   return (w.slab_floats + w.db_floats + w.pre_floats) * (int64_t)sizeof(float);
+}
+
+extern "C" int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* dy) {
+  WGeo w;
+  const int st = wgeometry(d, x, dy, w);
+  if (st) return st < 0 ? st : -st;
+  if (w.small) return 3;
+  if (w.bf16) return w.si == 1 ? 4 : 5;
+  if (w.ntaps == 1) return 2;
+  return w.si == 1 ? 0 : 1;
 }
 
 extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,

@@ -110,6 +110,10 @@ IGEMM_KERNELS = ["igemm_f32_kernel<1,4,8,8,8,8>", "igemm_f32_kernel<2,4,4,8,8,16
                  "igemm_kernel<1,1,4,4,8,16,bf16>", "igemm_kernel<2,2,4,4,8,16,bf16>", "igemm_kernel<4,4,4,4,8,16,bf16>"]
 
 
+WGRAD_KERNELS = ["wgrad_f32_kernel<4,4,8,7>", "wgrad_f32_kernel<2,2,8,7>", "wgrad_f32_kernel<4,4,8,1>", "wgrad_small_kernel",
+                 "wgrad_bf16_kernel<4,4,1>", "wgrad_bf16_kernel<2,4,2>"]
+
+
 class KernelProfiler:
     """Brackets every conv launch with events on the launch stream and books its algorithmic FLOPs
     (bench.py roofline: FLOPs per launch / measured duration).  Off unless installed in ops.PROFILER."""
@@ -262,9 +266,8 @@ class ConvOp:
             e0 = PROFILER.begin()
             for _ in range(PROFILER.reps):
                 launch()
-            name = "wgrad_f32_kernel<4,4,8,1>" if self.k == 1 else (
-                "wgrad_f32_kernel<4,4,8,7>" if self.stride == 1 else "wgrad_f32_kernel<2,2,8,7>")
-            PROFILER.end(name + "+reduce", PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0)
+            kid = lib.mmtta_conv_wgrad_kernel(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy))
+            PROFILER.end(WGRAD_KERNELS[kid] + "+reduce", PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0)
 
 
 class BatchedPacker:

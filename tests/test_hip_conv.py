@@ -56,6 +56,13 @@ CASES = [
     (16, 8, 1, 1, False, (1, 8, 8, 8)),
     (1, 4, 3, 2, False, (1, 16, 16, 16)),
     (4, 8, 3, 2, False, (1, 8, 8, 8)),
+    # wide-K layers that produce <= 4 channels (lanes-along-K direct kernel): full-resolution up-convolution,
+    # 1x1 heads; rows longer than one 64-voxel chunk and odd extents
+    (64, 3, 3, 2, True, (1, 3, 5, 70)),
+    (64, 1, 3, 2, True, (2, 4, 4, 8)),
+    (32, 3, 1, 1, False, (1, 4, 6, 150)),
+    (64, 2, 3, 1, False, (1, 5, 6, 7)),
+    (3, 64, 3, 1, False, (1, 6, 6, 9)),
 ]
 
 
@@ -238,3 +245,29 @@ def test_conv_bf16_operands(cin, cout, k, stride, transposed, shape):
     st = stats.view(n, rows // n, 2, cout).double().sum(1).cpu()
     got_sum = ncdhw(y_cl).double().sum(dim=(2, 3, 4))
     assert torch.allclose(st[:, 0], got_sum, rtol=1e-3, atol=1e-2 * max(1.0, got_sum.abs().max().item()))
+
+
+def test_batched_pack_matches_per_layer_pack():
+    """One launch repacks every image of a model; each image must be bit-identical to the per-layer pack
+    (fp32 and bf16 images, both orientations, 1x1, transposed, direct-path layers, ragged channel counts)."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(5)
+    layers = [(32, 64, 3, 2, False), (33, 40, 3, 1, False), (64, 3, 3, 2, True), (3, 3, 3, 1, False),
+              (256, 512, 1, 1, False), (768, 128, 3, 2, True), (4, 32, 3, 2, False), (32, 3, 1, 1, False)]
+    for dtype in (ops.F32, ops.BF16):
+        convs, items = [], []
+        for cin, cout, k, s, tr in layers:
+            op = ops.ConvOp(cin, cout, k, s, tr, "cuda", dtype=dtype)
+            shape = (cin, cout, k, k, k) if tr else (cout, cin, k, k, k)
+            w = torch.randn(shape, device="cuda")
+            op.pack(w)
+            convs.append((op, w, op.packed_fwd.clone(), op.packed_dgrad.clone()))
+            op.packed_fwd.fill_(0xAB)
+            op.packed_dgrad.fill_(0xAB)
+            items += [(op.d_fwd, w, op.packed_fwd), (op.d_dgrad, w, op.packed_dgrad)]
+        ops.BatchedPacker(items, torch.device("cuda")).run()
+        torch.cuda.synchronize()
+        for (op, w, pf, pd), (cin, cout, k, s, tr) in zip(convs, layers):
+            assert torch.equal(op.packed_fwd, pf), f"fwd image differs: {(cin, cout, k, s, tr)} dtype {dtype}"
+            assert torch.equal(op.packed_dgrad, pd), f"dgrad image differs: {(cin, cout, k, s, tr)} dtype {dtype}"
