@@ -44,8 +44,14 @@ typedef struct {
   int32_t n, c, d, h, w;
   int64_t sn, sc, sd, sh, sw;
   int32_t dtype; /* mmtta_dtype */
-  int32_t _pad;
+  int32_t flags; /* MMTTA_TENSOR_* */
 } mmtta_tensor;
+
+/* The (sw - c) elements behind every voxel's channels are padding that belongs to this view (a buffer allocated
+ * with a channel row padded to 4 floats, not a slice of a wider tensor): kernels may overwrite them with zeros so
+ * that a 3-channel voxel is ONE full 16-byte store instead of three partial ones (partial 32-byte sectors cost a
+ * read-modify-write in HBM). */
+#define MMTTA_TENSOR_OWNS_PAD 1
 
 /* Per-(n,c) normalisation applied to a tensor WHEN IT IS READ ("norm on load"):
  *   v = (x - mean[n*C+c]) * rstd[n*C+c] * (gamma ? gamma[c] : 1) + (beta ? beta[c] : 0);
@@ -169,6 +175,7 @@ int64_t mmtta_conv_wgrad_workspace_bytes(const mmtta_conv_desc* desc, const mmtt
 /* Which weight-gradient kernel mmtta_conv_wgrad picks for this problem (profiling / roofline bookkeeping):
  *   0 fp32 MFMA k3 s1   1 fp32 MFMA k3 s2 (and conv_transpose)   2 fp32 MFMA k1
  *   3 small-channel (<= 4 channels on one side, fp32 MFMA)       4 bf16 MFMA k3 s1   5 bf16 MFMA k3 s2
+ *   6 tiny (<= 4 channels on both sides, k3 s1: fp32 VALU)
  * or a negative mmtta error code. */
 int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_tensor* dy);
 int mmtta_conv_wgrad(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,

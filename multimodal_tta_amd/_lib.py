@@ -27,7 +27,7 @@ class Tensor(C.Structure):
         ("ptr", C.c_void_p),
         ("n", C.c_int32), ("c", C.c_int32), ("d", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
         ("sn", C.c_int64), ("sc", C.c_int64), ("sd", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64),
-        ("dtype", C.c_int32), ("_pad", C.c_int32),
+        ("dtype", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -143,6 +143,9 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else int(t.data_ptr())
 
 
+TENSOR_OWNS_PAD = 1   # include/mmtta.h MMTTA_TENSOR_OWNS_PAD
+
+
 def desc_cl(t: torch.Tensor) -> Tensor:
     """Descriptor of a channels-last activation view: torch shape [N, D, H, W, C], stride(C) == 1."""
     if t.dim() != 5 or t.dtype != torch.float32 or not t.is_cuda:
@@ -151,7 +154,8 @@ def desc_cl(t: torch.Tensor) -> Tensor:
     sn, sd, sh, sw, sc = t.stride()
     if sc != 1 and c != 1:
         raise MmttaError("activation views must have unit stride along C")
-    return Tensor(t.data_ptr(), n, c, d, h, w, sn, 1, sd, sh, sw, F32, 0)
+    flags = TENSOR_OWNS_PAD if getattr(t, "_mmtta_owns_pad", False) else 0
+    return Tensor(t.data_ptr(), n, c, d, h, w, sn, 1, sd, sh, sw, F32, flags)
 
 
 def desc_ncdhw(t: torch.Tensor) -> Tensor:

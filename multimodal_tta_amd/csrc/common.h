@@ -36,11 +36,13 @@ struct TV {
   float* p;
   int n, c, d, h, w;
   long long sn, sc, sd, sh, sw;
+  int flags;
 };
 
 inline TV tv(const mmtta_tensor* t) {
   TV v;
   v.p = (float*)t->ptr;
+  v.flags = t->flags;
   v.n = t->n; v.c = t->c; v.d = t->d; v.h = t->h; v.w = t->w;
   v.sn = t->sn; v.sc = t->sc; v.sd = t->sd; v.sh = t->sh; v.sw = t->sw;
   return v;
@@ -79,6 +81,21 @@ __device__ __forceinline__ void nl_coeff(const NL& t, int n, int C, int c, float
 __device__ __forceinline__ float nl_apply(float x, float sc, float sh, int relu) {
   float v = fmaf(x, sc, sh);
   return relu ? fmaxf(v, 0.f) : v;
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs, each with its own L2 (observed placement: a speed matter only).
+// Give the workgroups that share an XCD one CONTIGUOUS range of logical ids, so that neighbours in the logical order
+// (which share halo rows / operand panels) hit the same L2.  Bijective for any workgroup count.
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned b, unsigned nwg) {
+  const unsigned x = b & 7u, i = b >> 3, q = nwg >> 3, r = nwg & 7u;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// [first, last) of the work units of logical workgroup lb when `units` are split into nwg contiguous ranges
+__device__ __forceinline__ void unit_range(long long units, unsigned lb, unsigned nwg, long long& first, long long& last) {
+  const long long per = (units + nwg - 1) / nwg;
+  first = per * lb;
+  last = first + per < units ? first + per : units;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

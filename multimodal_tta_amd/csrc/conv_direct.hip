@@ -24,6 +24,7 @@ struct DArgs {
   const float* add; long long asn, asd, ash, asw; NL tadd;
   int K, N, ksize, stride, transposed, accumulate;
   float* stats; int blocks_per_n;
+  int out_vec4;        // N < 4, 16-byte voxel rows whose pad lanes this view owns: one full store per voxel
 };
 
 // valid taps of one axis for output coordinate o: (k, input coordinate) pairs
@@ -144,15 +145,69 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ shared epilogue
+// One lane owns one output voxel with NO channel values: bias, fused residual add, accumulate, store; the
+// values are also added into the lane's running statistics.
+template <int NO>
+__device__ __forceinline__ void direct_epilogue(const DArgs& a, int n, int oz, int oy, int ox, const float* val_in,
+                                                float* ssum, float* ssq) {
+  float* op = a.out.p + (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh +
+              (long long)ox * a.out.sw;
+  const float* ap = a.add ? a.add + (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash +
+                                (long long)ox * a.asw : nullptr;
+  float vals[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NO; ++c) {
+    float val = val_in[c] + (a.bias ? a.bias[c] : 0.f);
+    if (ap) {
+      float s1, h1;
+      nl_coeff(a.tadd, n, a.N, c, s1, h1);
+      val += nl_apply(ap[c], s1, h1, a.tadd.relu);
+    }
+    if (a.accumulate) val += op[c];
+    vals[c] = val;
+    ssum[c] += val; ssq[c] += val * val;
+  }
+  if (a.out_vec4) *reinterpret_cast<float4*>(op) = make_float4(vals[0], vals[1], vals[2], vals[3]);
+  else {
+#pragma unroll
+    for (int c = 0; c < NO; ++c) op[c] = vals[c];
+  }
+}
+
+// per-block statistics row from the lanes' running sums (red: 32 floats of LDS)
+template <int NO>
+__device__ __forceinline__ void direct_stats(const DArgs& a, int n, const float* ssum, const float* ssq, float* red) {
+  if (a.stats == nullptr) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < NO; ++c) {
+    const float s = wave_sum(ssum[c]), q = wave_sum(ssq[c]);
+    if (lane == 0) { red[(0 * 4 + wave) * 4 + c] = s; red[(1 * 4 + wave) * 4 + c] = q; }
+  }
+  __syncthreads();
+  if (threadIdx.x < NO) {
+    const int c = threadIdx.x;
+    const float s = red[0 * 4 + c] + red[1 * 4 + c] + red[2 * 4 + c] + red[3 * 4 + c];
+    const float q = red[16 + 0 * 4 + c] + red[16 + 1 * 4 + c] + red[16 + 2 * 4 + c] + red[16 + 3 * 4 + c];
+    const long long rrow = (long long)n * a.blocks_per_n + blockIdx.x;
+    a.stats[(rrow * 2 + 0) * a.N + c] = s;
+    a.stats[(rrow * 2 + 1) * a.N + c] = q;
+  }
+}
+
 // ------------------------------------------------------------------ lanes along K (K = 32 or 64)
 // The thread-per-voxel form above reads a 16-byte piece of 64 different cache lines with every load once K is
 // wide (the full-resolution ConvTranspose3d 64->R of the U-Net, the 1x1 final conv 32->R of the deep-fusion
 // net).  Here KL = K/4 adjacent lanes own one voxel's channels (one 16-byte load each: a voxel is one contiguous
-// K*4-byte run), a wave walks 64 voxels of one output row in KL passes, and the taps are the OUTER
-// loop so a tap's 4x4 weights are read from LDS once per wave, not once per voxel.  Stride-2 transposed taps
-// depend on the output parity, so a wave takes voxels of one x parity: its tap list is wave-uniform.
-// Partial sums (KL lanes x NO outputs x KL passes) are combined by a halving exchange: log2(KL) steps, each lane
-// ends with the NO outputs of one voxel.
+// K*4-byte run), a wave walks 64 voxels of one output row in KL passes, and the taps are the OUTER loop so a
+// tap's 4x4 weights are read from LDS once per wave, not once per voxel.  Stride-2 transposed taps depend on the
+// output parity, so a wave takes voxels of one x parity: its tap list is wave-uniform.  Addresses are a
+// wave-uniform row pointer plus a 32-bit lane offset that advances by a scalar per pass; rows whose 64 voxels
+// are all in range (all but the image border) take a path without per-voxel predicates.  Partial sums
+// (KL lanes x NO outputs x KL passes) are combined by a halving exchange: log2(KL) steps, each lane ends with
+// the NO outputs of one voxel.  A workgroup keeps its weights in LDS and walks a contiguous range of units;
+// ranges that are neighbours in the volume run on the same XCD (xcd_contiguous_id) so halo rows hit its L2.
 template <int KL, int NO, bool HAS_T>
 __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
   extern __shared__ float lds[];
@@ -174,32 +229,37 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
     for (int j = 0; j < 4; ++j) nl_coeff(a.tin, n, a.K, k0 + j, sc[j], sh[j]);
   }
   const int pad = (a.ksize - 1) / 2;
-  const bool s2t = a.transposed && a.stride == 2;
+  const bool s2 = a.stride == 2;
+  const bool s2t = a.transposed && s2;
   const int xstep = s2t ? 2 : 1;
   const int rowlen = (a.out.w + xstep - 1) / xstep;
   const int chunks = (rowlen + 63) / 64;
   const long long units = (long long)a.out.d * a.out.h * xstep * chunks;
-  long long u = (long long)blockIdx.x * 4 + wave;
-  const bool wave_on = u < units;
-  int chunk = 0, px = 0, oy = 0, oz = 0;
-  if (wave_on) {
-    chunk = (int)(u % chunks); u /= chunks;
-    px = (int)(u % xstep); u /= xstep;
-    oy = (int)(u % a.out.h);
-    oz = (int)(u / a.out.h);
-  }
-  float acc[NP * NO];
+  const unsigned sw4 = (unsigned)a.in.sw * 4u;         // bytes between x neighbours of the input
+  float ssum[NO], ssq[NO];
 #pragma unroll
-  for (int i = 0; i < NP * NO; ++i) acc[i] = 0.f;
-  if (wave_on) {
-    const float* inb = a.in.p + (long long)n * a.in.sn + k0;
+  for (int c = 0; c < NO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+
+  long long ufirst, ulast;
+  unit_range(units, xcd_contiguous_id(blockIdx.x, gridDim.x), gridDim.x, ufirst, ulast);
+  for (long long u0 = ufirst + wave; u0 < ulast; u0 += 4) {
+    long long u = u0;
+    const int chunk = (int)(u % chunks); u /= chunks;
+    const int px = (int)(u % xstep); u /= xstep;
+    const int oy = (int)(u % a.out.h);
+    const int oz = (int)(u / a.out.h);
+    const int ibase = chunk * 64;                        // first voxel index (within the parity row) of this wave
+    float acc[NP * NO];
+#pragma unroll
+    for (int i = 0; i < NP * NO; ++i) acc[i] = 0.f;
+    const char* inb = reinterpret_cast<const char*>(a.in.p + (long long)n * a.in.sn);
     for (int kz = 0; kz < a.ksize; ++kz) {
       int iz;
       if (!a.transposed) iz = oz * a.stride + kz - pad;
       else {
         const int t = oz + pad - kz;
-        if (t < 0 || (a.stride == 2 && (t & 1))) continue;
-        iz = a.stride == 2 ? (t >> 1) : t;
+        if (t < 0 || (s2 && (t & 1))) continue;
+        iz = s2 ? (t >> 1) : t;
       }
       if ((unsigned)iz >= (unsigned)a.in.d) continue;
       for (int ky = 0; ky < a.ksize; ++ky) {
@@ -207,13 +267,17 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
         if (!a.transposed) iy = oy * a.stride + ky - pad;
         else {
           const int t = oy + pad - ky;
-          if (t < 0 || (a.stride == 2 && (t & 1))) continue;
-          iy = a.stride == 2 ? (t >> 1) : t;
+          if (t < 0 || (s2 && (t & 1))) continue;
+          iy = s2 ? (t >> 1) : t;
         }
         if ((unsigned)iy >= (unsigned)a.in.h) continue;
-        const float* row = inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh;
+        const char* row = inb + ((long long)iz * a.in.sd + (long long)iy * a.in.sh) * 4;
         for (int kx = 0; kx < a.ksize; ++kx) {
-          if (s2t && ((px + pad - kx) & 1)) continue;
+          // input x of voxel i of this wave's row: ix = xa*i + xb (wave-uniform xa, xb)
+          int xa, xb;
+          if (!a.transposed) { xa = a.stride; xb = kx - pad; }
+          else if (s2) { if ((px + pad - kx) & 1) continue; xa = 1; xb = (px + pad - kx) >> 1; }
+          else { xa = 1; xb = pad - kx; }
           const float* wt = wl + (((kz * a.ksize + ky) * a.ksize + kx) * a.K + k0) * 4;
           float w[4][4];
 #pragma unroll
@@ -221,80 +285,141 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
             const float4 t4 = *reinterpret_cast<const float4*>(wt + 4 * j);
             w[j][0] = t4.x; w[j][1] = t4.y; w[j][2] = t4.z; w[j][3] = t4.w;
           }
+          const int ilast = ibase + 63;
+          const bool fast = px + xstep * ilast < a.out.w && xa * ibase + xb >= 0 && xa * ilast + xb < a.in.w;
+          if (fast) {
+            unsigned boff = (unsigned)(xa * (ibase + g) + xb) * sw4 + (unsigned)k0 * 4u;
+            const unsigned bstep = (unsigned)(xa * VW) * sw4;
 #pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            const int ox = px + xstep * (chunk * 64 + p * VW + g);
-            int ix;
-            if (!a.transposed) ix = ox * a.stride + kx - pad;
-            else { const int t = ox + pad - kx; ix = a.stride == 2 ? (t >> 1) : t; }
-            const bool ok = ox < a.out.w && (unsigned)ix < (unsigned)a.in.w;
-            const float4 x4 = *reinterpret_cast<const float4*>(row + (long long)(ok ? ix : 0) * a.in.sw);
-            float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+            for (int p = 0; p < NP; ++p) {
+              const float4 x4 = *reinterpret_cast<const float4*>(row + boff);
+              boff += bstep;
+              const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float xv = HAS_T ? nl_apply(xs[j], sc[j], sh[j], a.tin.relu) : xs[j];
-              xv = ok ? xv : 0.f;
+              for (int j = 0; j < 4; ++j) {
+                const float xv = HAS_T ? nl_apply(xs[j], sc[j], sh[j], a.tin.relu) : xs[j];
 #pragma unroll
-              for (int c = 0; c < NO; ++c) acc[p * NO + c] = fmaf(xv, w[j][c], acc[p * NO + c]);
+                for (int c = 0; c < NO; ++c) acc[p * NO + c] = fmaf(xv, w[j][c], acc[p * NO + c]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              const int i = ibase + p * VW + g;
+              const int ix = xa * i + xb;
+              const bool ok = px + xstep * i < a.out.w && (unsigned)ix < (unsigned)a.in.w;
+              const float4 x4 = *reinterpret_cast<const float4*>(row + (unsigned)(ok ? ix : 0) * sw4 + (unsigned)k0 * 4u);
+              const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float xv = HAS_T ? nl_apply(xs[j], sc[j], sh[j], a.tin.relu) : xs[j];
+                xv = ok ? xv : 0.f;
+#pragma unroll
+                for (int c = 0; c < NO; ++c) acc[p * NO + c] = fmaf(xv, w[j][c], acc[p * NO + c]);
+              }
             }
           }
         }
       }
     }
-  }
-  // ---- halving exchange inside each KL-lane group: lane kl ends with pass kl's NO sums
+    // ---- halving exchange inside each KL-lane group: lane kl ends with pass kl's NO sums
 #pragma unroll
-  for (int m = KL / 2, h = NP * NO / 2; m >= 1; m >>= 1, h >>= 1) {
-    const bool hi = (kl & m) != 0;
+    for (int m = KL / 2, h = NP * NO / 2; m >= 1; m >>= 1, h >>= 1) {
+      const bool hi = (kl & m) != 0;
 #pragma unroll
-    for (int i = 0; i < NP * NO / 2; ++i) {
-      if (i < h) {
-        const float send = hi ? acc[i] : acc[i + h];
-        const float keep = hi ? acc[i + h] : acc[i];
-        acc[i] = keep + __shfl_xor(send, m, 64);
+      for (int i = 0; i < NP * NO / 2; ++i) {
+        if (i < h) {
+          const float send = hi ? acc[i] : acc[i + h];
+          const float keep = hi ? acc[i + h] : acc[i];
+          acc[i] = keep + __shfl_xor(send, m, 64);
+        }
       }
     }
+    // ---- this lane owns voxel (ibase + kl*VW + g) of the wave's row
+    const int ox = px + xstep * (ibase + kl * VW + g);
+    if (ox < a.out.w) direct_epilogue<NO>(a, n, oz, oy, ox, acc, ssum, ssq);
   }
-  // ---- epilogue: this lane owns voxel (chunk*64 + kl*VW + g) of the wave's row
-  const int ox = px + xstep * (chunk * 64 + kl * VW + g);
-  const bool active = wave_on && ox < a.out.w;
+  direct_stats<NO>(a, n, ssum, ssq, red);
+}
+
+// ------------------------------------------------------------------ thread per voxel, K <= 4, stride 1
+// The full-resolution R->R convolutions of the top ResidualUnit (forward and input gradient): a voxel's K
+// channels are ONE 16-byte load (channel rows are padded to 4 floats), weights are wave-uniform and come
+// through the scalar cache (constant address space: s_load, SGPR operands of the FMAs), the z / y borders are
+// skipped per wave (a wave is 64 consecutive x of one row), the x border is resolved once per voxel by keeping
+// one partial sum per kx and dropping the invalid ones at the end.
+typedef const __attribute__((address_space(4))) float cfloat;
+
+template <int KI, int NO, bool HAS_T>
+__global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
+  __shared__ float red[32];
+  cfloat* wc = (cfloat*)a.w;             // [T][KI][4]
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float sc[KI], sh[KI];
+#pragma unroll
+  for (int k = 0; k < KI; ++k) { sc[k] = 1.f; sh[k] = 0.f; if (HAS_T) nl_coeff(a.tin, n, KI, k, sc[k], sh[k]); }
+  const int ks = a.ksize, pad = (ks - 1) / 2;
+  const int chunks = (a.out.w + 63) / 64;
+  const long long units = (long long)a.out.d * a.out.h * chunks;
+  const int sw4 = a.in.sw * 4;
   float ssum[NO], ssq[NO];
 #pragma unroll
   for (int c = 0; c < NO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
-  if (active) {
-    float* op = a.out.p + (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh +
-                (long long)ox * a.out.sw;
-    const float* ap = a.add ? a.add + (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash +
-                                  (long long)ox * a.asw : nullptr;
+  long long ufirst, ulast;
+  unit_range(units, xcd_contiguous_id(blockIdx.x, gridDim.x), gridDim.x, ufirst, ulast);
+  for (long long u0 = ufirst + wave; u0 < ulast; u0 += 4) {
+    long long u = u0;
+    const int chunk = (int)(u % chunks); u /= chunks;
+    const int oy = (int)(u % a.out.h);
+    const int oz = (int)(u / a.out.h);
+    const int ox = chunk * 64 + lane;
+    // byte offsets of the three x neighbours inside a row, clamped into the row (invalid ones are dropped below)
+    unsigned boff[3];
+    bool okx[3];
 #pragma unroll
-    for (int c = 0; c < NO; ++c) {
-      float val = acc[c] + (a.bias ? a.bias[c] : 0.f);
-      if (ap) {
-        float s1, h1;
-        nl_coeff(a.tadd, n, a.N, c, s1, h1);
-        val += nl_apply(ap[c], s1, h1, a.tadd.relu);
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ks == 1 ? ox : (a.transposed ? ox + pad - kx : ox + kx - pad);
+      okx[kx] = (unsigned)ix < (unsigned)a.in.w && ox < a.out.w && kx < ks;
+      boff[kx] = (unsigned)(min(max(ix, 0), a.in.w - 1) * sw4);
+    }
+    float acc[3][NO];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int c = 0; c < NO; ++c) acc[kx][c] = 0.f;
+    const char* inb = reinterpret_cast<const char*>(a.in.p + (long long)n * a.in.sn);
+    for (int kz = 0; kz < ks; ++kz) {
+      const int iz = a.transposed ? oz + pad - kz : oz + kz - pad;
+      if ((unsigned)iz >= (unsigned)a.in.d) continue;
+      for (int ky = 0; ky < ks; ++ky) {
+        const int iy = a.transposed ? oy + pad - ky : oy + ky - pad;
+        if ((unsigned)iy >= (unsigned)a.in.h) continue;
+        const char* row = inb + ((long long)iz * a.in.sd + (long long)iy * a.in.sh) * 4;
+        cfloat* wt = wc + ((kz * ks + ky) * ks) * KI * 4;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          if (kx < ks) {
+            const float4 x4 = *reinterpret_cast<const float4*>(row + boff[kx]);
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int k = 0; k < KI; ++k) {
+              const float xv = HAS_T ? nl_apply(xs[k], sc[k], sh[k], a.tin.relu) : xs[k];
+#pragma unroll
+              for (int c = 0; c < NO; ++c) acc[kx][c] = fmaf(xv, wt[(kx * KI + k) * 4 + c], acc[kx][c]);
+            }
+          }
+        }
       }
-      if (a.accumulate) val += op[c];
-      op[c] = val;
-      ssum[c] = val; ssq[c] = val * val;
     }
-  }
-  if (a.stats != nullptr) {
+    float val[NO];
 #pragma unroll
-    for (int c = 0; c < NO; ++c) {
-      const float s = wave_sum(ssum[c]), q = wave_sum(ssq[c]);
-      if (lane == 0) { red[(0 * 4 + wave) * 4 + c] = s; red[(1 * 4 + wave) * 4 + c] = q; }
-    }
-    __syncthreads();
-    if (threadIdx.x < NO) {
-      const int c = threadIdx.x;
-      const float s = red[0 * 4 + c] + red[1 * 4 + c] + red[2 * 4 + c] + red[3 * 4 + c];
-      const float q = red[16 + 0 * 4 + c] + red[16 + 1 * 4 + c] + red[16 + 2 * 4 + c] + red[16 + 3 * 4 + c];
-      const long long rrow = (long long)n * a.blocks_per_n + blockIdx.x;
-      a.stats[(rrow * 2 + 0) * a.N + c] = s;
-      a.stats[(rrow * 2 + 1) * a.N + c] = q;
-    }
+    for (int c = 0; c < NO; ++c)
+      val[c] = (okx[0] ? acc[0][c] : 0.f) + (okx[1] ? acc[1][c] : 0.f) + (okx[2] ? acc[2][c] : 0.f);
+    if (ox < a.out.w) direct_epilogue<NO>(a, n, oz, oy, ox, val, ssum, ssq);
   }
+  direct_stats<NO>(a, n, ssum, ssq, red);
 }
 
 static void direct_dims(const mmtta_conv_desc* d, int& K, int& N) {
@@ -312,24 +437,38 @@ bool direct_applicable(const mmtta_conv_desc* d) {
   return N <= 4 && (size_t)T * K * 16 + (size_t)K * 8 + 128 <= 96 * 1024;
 }
 
-// lanes-along-K form: K = 32 or 64 and 16-byte addressable input
-static bool klane_ok(const mmtta_conv_desc* d, const mmtta_tensor* x) {
-  int K, N;
-  direct_dims(d, K, N);
-  return (K == 32 || K == 64) && x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0 &&
-         ((uintptr_t)x->ptr) % 16 == 0;
+static bool aligned16(const mmtta_tensor* x) {
+  return x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0 && ((uintptr_t)x->ptr) % 16 == 0;
 }
 
+// 0: thread per voxel (any shape); 1: lanes along K (K = 32 or 64); 2: row kernel (K <= 4, stride 1)
+static int direct_variant(const mmtta_conv_desc* d, const mmtta_tensor* x) {
+  int K, N;
+  direct_dims(d, K, N);
+  if (!aligned16(x) || (long long)x->w * x->sw * 4 >= (1LL << 31)) return 0;
+  if (K == 32 || K == 64) return 1;
+  if (K <= 4 && d->stride == 1) return 2;
+  return 0;
+}
+
+static long long direct_units(const mmtta_conv_desc* d, int variant, const mmtta_tensor* y) {
+  const bool s2t = (d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONV_DGRAD) && d->stride == 2;
+  const int xstep = (variant == 1 && s2t) ? 2 : 1;
+  const int rowlen = (y->w + xstep - 1) / xstep;
+  return (long long)y->d * y->h * xstep * ((rowlen + 63) / 64);
+}
+
+// workgroups per batch item = statistics rows per batch item
 int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y) {
-  if (klane_ok(d, x)) {
-    const bool s2t = (d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONV_DGRAD) && d->stride == 2;
-    const int xstep = s2t ? 2 : 1;
-    const int rowlen = (y->w + xstep - 1) / xstep;
-    const long long units = (long long)y->d * y->h * xstep * ((rowlen + 63) / 64);
-    return (int)((units + 3) / 4);
+  const int v = direct_variant(d, x);
+  if (v == 0) {
+    const long long dhw = (long long)y->d * y->h * y->w;
+    return (int)((dhw + 255) / 256);
   }
-  const long long dhw = (long long)y->d * y->h * y->w;
-  return (int)((dhw + 255) / 256);
+  // grid-stride kernels: enough workgroups to fill the chip a few times over, never more than the work
+  const long long want = (direct_units(d, v, y) + 3) / 4;
+  const long long cap = v == 1 ? 1024 : 2048;
+  return (int)(want < cap ? want : cap);
 }
 
 template <int KL, bool HAS_T>
@@ -340,6 +479,27 @@ static void launch_klane(const DArgs& a, int n, size_t lds, hipStream_t stream) 
     case 2: hipLaunchKernelGGL((direct_klane_kernel<KL, 2, HAS_T>), grid, block, lds, stream, a); break;
     case 3: hipLaunchKernelGGL((direct_klane_kernel<KL, 3, HAS_T>), grid, block, lds, stream, a); break;
     default: hipLaunchKernelGGL((direct_klane_kernel<KL, 4, HAS_T>), grid, block, lds, stream, a); break;
+  }
+}
+
+template <int KI, bool HAS_T>
+static void launch_row_n(const DArgs& a, int n, hipStream_t stream) {
+  const dim3 grid(a.blocks_per_n, n), block(256);
+  switch (a.N) {
+    case 1: hipLaunchKernelGGL((direct_row_kernel<KI, 1, HAS_T>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((direct_row_kernel<KI, 2, HAS_T>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((direct_row_kernel<KI, 3, HAS_T>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((direct_row_kernel<KI, 4, HAS_T>), grid, block, 0, stream, a); break;
+  }
+}
+
+template <bool HAS_T>
+static void launch_row(const DArgs& a, int n, hipStream_t stream) {
+  switch (a.K) {
+    case 1: launch_row_n<1, HAS_T>(a, n, stream); break;
+    case 2: launch_row_n<2, HAS_T>(a, n, stream); break;
+    case 3: launch_row_n<3, HAS_T>(a, n, stream); break;
+    default: launch_row_n<4, HAS_T>(a, n, stream); break;
   }
 }
 
@@ -360,6 +520,8 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   a.K = x->c; a.N = y->c; a.ksize = d->ksize; a.stride = d->stride;
   a.transposed = (d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONV_DGRAD) ? 1 : 0;
   a.accumulate = accumulate;
+  a.out_vec4 = (y->flags & MMTTA_TENSOR_OWNS_PAD) && y->sw == 4 && y->sc == 1 && y->sh % 4 == 0 && y->sd % 4 == 0 &&
+               y->sn % 4 == 0 && ((uintptr_t)y->ptr) % 16 == 0;
   a.stats = stats; a.blocks_per_n = direct_blocks_per_n(d, x, y);
   const int T = d->ksize * d->ksize * d->ksize;
   const size_t lds = (size_t)T * a.K * 16 + (size_t)a.K * 8 + 32 * sizeof(float);
@@ -372,11 +534,16 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
     attr_set = true;
   }
   const bool has_t = a.tin.mean != nullptr || a.tin.scale != nullptr;
-  if (klane_ok(d, x)) {
+  const int variant = direct_variant(d, x);
+  if (variant == 1) {
     const size_t kl_lds = (size_t)T * a.K * 16 + 32 * sizeof(float);
     if (a.K == 64) { if (has_t) launch_klane<16, true>(a, y->n, kl_lds, stream); else launch_klane<16, false>(a, y->n, kl_lds, stream); }
     else { if (has_t) launch_klane<8, true>(a, y->n, kl_lds, stream); else launch_klane<8, false>(a, y->n, kl_lds, stream); }
     return launch_status("direct conv (lanes along K)");
+  }
+  if (variant == 2) {
+    if (has_t) launch_row<true>(a, y->n, stream); else launch_row<false>(a, y->n, stream);
+    return launch_status("direct conv (row)");
   }
   if (has_t) hipLaunchKernelGGL(direct_conv_kernel<true>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL(direct_conv_kernel<false>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);

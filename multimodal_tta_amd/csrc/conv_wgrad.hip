@@ -600,7 +600,147 @@ __global__ void wgrad_small_reduce_kernel(const float* __restrict__ slab, float*
 }
 
 
+// ------------------------------------------------------------------ tiny x tiny weight gradient (VALU)
+// Conv3d k3 s1 with <= 4 channels on BOTH sides (the full-resolution R->R unit of the top ResidualUnit): 1 GFLOP
+// over 2 M voxels.  On the matrix cores the 3 dense columns would be padded to 32; here a thread owns a voxel,
+// keeps the 9 (ky,kx) x CS x CB products of one kz plane in registers and walks rows (a wave = 64 consecutive x
+// of one row; blockIdx.y = kz).  x is read as one 16-byte voxel per neighbour (clamped address, the invalid x
+// neighbours are dropped by zeroing dy for that kx), norm+ReLU applied on load.  Lanes are combined once at the
+// end; workgroup partials land in dw's own layout so the generic row-sum reduce finishes the job.
+struct WTArgs {
+  TV x; NL tx;
+  TV dy;
+  float* part;      // [blocks][ld]: dw layout [cb][cs][27]
+  float* dbpart;    // [blocks][4] or null
+  int ld;
+};
+
+template <int CS, int CB, bool HAS_T>
+__global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
+  __shared__ float red[4][9 * CS * CB + CB];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kz = blockIdx.y;
+  const int chunks = (a.dy.w + 63) / 64;
+  const long long units = (long long)a.dy.n * a.dy.d * a.dy.h * chunks;
+  const int xsw4 = (int)a.x.sw * 4, dsw4 = (int)a.dy.sw * 4;
+  float acc[9][CS][CB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < CS; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[t][i][j] = 0.f;
+  float dbs[CB];
+#pragma unroll
+  for (int j = 0; j < CB; ++j) dbs[j] = 0.f;
+  int n_cached = -1;
+  float sc[CS], sh[CS];
+#pragma unroll
+  for (int i = 0; i < CS; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+  long long ufirst, ulast;
+  unit_range(units, xcd_contiguous_id(blockIdx.x, gridDim.x), gridDim.x, ufirst, ulast);
+  for (long long u0 = ufirst + wave; u0 < ulast; u0 += 4) {
+    long long u = u0;
+    const int chunk = (int)(u % chunks); u /= chunks;
+    const int oy = (int)(u % a.dy.h); u /= a.dy.h;
+    const int oz = (int)(u % a.dy.d);
+    const int n = (int)(u / a.dy.d);
+    const int iz = oz + kz - 1;
+    if ((unsigned)iz >= (unsigned)a.x.d) continue;
+    if (HAS_T && n != n_cached) {
+#pragma unroll
+      for (int i = 0; i < CS; ++i) nl_coeff(a.tx, n, CS, i, sc[i], sh[i]);
+      n_cached = n;
+    }
+    const int ox = chunk * 64 + lane;
+    const bool on = ox < a.dy.w;
+    const char* dyrow = reinterpret_cast<const char*>(a.dy.p + (long long)n * a.dy.sn + (long long)oz * a.dy.sd + (long long)oy * a.dy.sh);
+    const float4 g4 = *reinterpret_cast<const float4*>(dyrow + (unsigned)(min(ox, a.dy.w - 1) * dsw4));
+    const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
+    float g[3][CB];     // dy of this voxel as seen by the three kx (zero where the x neighbour does not exist)
+    unsigned boff[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox + kx - 1;
+      const bool ok = on && (unsigned)ix < (unsigned)a.x.w;
+      boff[kx] = (unsigned)(min(max(ix, 0), a.x.w - 1) * xsw4);
+#pragma unroll
+      for (int j = 0; j < CB; ++j) g[kx][j] = ok ? gs[j] : 0.f;
+    }
+    if (kz == 1) {
+#pragma unroll
+      for (int j = 0; j < CB; ++j) dbs[j] += on ? gs[j] : 0.f;
+    }
+    const char* xb = reinterpret_cast<const char*>(a.x.p + (long long)n * a.x.sn + (long long)iz * a.x.sd);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy + ky - 1;
+      if ((unsigned)iy >= (unsigned)a.x.h) continue;
+      const char* xrow = xb + (long long)iy * a.x.sh * 4;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4 x4 = *reinterpret_cast<const float4*>(xrow + boff[kx]);
+        const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+        for (int i = 0; i < CS; ++i) {
+          const float xv = HAS_T ? nl_apply(xs[i], sc[i], sh[i], a.tx.relu) : xs[i];
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[ky * 3 + kx][i][j] = fmaf(xv, g[kx][j], acc[ky * 3 + kx][i][j]);
+        }
+      }
+    }
+  }
+  // lanes -> wave -> workgroup
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < CS; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        const float v = wave_sum(acc[t][i][j]);
+        if (lane == 0) red[wave][(t * CS + i) * CB + j] = v;
+      }
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const float v = wave_sum(dbs[j]);
+    if (lane == 0) red[wave][9 * CS * CB + j] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 9 * CS * CB + CB; e += 256) {
+    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (e < 9 * CS * CB) {
+      const int j = e % CB, i = (e / CB) % CS, t = e / (CB * CS);
+      a.part[(long long)blockIdx.x * a.ld + (j * CS + i) * 27 + kz * 9 + t] = v;
+    } else if (kz == 1 && a.dbpart != nullptr) {
+      a.dbpart[(long long)blockIdx.x * 4 + (e - 9 * CS * CB)] = v;
+    }
+  }
+}
+
+template <int CS, bool HAS_T>
+static void launch_tiny_cb(const WTArgs& a, int cb, int blocks, hipStream_t s) {
+  const dim3 grid(blocks, 3), block(256);
+  switch (cb) {
+    case 1: hipLaunchKernelGGL((wgrad_tiny_kernel<CS, 1, HAS_T>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((wgrad_tiny_kernel<CS, 2, HAS_T>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((wgrad_tiny_kernel<CS, 3, HAS_T>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((wgrad_tiny_kernel<CS, 4, HAS_T>), grid, block, 0, s, a); break;
+  }
+}
+
+template <bool HAS_T>
+static void launch_tiny(const WTArgs& a, int cs, int cb, int blocks, hipStream_t s) {
+  switch (cs) {
+    case 1: launch_tiny_cb<1, HAS_T>(a, cb, blocks, s); break;
+    case 2: launch_tiny_cb<2, HAS_T>(a, cb, blocks, s); break;
+    case 3: launch_tiny_cb<3, HAS_T>(a, cb, blocks, s); break;
+    default: launch_tiny_cb<4, HAS_T>(a, cb, blocks, s); break;
+  }
+}
+
 struct WGeo {
+  bool tiny; int tiny_blocks;
   bool bf16; bool small; int small_is_cd; const mmtta_tensor *q, *pb; bool q_is_x;
   const mmtta_tensor *g, *dn;
   int si, ntaps, TZ, TY, TX;
@@ -631,6 +771,24 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     const int want = w.convt ? gd[i] / 2 : (d->stride == 1 ? gd[i] : (gd[i] + 1) / 2);
     MMTTA_CHECK(dd[i] == want && (!w.convt || gd[i] % 2 == 0), MMTTA_ERR_INVALID,
                 "wgrad: spatial mismatch on axis %d (fine %d, coarse %d)", i, gd[i], dd[i]);
+  }
+  // both sides <= 4 channels, k3 s1, 16-byte voxel rows: VALU kernel, partials in dw layout
+  auto al16 = [](const mmtta_tensor* t) {
+    return ((uintptr_t)t->ptr) % 16 == 0 && t->sc == 1 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 &&
+           (long long)t->w * t->sw * 4 < (1LL << 31);
+  };
+  w.tiny = !w.convt && d->cin <= 4 && d->cout <= 4 && d->ksize == 3 && d->stride == 1 && al16(x) && al16(dy);
+  if (w.tiny) {
+    const long long units = (long long)dy->n * dy->d * dy->h * ((dy->w + 63) / 64);
+    long long blocks = (units + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    w.tiny_blocks = (int)blocks;
+    w.small = false; w.bf16 = false; w.small_is_cd = 0; w.q = w.pb = nullptr; w.q_is_x = false;
+    w.TZ = w.TY = w.TX = 0; w.tz = w.ty = w.tx = w.tiles = w.S = w.tps = w.nsl = 0; w.CGp = w.CDp = 0;
+    w.slab_floats = (int64_t)blocks * (27 * d->cin * d->cout);
+    w.db_floats = (int64_t)blocks * 4;
+    w.pre_floats = 0; w.pre_chunks = 0; w.colsum_blocks = 0;
+    return MMTTA_OK;
   }
   // small-channel path: which tensor is the small gathered one (Q) and which the dense one (P)
   w.small = false; w.bf16 = false; w.small_is_cd = 0; w.q = w.pb = nullptr; w.q_is_x = false;
@@ -719,6 +877,7 @@ extern "C" int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* d, const mmtta_ten
   WGeo w;
   const int st = wgeometry(d, x, dy, w);
   if (st) return st < 0 ? st : -st;
+  if (w.tiny) return 6;
   if (w.small) return 3;
   if (w.bf16) return w.si == 1 ? 4 : 5;
   if (w.ntaps == 1) return 2;
@@ -736,6 +895,20 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   MMTTA_CHECK(workspace != nullptr && workspace_bytes >= need, MMTTA_ERR_WORKSPACE, "wgrad: workspace %lld bytes, need %lld",
               (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
+  if (w.tiny) {
+    WTArgs t;
+    t.x = tv(x); t.tx = nl(x_norm); t.dy = tv(dy);
+    t.part = (float*)workspace; t.ld = 27 * d->cin * d->cout;
+    t.dbpart = db != nullptr ? (float*)workspace + w.slab_floats : nullptr;
+    if (t.tx.mean != nullptr || t.tx.scale != nullptr) launch_tiny<true>(t, d->cin, d->cout, w.tiny_blocks, s);
+    else launch_tiny<false>(t, d->cin, d->cout, w.tiny_blocks, s);
+    st = launch_status("wgrad tiny");
+    if (st) return st;
+    hipLaunchKernelGGL(db_reduce_kernel, dim3(t.ld), dim3(64), 0, s, t.part, dw, w.tiny_blocks, t.ld, t.ld, accumulate);
+    if (db != nullptr)
+      hipLaunchKernelGGL(db_reduce_kernel, dim3(d->cout), dim3(64), 0, s, t.dbpart, db, w.tiny_blocks, d->cout, 4, accumulate);
+    return launch_status("wgrad tiny reduce");
+  }
   if (w.small) {
     W2Args b;
     b.q = (const float*)w.q->ptr; b.qsn = w.q->sn; b.qsd = w.q->sd; b.qsh = w.q->sh; b.qsw = w.q->sw;

@@ -117,6 +117,8 @@ class Pool:
         self._b: Dict[Tuple, torch.Tensor] = {}
 
     def cl(self, key, n, d, h, w, c, ldc=None, zero=False) -> torch.Tensor:
+        if ldc is None:
+            ldc = (c + 3) // 4 * 4       # 16-byte voxel rows: one aligned vector access per 4 channels, for any C
         k = ("cl", key, n, d, h, w, c, ldc)
         t = self._b.get(k)
         if t is None:

@@ -75,7 +75,11 @@ def new_cl(n: int, d: int, h: int, w: int, c: int, device, ldc: Optional[int] = 
     """Allocate a channels-last buffer [n,d,h,w,ldc] and return the [.., :c] view."""
     ldc = c if ldc is None else ldc
     buf = (torch.zeros if zero else torch.empty)((n, d, h, w, ldc), dtype=torch.float32, device=device)
-    return buf[..., :c] if ldc != c else buf
+    if ldc == c:
+        return buf
+    view = buf[..., :c]
+    view._mmtta_owns_pad = True     # this view owns the pad lanes of its rows (any further slice does not)
+    return view
 
 
 def to_cl(x: torch.Tensor, out: Optional[torch.Tensor] = None, ldc: Optional[int] = None) -> torch.Tensor:
@@ -111,7 +115,7 @@ IGEMM_KERNELS = ["igemm_f32_kernel<1,4,8,8,8,8>", "igemm_f32_kernel<2,4,4,8,8,16
 
 
 WGRAD_KERNELS = ["wgrad_f32_kernel<4,4,8,7>", "wgrad_f32_kernel<2,2,8,7>", "wgrad_f32_kernel<4,4,8,1>", "wgrad_small_kernel",
-                 "wgrad_bf16_kernel<4,4,1>", "wgrad_bf16_kernel<2,4,2>"]
+                 "wgrad_bf16_kernel<4,4,1>", "wgrad_bf16_kernel<2,4,2>", "wgrad_tiny_kernel"]
 
 
 class KernelProfiler:
@@ -130,15 +134,26 @@ class KernelProfiler:
         e.record()
         return e
 
-    def end(self, name: str, launches: int, flops: float, e0) -> None:
+    def end(self, name: str, launches: int, flops: float, e0, detail: str = "") -> None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((name, launches, flops, e0, e1))
+        self.records.append((name, launches, flops, e0, e1, detail))
+
+    def by_layer(self):
+        """Per (kernel, layer shape) totals: scripts/layer_times.py prints them."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, launches, flops, e0, e1, detail in self.records:
+            d = out.setdefault((name, detail), {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += launches
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, launches, flops, e0, e1 in self.records:
+        for name, launches, flops, e0, e1, _detail in self.records:
             d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "calls": 0})
             d["launches"] += launches
             d["flops"] += flops
@@ -232,7 +247,12 @@ class ConvOp:
             for _ in range(PROFILER.reps):
                 launch()
             PROFILER.end(IGEMM_KERNELS[p.config] + ("+splitk" if p.ksplit > 1 else ""), int(p.launches) * PROFILER.reps,
-                         self.flops(x, y, desc) * PROFILER.reps, e0)
+                         self.flops(x, y, desc) * PROFILER.reps, e0, self._detail(desc.op, x))
+
+    def _detail(self, op: int, x: torch.Tensor) -> str:
+        kind = {CONV_FWD: "fwd", CONV_DGRAD: "dgrad", CONVT_FWD: "fwdT", CONVT_DGRAD: "dgradT", -1: "wgrad"}[op]
+        return (f"{kind} {'convT' if self.transposed else 'conv'} {self.cin}->{self.cout} k{self.k}s{self.stride} "
+                f"read {x.shape[1]}x{x.shape[2]}x{x.shape[3]}")
 
     def flops(self, x: torch.Tensor, y: torch.Tensor, desc=None) -> float:
         """Algorithmic FLOPs (2 x MACs) of one forward / input-gradient / weight-gradient of this module for
@@ -267,7 +287,8 @@ class ConvOp:
             for _ in range(PROFILER.reps):
                 launch()
             kid = lib.mmtta_conv_wgrad_kernel(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy))
-            PROFILER.end(WGRAD_KERNELS[kid] + "+reduce", PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0)
+            PROFILER.end(WGRAD_KERNELS[kid] + "+reduce", PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0,
+                         self._detail(-1, x))
 
 
 class BatchedPacker:

@@ -63,6 +63,9 @@ CASES = [
     (32, 3, 1, 1, False, (1, 4, 6, 150)),
     (64, 2, 3, 1, False, (1, 5, 6, 7)),
     (3, 64, 3, 1, False, (1, 6, 6, 9)),
+    # <= 4 channels on both sides (VALU weight gradient, row kernel forward / input gradient), rows > 64 voxels
+    (4, 2, 3, 1, False, (2, 5, 6, 70)),
+    (1, 1, 3, 1, False, (1, 6, 5, 9)),
 ]
 
 
