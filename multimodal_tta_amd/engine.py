@@ -187,8 +187,9 @@ class NormLayer:
 
 
 class ConvLayer:
-    def __init__(self, op: ConvOp, weight: ParamRef, bias: Optional[ParamRef]):
-        self.op, self.weight, self.bias = op, weight, bias
+    def __init__(self, op: ConvOp, weight: ParamRef, bias: Optional[ParamRef], rt: Optional["Runtime"] = None):
+        self.op, self.weight, self.bias, self.rt = op, weight, bias, rt
+        self.side_index = 0          # which side stream takes this layer's weight gradient (Runtime.make_conv)
 
     def pack(self) -> None:
         self.op.pack(self.weight.data)
@@ -200,7 +201,22 @@ class ConvLayer:
         if not self.weight.trainable and not (self.bias is not None and self.bias.trainable):
             return
         # a frozen weight with a trainable bias still needs db; dw then lands in the (ignored) frozen grads
-        self.op.wgrad(x, x_nl, dy, self.weight.grad, self.bias.grad if self.bias is not None else None, accumulate)
+        db = self.bias.grad if self.bias is not None else None
+        side = self.rt.side_stream(self.side_index) if self.rt is not None else None
+        if side is None:
+            self.op.wgrad(x, x_nl, dy, self.weight.grad, db, accumulate)
+            return
+        # The weight gradient feeds nothing before the optimizer: it runs on a side stream, concurrently with the
+        # input-gradient / norm-backward chain of the main stream (neither kernel fills the chip on its own).
+        # Its operands (saved activations, per-block dy buffers) are never rewritten inside a step.
+        side.wait_stream(torch.cuda.current_stream())
+        ops.Workspace.slot = 1 + self.side_index % self.rt.n_side
+        try:
+            with torch.cuda.stream(side):
+                self.op.wgrad(x, x_nl, dy, self.weight.grad, db, accumulate)
+        finally:
+            ops.Workspace.slot = 0
+        self.rt.side_pending = True
 
 
 class Block:
@@ -312,6 +328,10 @@ class Runtime:
         self.conv_dtype = conv_dtype   # ops.F32: exact fp32 MFMA; ops.BF16: bf16 operands / fp32 accumulate
         self.pool = Pool(device)
         self.training = False
+        self.overlap_wgrad = True      # weight gradients on a side stream (joined before the optimizer)
+        self.n_side = 2                # layers alternate between the side streams (a layer always uses the same one)
+        self._side: List[torch.cuda.Stream] = []
+        self.side_pending = False
         self.convs: List[ConvLayer] = []
         self.refs: List[ParamRef] = []
         self.buffers: List[torch.nn.Module] = []     # modules owning running statistics (BatchNorm)
@@ -331,9 +351,24 @@ class Runtime:
         op = ConvOp(cin, cout, k, s, transposed, self.device, dtype=self.conv_dtype)
         w = self.make_ref(name + ".weight", module.weight)
         b = self.make_ref(name + ".bias", module.bias) if module.bias is not None else None
-        layer = ConvLayer(op, w, b)
+        layer = ConvLayer(op, w, b, self)
+        layer.side_index = len(self.convs)
         self.convs.append(layer)
         return layer
+
+    def side_stream(self, index: int = 0) -> Optional[torch.cuda.Stream]:
+        if not self.overlap_wgrad or ops.PROFILER is not None:
+            return None
+        while len(self._side) < self.n_side:
+            self._side.append(torch.cuda.Stream(device=self.device))
+        return self._side[index % self.n_side]
+
+    def join_side(self) -> None:
+        """Main stream waits for the side streams' weight gradients (call before anything reads .grad)."""
+        if self.side_pending:
+            for s in self._side:
+                torch.cuda.current_stream().wait_stream(s)
+        self.side_pending = False
 
     def assign_groups(self, trainable: Optional[set], no_decay_keys: Sequence[str], treat_1d: bool) -> None:
         """decay / no-decay split of reference src/core/experiment_manager.py:214-228; parameters whose
@@ -395,6 +430,7 @@ class Runtime:
 
     def run_backward(self, dlogits_cl: torch.Tensor) -> None:
         self.backward_cl(dlogits_cl)
+        self.join_side()
 
 
 # ----------------------------------------------------------------------------- container -> block builders

@@ -32,18 +32,24 @@ class Workspace:
     """One grow-only scratch buffer per device, shared by split-K convs and weight gradients
     (stream ordered).  It must reach its final size before a graph capture starts."""
 
-    _buffers: Dict[int, torch.Tensor] = {}
+    _buffers: Dict[Tuple[int, int], torch.Tensor] = {}
     frozen = False
+    slot = 0        # 0: main launch sequence; 1: the side stream of the weight gradients (engine.ConvLayer.wgrad)
 
     @classmethod
     def get(cls, nbytes: int, device: torch.device) -> torch.Tensor:
+        """The scratch buffer of the current slot: kernels of the two streams run concurrently and must not share
+        scratch."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        buf = cls._buffers.get(idx)
+        key = (idx, cls.slot)
+        buf = cls._buffers.get(key)
         if buf is None or buf.numel() < nbytes:
             if cls.frozen:
                 raise MmttaError("workspace would have to grow during graph capture; run one eager warm-up step first")
+            if buf is not None:
+                torch.cuda.synchronize(device)     # kernels of any stream may still be reading the old buffer
             buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-            cls._buffers[idx] = buf
+            cls._buffers[key] = buf
         return buf
 
 

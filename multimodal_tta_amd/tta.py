@@ -137,7 +137,7 @@ class EntropyMinimizationTTA:
         loss = rt.pool.flat("ent_loss", 1)
         ops.entropy_loss(logits, dlogits, partial, loss, softmax=self.softmax)
         if ar.n_train > 0:
-            rt.backward_cl(dlogits)
+            rt.run_backward(dlogits)
             ops.adam_step(ar.params[:ar.n_train], ar.grads[:ar.n_train], ar.exp_avg[:ar.n_train],
                           ar.exp_avg_sq[:ar.n_train], ar.n_decay, self.lr, self.beta1, self.beta2, self.eps,
                           self.weight_decay, ar.step)
