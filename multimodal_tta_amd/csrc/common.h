@@ -78,6 +78,44 @@ __device__ __forceinline__ void nl_coeff(const NL& t, int n, int C, int c, float
   sh = b - mu * sc;
 }
 
+// J consecutive channels c0 .. c0+J-1 (channels >= C get 0, 0).  All loads are issued straight-line from clamped
+// indices under wave-uniform branches only: a load inside a per-channel branch gets its own s_waitcnt and the J
+// round trips serialise (measured: 8 channels = ~16 exposed L2 latencies per staging pass).
+template <int J>
+__device__ __forceinline__ void nl_coeff_vec(const NL& t, int n, int C, int c0, float* sc, float* sh) {
+  if (t.scale != nullptr) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int i = n * C + min(c0 + j, C - 1);
+      sc[j] = t.scale[i]; sh[j] = t.shift[i];
+    }
+  } else if (t.mean == nullptr) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+  } else {
+    float mu[J], rs[J], g[J], b[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int cc = min(c0 + j, C - 1);
+      mu[j] = t.mean[n * C + cc]; rs[j] = t.rstd[n * C + cc];
+      g[j] = 1.f; b[j] = 0.f;
+    }
+    if (t.gamma != nullptr) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) g[j] = t.gamma[min(c0 + j, C - 1)];
+    }
+    if (t.beta != nullptr) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) b[j] = t.beta[min(c0 + j, C - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) { sc[j] = rs[j] * g[j]; sh[j] = b[j] - mu[j] * sc[j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+    if (c0 + j >= C) { sc[j] = 0.f; sh[j] = 0.f; }
+}
+
 __device__ __forceinline__ float nl_apply(float x, float sc, float sh, int relu) {
   float v = fmaf(x, sc, sh);
   return relu ? fmaxf(v, 0.f) : v;

@@ -225,8 +225,7 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
   const int kl = lane % KL, g = lane / KL, k0 = kl * 4;
   float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
   if (HAS_T) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) nl_coeff(a.tin, n, a.K, k0 + j, sc[j], sh[j]);
+    nl_coeff_vec<4>(a.tin, n, a.K, k0, sc, sh);
   }
   const int pad = (a.ksize - 1) / 2;
   const bool s2 = a.stride == 2;
@@ -359,7 +358,8 @@ __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float sc[KI], sh[KI];
 #pragma unroll
-  for (int k = 0; k < KI; ++k) { sc[k] = 1.f; sh[k] = 0.f; if (HAS_T) nl_coeff(a.tin, n, KI, k, sc[k], sh[k]); }
+  for (int k = 0; k < KI; ++k) { sc[k] = 1.f; sh[k] = 0.f; }
+  if (HAS_T) nl_coeff_vec<KI>(a.tin, n, KI, 0, sc, sh);
   const int ks = a.ksize, pad = (ks - 1) / 2;
   const int chunks = (a.out.w + 63) / 64;
   const long long units = (long long)a.out.d * a.out.h * chunks;

@@ -149,11 +149,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
         const int cv = tid % CV8;          // 256 % CV8 == 0
         const int c = c0 + cv * 8;
         float sc[8], sh[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (c + j < a.Ci) nl_coeff(a.tin, n, a.Ci, c + j, sc[j], sh[j]);
-          else { sc[j] = 0.f; sh[j] = 0.f; }
-        }
+        nl_coeff_vec<8>(a.tin, n, a.Ci, c, sc, sh);
         // U items per trip: all their global loads are issued before the first use (one exposed latency per
         // trip instead of one per item)
         constexpr int U = 4, STEP = 256 / CV8;
@@ -199,8 +195,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
       } else {
         const int cc = tid % KCI;
         const int c = c0 + cc;
-        float sc = 0.f, sh = 0.f;
-        if (c < a.Ci) nl_coeff(a.tin, n, a.Ci, c, sc, sh);
+        float sc, sh;
+        nl_coeff_vec<1>(a.tin, n, a.Ci, c, &sc, &sh);
         for (int bv = tid / KCI; bv < boxvox; bv += 256 / KCI) {
           const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
           const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
@@ -217,11 +213,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
       const int cv = tid % CV;           // 256 % CV == 0: fixed channel group per thread
       const int c = c0 + cv * 4;
       float sc[4], sh[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (c + j < a.Ci) nl_coeff(a.tin, n, a.Ci, c + j, sc[j], sh[j]);
-        else { sc[j] = 0.f; sh[j] = 0.f; }
-      }
+      nl_coeff_vec<4>(a.tin, n, a.Ci, c, sc, sh);
       constexpr int U = 4, STEP = 256 / CV;
       for (int bv0 = tid / CV; bv0 < boxvox; bv0 += U * STEP) {
         float4 xin[U];
@@ -255,8 +247,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
     } else {
       const int cc = tid % KCI;          // 256 % KCI == 0
       const int c = c0 + cc;
-      float sc = 0.f, sh = 0.f;
-      if (c < a.Ci) nl_coeff(a.tin, n, a.Ci, c, sc, sh);
+      float sc, sh;
+      nl_coeff_vec<1>(a.tin, n, a.Ci, c, &sc, &sh);
       for (int bv = tid / KCI; bv < boxvox; bv += 256 / KCI) {
         const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
         const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
@@ -284,36 +276,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
         const int ntap = ci.ntaps;
         const int* tslab = a.slab + ci.tap0;
         const int* ttoff = a.toff + ci.tap0;
-        if (nks == KS) {
-          // A tap is only MB*KS MFMAs of 32 cycles: far less than an L2 round trip, so the weight fragments
-          // run through a ring of D taps in flight (static register indices: the tap loop is unrolled by D).
+        if (nks == KS && ntap >= 4) {
+          // A tap is only MB*KS MFMAs of 32 cycles: far less than an L2 round trip, so the weight fragments run
+          // through a ring of D taps in flight.  The body is branch-free (a load behind a branch is waited for on
+          // the spot): the tap count is padded to a multiple of D, a padded tap multiplies by a zero fragment and
+          // re-reads a valid LDS / weight address.
           constexpr int D = 4;
           uint4 ring[D][KS];
 #pragma unroll
           for (int d = 0; d < D; ++d) {
-            const uint4* wb = wcol + tslab[min(d, ntap - 1)] * slabsz8;
+            const uint4* wb = wcol + tslab[d] * slabsz8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) ring[d][ks] = wb[ks * np2];
           }
-          for (int tp0 = 0; tp0 < ntap; tp0 += D) {
+          const int ntap_pad = (ntap + D - 1) / D * D;
+          for (int tp0 = 0; tp0 < ntap_pad; tp0 += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
               const int tp = tp0 + d;
-              if (tp < ntap) {
-                bf16x8 bfrag[KS];
+              const bool live = tp < ntap;
+              bf16x8 bfrag[KS];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) bfrag[ks] = __builtin_bit_cast(bf16x8, ring[d][ks]);
-                const uint4* wb = wcol + tslab[min(tp + D, ntap - 1)] * slabsz8;
+              for (int ks = 0; ks < KS; ++ks) {
+                uint4 q = ring[d][ks];
+                q.x = live ? q.x : 0u; q.y = live ? q.y : 0u; q.z = live ? q.z : 0u; q.w = live ? q.w : 0u;
+                bfrag[ks] = __builtin_bit_cast(bf16x8, q);
+              }
+              const uint4* wb = wcol + tslab[min(tp + D, ntap - 1)] * slabsz8;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) ring[d][ks] = wb[ks * np2];
-                const int ta = ttoff[tp] * VS;
+              for (int ks = 0; ks < KS; ++ks) ring[d][ks] = wb[ks * np2];
+              const int ta = ttoff[min(tp, ntap - 1)] * VS;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
+              for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                  for (int mb = 0; mb < MB; ++mb) {
-                    const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + ks * 16);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag[ks], acc[mb], 0, 0, 0);
-                  }
+                for (int mb = 0; mb < MB; ++mb) {
+                  const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + ks * 16);
+                  acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag[ks], acc[mb], 0, 0, 0);
                 }
               }
             }

@@ -85,11 +85,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
         const int cv = tid & 7;
         const int c = cg0 + cv * 4;
         float sc[4], sh[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (c + j < a.Cg) nl_coeff(a.tg, n, a.Cg, c + j, sc[j], sh[j]);
-          else { sc[j] = 0.f; sh[j] = 0.f; }
-        }
+        nl_coeff_vec<4>(a.tg, n, a.Cg, c, sc, sh);
         constexpr int U = 4;       // 4 box voxels per trip: loads first, then transform + LDS store
         for (int bv0 = tid >> 3; bv0 < boxvox; bv0 += 32 * U) {
           float4 xin[U];
@@ -123,7 +119,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
         const int cc = tid & 31;
         const int c = cg0 + cc;
         float sc = 0.f, sh = 0.f;
-        if (c < a.Cg) nl_coeff(a.tg, n, a.Cg, c, sc, sh);
+        nl_coeff_vec<1>(a.tg, n, a.Cg, c, &sc, &sh);
         for (int bv = tid >> 5; bv < boxvox; bv += 8) {
           const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
           const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
@@ -141,7 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
       const int cc = tid & 31;
       const int c = cd0 + cc;
       float sc = 0.f, sh = 0.f;
-      if (c < a.Cd) nl_coeff(a.td, n, a.Cd, c, sc, sh);
+      nl_coeff_vec<1>(a.td, n, a.Cd, c, &sc, &sh);
       for (int v = tid >> 5; v < MT; v += 8) {
         const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
         const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
@@ -343,28 +339,46 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WArgs a) {
     const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * 8;
     const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
     {  // ---- G box: thread = (channel, box row); builds the three x-shifted 8-voxel copies
+      // Every load is issued unconditionally from a clamped (always valid) address and masked afterwards (a load
+      // inside a branch is followed by its own s_waitcnt, which serialises the round trips), RB box rows at a
+      // time: RB*NX loads in flight per thread.
       const int c = cg0 + cs;
       float sc = 0.f, sh = 0.f;
       const bool cok = c < a.Cg;
-      if (cok) nl_coeff(a.tg, n, a.Cg, c, sc, sh);
-      const float* gb = a.g + (long long)n * a.gsn + c;
-      for (int row = tid >> 5; row < G::RG; row += 8) {
-        const int bz = row / G::BYr, by = row % G::BYr;
-        const int iz = iz0 + bz, iy = iy0 + by;
-        const bool rok = cok && (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg;
-        const float* rp = gb + (long long)iz * a.gsd + (long long)iy * a.gsh;
-        float v[G::NX];
+      nl_coeff_vec<1>(a.tg, n, a.Cg, c, &sc, &sh);
+      const float* gb = a.g + (long long)n * a.gsn + min(c, a.Cg - 1);
+      constexpr int RB = SI == 1 ? 5 : 2;
+      for (int row0 = tid >> 5; row0 < G::RG; row0 += 8 * RB) {
+        float v[RB][G::NX];
 #pragma unroll
-        for (int x = 0; x < G::NX; ++x) {
-          const int ix = ix0 + x;
-          v[x] = (rok && (unsigned)ix < (unsigned)a.Wgg) ? nl_apply(rp[(long long)ix * a.gsw], sc, sh, a.tg.relu) : 0.f;
+        for (int q = 0; q < RB; ++q) {
+          const int row = min(row0 + 8 * q, G::RG - 1);
+          const int bz = row / G::BYr, by = row % G::BYr;
+          const float* rp = gb + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd +
+                            (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
+#pragma unroll
+          for (int x = 0; x < G::NX; ++x) v[q][x] = rp[(long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw];
         }
 #pragma unroll
-        for (int dxi = 0; dxi < 3; ++dxi) {
-          uint4 pk;
-          pk.x = wpack2(v[0 * SI + dxi], v[1 * SI + dxi]); pk.y = wpack2(v[2 * SI + dxi], v[3 * SI + dxi]);
-          pk.z = wpack2(v[4 * SI + dxi], v[5 * SI + dxi]); pk.w = wpack2(v[6 * SI + dxi], v[7 * SI + dxi]);
-          *reinterpret_cast<uint4*>(gl + dxi * G::COPY + cs * G::CHS_G + row * 16) = pk;
+        for (int q = 0; q < RB; ++q) {
+          const int row = row0 + 8 * q;
+          if (row < G::RG) {
+            const int bz = row / G::BYr, by = row % G::BYr;
+            const int iz = iz0 + bz, iy = iy0 + by;
+            const bool rok = cok && (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg;
+#pragma unroll
+            for (int x = 0; x < G::NX; ++x) {
+              const int ix = ix0 + x;
+              v[q][x] = (rok && (unsigned)ix < (unsigned)a.Wgg) ? nl_apply(v[q][x], sc, sh, a.tg.relu) : 0.f;
+            }
+#pragma unroll
+            for (int dxi = 0; dxi < 3; ++dxi) {
+              uint4 pk;
+              pk.x = wpack2(v[q][0 * SI + dxi], v[q][1 * SI + dxi]); pk.y = wpack2(v[q][2 * SI + dxi], v[q][3 * SI + dxi]);
+              pk.z = wpack2(v[q][4 * SI + dxi], v[q][5 * SI + dxi]); pk.w = wpack2(v[q][6 * SI + dxi], v[q][7 * SI + dxi]);
+              *reinterpret_cast<uint4*>(gl + dxi * G::COPY + cs * G::CHS_G + row * 16) = pk;
+            }
+          }
         }
       }
     }
@@ -372,21 +386,33 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WArgs a) {
       const int c = cd0 + cs;
       float sc = 0.f, sh = 0.f;
       const bool cok = c < a.Cd;
-      if (cok) nl_coeff(a.td, n, a.Cd, c, sc, sh);
-      const float* db = a.dn + (long long)n * a.dsn + c;
-      for (int xr = tid >> 5; xr < G::NXR; xr += 8) {
-        const int oz = oz0 + xr / TY, oy = oy0 + xr % TY;
-        const bool rok = cok && oz < a.Dd && oy < a.Hd;
-        const float* rp = db + (long long)oz * a.dsd + (long long)oy * a.dsh;
-        float v[8];
+      nl_coeff_vec<1>(a.td, n, a.Cd, c, &sc, &sh);
+      const float* db = a.dn + (long long)n * a.dsn + min(c, a.Cd - 1);
+      constexpr int ND = (G::NXR + 7) / 8;          // x-rows per thread: all their loads go out together
+      float v[ND][8];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          v[x] = (rok && ox0 + x < a.Wd) ? nl_apply(rp[(long long)(ox0 + x) * a.dsw], sc, sh, a.td.relu) : 0.f;
-          dbsum += v[x];
+      for (int q = 0; q < ND; ++q) {
+        const int xr = min((tid >> 5) + 8 * q, G::NXR - 1);
+        const float* rp = db + (long long)min(oz0 + xr / TY, a.Dd - 1) * a.dsd + (long long)min(oy0 + xr % TY, a.Hd - 1) * a.dsh;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) v[q][x] = rp[(long long)min(ox0 + x, a.Wd - 1) * a.dsw];
+      }
+#pragma unroll
+      for (int q = 0; q < ND; ++q) {
+        const int xr = (tid >> 5) + 8 * q;
+        if (xr < G::NXR) {
+          const int oz = oz0 + xr / TY, oy = oy0 + xr % TY;
+          const bool rok = cok && oz < a.Dd && oy < a.Hd;
+#pragma unroll
+          for (int x = 0; x < 8; ++x) {
+            v[q][x] = (rok && ox0 + x < a.Wd) ? nl_apply(v[q][x], sc, sh, a.td.relu) : 0.f;
+            dbsum += v[q][x];
+          }
+          uint4 pk;
+          pk.x = wpack2(v[q][0], v[q][1]); pk.y = wpack2(v[q][2], v[q][3]);
+          pk.z = wpack2(v[q][4], v[q][5]); pk.w = wpack2(v[q][6], v[q][7]);
+          *reinterpret_cast<uint4*>(dl + cs * G::CHS_D + xr * 16) = pk;
         }
-        uint4 pk;
-        pk.x = wpack2(v[0], v[1]); pk.y = wpack2(v[2], v[3]); pk.z = wpack2(v[4], v[5]); pk.w = wpack2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(dl + cs * G::CHS_D + xr * 16) = pk;
       }
     }
     __syncthreads();
@@ -500,11 +526,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
     {  // Q box: up to 4 channels per voxel
       const float* qb = a.q + (long long)n * a.qsn;
       float sc[4], sh[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j < a.Cs) nl_coeff(a.tq, n, a.Cs, j, sc[j], sh[j]);
-        else { sc[j] = 0.f; sh[j] = 0.f; }
-      }
+      nl_coeff_vec<4>(a.tq, n, a.Cs, 0, sc, sh);
       for (int bv = tid; bv < boxvox; bv += 256) {
         const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
         const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
@@ -527,11 +549,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
       if (a.pvec4) {
         const int cv = tid & 7, c = cb0 + cv * 4;
         float sc[4], sh[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (c + j < a.Cb) nl_coeff(a.tp, n, a.Cb, c + j, sc[j], sh[j]);
-          else { sc[j] = 0.f; sh[j] = 0.f; }
-        }
+        nl_coeff_vec<4>(a.tp, n, a.Cb, c, sc, sh);
         for (int v = tid >> 3; v < MT; v += 32) {
           const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
           const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
@@ -548,7 +566,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
       } else {
         const int cc = tid & 31, c = cb0 + cc;
         float sc = 0.f, sh = 0.f;
-        if (c < a.Cb) nl_coeff(a.tp, n, a.Cb, c, sc, sh);
+        nl_coeff_vec<1>(a.tp, n, a.Cb, c, &sc, &sh);
         for (int v = tid >> 5; v < MT; v += 8) {
           const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
           const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
@@ -649,8 +667,7 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
     const int iz = oz + kz - 1;
     if ((unsigned)iz >= (unsigned)a.x.d) continue;
     if (HAS_T && n != n_cached) {
-#pragma unroll
-      for (int i = 0; i < CS; ++i) nl_coeff(a.tx, n, CS, i, sc[i], sh[i]);
+      nl_coeff_vec<CS>(a.tx, n, CS, 0, sc, sh);
       n_cached = n;
     }
     const int ox = chunk * 64 + lane;
