@@ -341,18 +341,21 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
   direct_stats<NO>(a, n, ssum, ssq, red);
 }
 
-// ------------------------------------------------------------------ thread per voxel, K <= 4, stride 1
+// ------------------------------------------------------------------ thread per voxel, K <= 4, k3 s1
 // The full-resolution R->R convolutions of the top ResidualUnit (forward and input gradient): a voxel's K
-// channels are ONE 16-byte load (channel rows are padded to 4 floats), weights are wave-uniform and come
-// through the scalar cache (constant address space: s_load, SGPR operands of the FMAs), the z / y borders are
-// skipped per wave (a wave is 64 consecutive x of one row), the x border is resolved once per voxel by keeping
-// one partial sum per kx and dropping the invalid ones at the end.
+// channels are ONE 16-byte load (channel rows are padded to 4 floats); weights are wave-uniform and come through
+// the scalar cache (constant address space: s_load, SGPR operands of the FMAs).  A wave computes 64 consecutive x
+// of TWO adjacent output rows: the four input rows of a z-plane are loaded once for both (12 independent 16-byte
+// loads per plane, issued before any use) and every weight is fetched once per pair.  Rows away from the z / y
+// border (97 % at 128^3) take a path without any row test; the x border is resolved once per voxel by keeping one
+// partial sum per kx and dropping the invalid ones at the end.  The input gradient is the same loop with the tap
+// index mirrored (26 - tap).
 typedef const __attribute__((address_space(4))) float cfloat;
 
 template <int KI, int NO, bool HAS_T>
 __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
   __shared__ float red[32];
-  cfloat* wc = (cfloat*)a.w;             // [T][KI][4]
+  cfloat* wc = (cfloat*)a.w;             // [27][KI][4]
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -360,64 +363,90 @@ __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
 #pragma unroll
   for (int k = 0; k < KI; ++k) { sc[k] = 1.f; sh[k] = 0.f; }
   if (HAS_T) nl_coeff_vec<KI>(a.tin, n, KI, 0, sc, sh);
-  const int ks = a.ksize, pad = (ks - 1) / 2;
+  const int hp = (a.out.h + 1) / 2;
   const int chunks = (a.out.w + 63) / 64;
-  const long long units = (long long)a.out.d * a.out.h * chunks;
+  const long long units = (long long)a.out.d * hp * chunks;
   const int sw4 = a.in.sw * 4;
   float ssum[NO], ssq[NO];
 #pragma unroll
   for (int c = 0; c < NO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
   long long ufirst, ulast;
   unit_range(units, xcd_contiguous_id(blockIdx.x, gridDim.x), gridDim.x, ufirst, ulast);
+  const char* inb = reinterpret_cast<const char*>(a.in.p + (long long)n * a.in.sn);
   for (long long u0 = ufirst + wave; u0 < ulast; u0 += 4) {
     long long u = u0;
     const int chunk = (int)(u % chunks); u /= chunks;
-    const int oy = (int)(u % a.out.h);
-    const int oz = (int)(u / a.out.h);
+    const int oy0 = 2 * (int)(u % hp);
+    const int oz = (int)(u / hp);
     const int ox = chunk * 64 + lane;
     // byte offsets of the three x neighbours inside a row, clamped into the row (invalid ones are dropped below)
     unsigned boff[3];
     bool okx[3];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ks == 1 ? ox : (a.transposed ? ox + pad - kx : ox + kx - pad);
-      okx[kx] = (unsigned)ix < (unsigned)a.in.w && ox < a.out.w && kx < ks;
-      boff[kx] = (unsigned)(min(max(ix, 0), a.in.w - 1) * sw4);
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ox + dx - 1;
+      okx[dx] = (unsigned)ix < (unsigned)a.in.w && ox < a.out.w;
+      boff[dx] = (unsigned)(min(max(ix, 0), a.in.w - 1) * sw4);
     }
-    float acc[3][NO];
+    float acc[2][3][NO];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int c = 0; c < NO; ++c) acc[kx][c] = 0.f;
-    const char* inb = reinterpret_cast<const char*>(a.in.p + (long long)n * a.in.sn);
-    for (int kz = 0; kz < ks; ++kz) {
-      const int iz = a.transposed ? oz + pad - kz : oz + kz - pad;
-      if ((unsigned)iz >= (unsigned)a.in.d) continue;
-      for (int ky = 0; ky < ks; ++ky) {
-        const int iy = a.transposed ? oy + pad - ky : oy + ky - pad;
-        if ((unsigned)iy >= (unsigned)a.in.h) continue;
-        const char* row = inb + ((long long)iz * a.in.sd + (long long)iy * a.in.sh) * 4;
-        cfloat* wt = wc + ((kz * ks + ky) * ks) * KI * 4;
+      for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          if (kx < ks) {
-            const float4 x4 = *reinterpret_cast<const float4*>(row + boff[kx]);
-            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+        for (int c = 0; c < NO; ++c) acc[j][dx][c] = 0.f;
+    const bool interior = oz >= 1 && oz + 1 < a.in.d && oy0 >= 1 && oy0 + 2 < a.in.h;
 #pragma unroll
-            for (int k = 0; k < KI; ++k) {
-              const float xv = HAS_T ? nl_apply(xs[k], sc[k], sh[k], a.tin.relu) : xs[k];
+    for (int dz = 0; dz < 3; ++dz) {
+      const int iz = oz + dz - 1;
+      if (!interior && (unsigned)iz >= (unsigned)a.in.d) continue;
+      const char* plane = inb + (long long)iz * a.in.sd * 4;
+      float4 xr[4][3];
 #pragma unroll
-              for (int c = 0; c < NO; ++c) acc[kx][c] = fmaf(xv, wt[(kx * KI + k) * 4 + c], acc[kx][c]);
-            }
+      for (int r = 0; r < 4; ++r) {
+        const int iy = min(max(oy0 - 1 + r, 0), a.in.h - 1);
+        const char* row = plane + (long long)iy * a.in.sh * 4;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) xr[r][dx] = *reinterpret_cast<const float4*>(row + boff[dx]);
+      }
+      float xs[4][3][KI];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool rok = interior || (unsigned)(oy0 - 1 + r) < (unsigned)a.in.h;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float raw[4] = {xr[r][dx].x, xr[r][dx].y, xr[r][dx].z, xr[r][dx].w};
+#pragma unroll
+          for (int k = 0; k < KI; ++k) {
+            const float v = HAS_T ? nl_apply(raw[k], sc[k], sh[k], a.tin.relu) : raw[k];
+            xs[r][dx][k] = rok ? v : 0.f;
           }
         }
       }
-    }
-    float val[NO];
 #pragma unroll
-    for (int c = 0; c < NO; ++c)
-      val[c] = (okx[0] ? acc[0][c] : 0.f) + (okx[1] ? acc[1][c] : 0.f) + (okx[2] ? acc[2][c] : 0.f);
-    if (ox < a.out.w) direct_epilogue<NO>(a, n, oz, oy, ox, val, ssum, ssq);
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int t = (dz * 3 + dy) * 3 + dx;
+          cfloat* wt = wc + (a.transposed ? 26 - t : t) * KI * 4;
+#pragma unroll
+          for (int k = 0; k < KI; ++k)
+#pragma unroll
+            for (int c = 0; c < NO; ++c) {
+              const float w = wt[k * 4 + c];
+              acc[0][dx][c] = fmaf(xs[dy][dx][k], w, acc[0][dx][c]);
+              acc[1][dx][c] = fmaf(xs[dy + 1][dx][k], w, acc[1][dx][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float val[NO];
+#pragma unroll
+      for (int c = 0; c < NO; ++c)
+        val[c] = (okx[0] ? acc[j][0][c] : 0.f) + (okx[1] ? acc[j][1][c] : 0.f) + (okx[2] ? acc[j][2][c] : 0.f);
+      if (ox < a.out.w && oy0 + j < a.out.h) direct_epilogue<NO>(a, n, oz, oy0 + j, ox, val, ssum, ssq);
+    }
   }
   direct_stats<NO>(a, n, ssum, ssq, red);
 }
@@ -447,13 +476,14 @@ static int direct_variant(const mmtta_conv_desc* d, const mmtta_tensor* x) {
   direct_dims(d, K, N);
   if (!aligned16(x) || (long long)x->w * x->sw * 4 >= (1LL << 31)) return 0;
   if (K == 32 || K == 64) return 1;
-  if (K <= 4 && d->stride == 1) return 2;
+  if (K <= 4 && d->stride == 1 && d->ksize == 3) return 2;
   return 0;
 }
 
 static long long direct_units(const mmtta_conv_desc* d, int variant, const mmtta_tensor* y) {
+  if (variant == 2) return (long long)y->d * ((y->h + 1) / 2) * ((y->w + 63) / 64);     // pairs of rows
   const bool s2t = (d->op == MMTTA_CONVT_FWD || d->op == MMTTA_CONV_DGRAD) && d->stride == 2;
-  const int xstep = (variant == 1 && s2t) ? 2 : 1;
+  const int xstep = s2t ? 2 : 1;
   const int rowlen = (y->w + xstep - 1) / xstep;
   return (long long)y->d * y->h * xstep * ((rowlen + 63) / 64);
 }

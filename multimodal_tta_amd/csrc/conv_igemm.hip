@@ -89,7 +89,7 @@ __device__ __forceinline__ void row_to_local(int v, int& zl, int& yl, int& xl) {
 //              v_mfma_f32_32x32x16_bf16 with fp32 accumulation (16x the matrix rate: these layers turn
 //              HBM/LDS bound).  Storage, statistics, epilogue stay fp32 in both modes.
 template <int NB, int MB, int TZ, int TY, int TX, int KCI, bool BF>
-__global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
+__global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workgroups per CU: <= 256 registers
   extern __shared__ float lds[];
   // LDS voxel stride: fp32: KCI+1 words (odd: the 32 rows of a fragment hit distinct banks);
   // bf16: KCI+8 halfwords (16-byte slots stay aligned for ds_read_b128)
@@ -411,29 +411,53 @@ __global__ __launch_bounds__(256) void igemm_kernel(GArgs a) {
     if (a.bias) bias = a.bias[col];
     if (a.add) nl_coeff(a.tadd, n, a.Co, col, asc, ash);
   }
+  // Per 32-row block: addresses and masks of its 16 rows first, then ALL loads of the fused add / accumulate
+  // (unconditional, from clamped addresses, under wave-uniform branches), then the arithmetic and the stores: a load
+  // inside a per-element branch would be waited for on the spot, 16 exposed round trips per block.
+  const int colc = min(col, a.Co - 1);
+  const float* addb = a.add ? a.add + (long long)n * a.asn + colc : nullptr;
+  float* outb = a.out + (long long)n * a.osn + colc;
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+  for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      int zl, yl, xl;
-      row_to_local<TZ, TY, TX>((mg * MB + mb) * 32 + row, zl, yl, xl);
-      const int gz = gz0 + zl, gy = gy0 + yl, gx = gx0 + xl;
-      if (colok && gz < ci.Dg && gy < ci.Hg && gx < ci.Wg) {
+    for (int half = 0; half < 2; ++half) {       // 8 rows at a time: keeps the kernel at two waves per SIMD
+      int ooff[8], aoff[8];                      // element offsets inside batch item n (host checks < 2^31)
+      bool ok[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = half * 8 + j;
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        int zl, yl, xl;
+        row_to_local<TZ, TY, TX>((mg * MB + mb) * 32 + row, zl, yl, xl);
+        const int gz = gz0 + zl, gy = gy0 + yl, gx = gx0 + xl;
         const int oz = gz * a.so + ci.oz, oy = gy * a.so + ci.oy, ox = gx * a.so + ci.ox;
-        if (oz < a.Do && oy < a.Ho && ox < a.Wo) {
-          float v = acc[mb][i] + bias;
-          if (a.add)
-            v += nl_apply(a.add[(long long)n * a.asn + oz * a.asd + oy * a.ash + ox * a.asw + col], asc, ash,
-                          a.tadd.relu);
-          float* op = a.out + (long long)n * a.osn + oz * a.osd + oy * a.osh + ox * a.osw + col;
-          if (a.accumulate) v += *op;
-          *op = v;
+        ok[j] = colok && gz < ci.Dg && gy < ci.Hg && gx < ci.Wg && oz < a.Do && oy < a.Ho && ox < a.Wo;
+        const int cz = min(oz, a.Do - 1), cy = min(oy, a.Ho - 1), cx = min(ox, a.Wo - 1);
+        ooff[j] = cz * (int)a.osd + cy * (int)a.osh + cx * (int)a.osw;
+        aoff[j] = cz * (int)a.asd + cy * (int)a.ash + cx * (int)a.asw;
+      }
+      float addv[8], oldv[8];
+      if (a.add) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) addv[j] = addb[aoff[j]];
+      }
+      if (a.accumulate) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oldv[j] = outb[ooff[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = acc[mb][half * 8 + j] + bias;
+        if (a.add) v += nl_apply(addv[j], asc, ash, a.tadd.relu);
+        if (a.accumulate) v += oldv[j];
+        if (ok[j]) {
+          outb[ooff[j]] = v;
           s_sum += v;
           s_sq += v * v;
         }
       }
     }
+  }
   if (a.stats != nullptr) {
     // lanes l and l+32 hold the same column; waves of different m-groups too.
     s_sum += __shfl_xor(s_sum, 32, 64);
@@ -484,33 +508,49 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
     if (a.add) nl_coeff(a.tadd, n, a.Co, col, asc, ash);
   }
   float s_sum = 0.f, s_sq = 0.f;
+  // the thread's 4 rows advance together: every load is unconditional (clamped address) and independent
+  const int colc = min(col, a.Co - 1);
+  const long long kstride = (long long)tiles * MT * a.Np;
+  const float* wsp[4];
+  long long ooff[4], aoff[4];
+  bool ok[4];
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int v = rb * 32 + rg * 4 + q;
     int zl, yl, xl;
     row_to_local<TZ, TY, TX>(v, zl, yl, xl);
     const int gz = tzi * TZ + zl, gy = tyi * TY + yl, gx = txi * TX + xl;
-    if (!(colok && gz < ci.Dg && gy < ci.Hg && gx < ci.Wg)) continue;
     const int oz = gz * a.so + ci.oz, oy = gy * a.so + ci.oy, ox = gx * a.so + ci.ox;
-    if (!(oz < a.Do && oy < a.Ho && ox < a.Wo)) continue;
-    const float* wsp = a.ws + ((long long)tile * MT + v) * a.Np + col;
-    const long long kstride = (long long)tiles * MT * a.Np;
-    float s4[4] = {0.f, 0.f, 0.f, 0.f};
-    int kz = 0;
-    for (; kz + 4 <= a.ksplit; kz += 4) {        // four independent loads in flight
+    ok[q] = colok && gz < ci.Dg && gy < ci.Hg && gx < ci.Wg && oz < a.Do && oy < a.Ho && ox < a.Wo;
+    const int cz = min(oz, a.Do - 1), cy = min(oy, a.Ho - 1), cx = min(ox, a.Wo - 1);
+    ooff[q] = (long long)n * a.osn + cz * a.osd + cy * a.osh + cx * a.osw + colc;
+    aoff[q] = (long long)n * a.asn + cz * a.asd + cy * a.ash + cx * a.asw + colc;
+    wsp[q] = a.ws + ((long long)tile * MT + v) * a.Np + min(col, a.Np - 1);
+  }
+  for (int kz = 0; kz < a.ksplit; ++kz) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s4[u] += wsp[(kz + u) * kstride];
+    for (int q = 0; q < 4; ++q) s4[q] += wsp[q][kz * kstride];
+  }
+  float addv[4] = {0.f, 0.f, 0.f, 0.f}, oldv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.add) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) addv[q] = a.add[aoff[q]];
+  }
+  if (a.accumulate) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) oldv[q] = a.out[ooff[q]];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float val = s4[q] + bias;
+    if (a.add) val += nl_apply(addv[q], asc, ash, a.tadd.relu);
+    if (a.accumulate) val += oldv[q];
+    if (ok[q]) {
+      a.out[ooff[q]] = val;
+      s_sum += val;
+      s_sq += val * val;
     }
-    for (; kz < a.ksplit; ++kz) s4[0] += wsp[kz * kstride];
-    float val = (s4[0] + s4[1]) + (s4[2] + s4[3]) + bias;
-    if (a.add)
-      val += nl_apply(a.add[(long long)n * a.asn + oz * a.asd + oy * a.ash + ox * a.asw + col], asc, ash,
-                      a.tadd.relu);
-    float* op = a.out + (long long)n * a.osn + oz * a.osd + oy * a.osh + ox * a.osw + col;
-    if (a.accumulate) val += *op;
-    *op = val;
-    s_sum += val;
-    s_sq += val * val;
   }
   if (a.stats != nullptr) {
     red[0][rg][r] = s_sum;

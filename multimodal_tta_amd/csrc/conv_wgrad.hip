@@ -527,21 +527,43 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
       const float* qb = a.q + (long long)n * a.qsn;
       float sc[4], sh[4];
       nl_coeff_vec<4>(a.tq, n, a.Cs, 0, sc, sh);
-      for (int bv = tid; bv < boxvox; bv += 256) {
-        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
-        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)iz < (unsigned)a.Dq && (unsigned)iy < (unsigned)a.Hq && (unsigned)ix < (unsigned)a.Wq) {
-          const float* src = qb + iz * a.qsd + iy * a.qsh + ix * a.qsw;
-          float xs[4] = {0.f, 0.f, 0.f, 0.f};
-          if (a.qvec4) { const float4 x4 = *reinterpret_cast<const float4*>(src); xs[0] = x4.x; xs[1] = x4.y; xs[2] = x4.z; xs[3] = x4.w; }
-          else { for (int j = 0; j < a.Cs; ++j) xs[j] = src[j]; }
-          v.x = nl_apply(xs[0], sc[0], sh[0], a.tq.relu);
-          v.y = a.Cs > 1 ? nl_apply(xs[1], sc[1], sh[1], a.tq.relu) : 0.f;
-          v.z = a.Cs > 2 ? nl_apply(xs[2], sc[2], sh[2], a.tq.relu) : 0.f;
-          v.w = a.Cs > 3 ? nl_apply(xs[3], sc[3], sh[3], a.tq.relu) : 0.f;
+      // all of the thread's box voxels are loaded (from clamped addresses) before the first is used
+      constexpr int NQ = 6;                       // ceil(9*9*17 / 256): the stride-2 box is the largest
+      float4 raw[NQ];
+      if (a.qvec4) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int bv = min(tid + 256 * q, boxvox - 1);
+          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+          const int iz = min(max(iz0 + bz, 0), a.Dq - 1), iy = min(max(iy0 + by, 0), a.Hq - 1), ix = min(max(ix0 + bx, 0), a.Wq - 1);
+          raw[q] = *reinterpret_cast<const float4*>(qb + iz * a.qsd + iy * a.qsh + ix * a.qsw);
         }
-        *reinterpret_cast<float4*>(ql + bv * 4) = v;
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int bv = min(tid + 256 * q, boxvox - 1);
+          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+          const int iz = min(max(iz0 + bz, 0), a.Dq - 1), iy = min(max(iy0 + by, 0), a.Hq - 1), ix = min(max(ix0 + bx, 0), a.Wq - 1);
+          const float* src = qb + iz * a.qsd + iy * a.qsh + ix * a.qsw;
+          raw[q].x = src[0];
+          raw[q].y = src[min(1, a.Cs - 1)]; raw[q].z = src[min(2, a.Cs - 1)]; raw[q].w = src[min(3, a.Cs - 1)];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int bv = tid + 256 * q;
+        if (bv < boxvox) {
+          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+          const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((unsigned)iz < (unsigned)a.Dq && (unsigned)iy < (unsigned)a.Hq && (unsigned)ix < (unsigned)a.Wq) {
+            v.x = nl_apply(raw[q].x, sc[0], sh[0], a.tq.relu);
+            v.y = a.Cs > 1 ? nl_apply(raw[q].y, sc[1], sh[1], a.tq.relu) : 0.f;
+            v.z = a.Cs > 2 ? nl_apply(raw[q].z, sc[2], sh[2], a.tq.relu) : 0.f;
+            v.w = a.Cs > 3 ? nl_apply(raw[q].w, sc[3], sh[3], a.tq.relu) : 0.f;
+          }
+          *reinterpret_cast<float4*>(ql + bv * 4) = v;
+        }
       }
     }
     {  // P tile
@@ -550,12 +572,23 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
         const int cv = tid & 7, c = cb0 + cv * 4;
         float sc[4], sh[4];
         nl_coeff_vec<4>(a.tp, n, a.Cb, c, sc, sh);
-        for (int v = tid >> 3; v < MT; v += 32) {
+        float4 praw[MT / 32];
+        const int cl4 = min(c, (a.Cb - 1) & ~3);           // clamped channel group (16-byte aligned)
+#pragma unroll
+        for (int q = 0; q < MT / 32; ++q) {
+          const int v = (tid >> 3) + 32 * q;
+          const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+          const int oz = min(oz0 + zl, a.Dp - 1), oy = min(oy0 + yl, a.Hp - 1), ox = min(ox0 + xl, a.Wp - 1);
+          praw[q] = *reinterpret_cast<const float4*>(pb + oz * a.psd + oy * a.psh + ox * a.psw + cl4);
+        }
+#pragma unroll
+        for (int q = 0; q < MT / 32; ++q) {
+          const int v = (tid >> 3) + 32 * q;
           const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
           const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
           float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
           if (oz < a.Dp && oy < a.Hp && ox < a.Wp && c < a.Cb) {
-            const float4 x4 = *reinterpret_cast<const float4*>(pb + oz * a.psd + oy * a.psh + ox * a.psw + c);
+            const float4 x4 = praw[q];
             o.x = nl_apply(x4.x, sc[0], sh[0], a.tp.relu);
             o.y = (c + 1 < a.Cb) ? nl_apply(x4.y, sc[1], sh[1], a.tp.relu) : 0.f;
             o.z = (c + 2 < a.Cb) ? nl_apply(x4.z, sc[2], sh[2], a.tp.relu) : 0.f;
@@ -640,7 +673,8 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kz = blockIdx.y;
   const int chunks = (a.dy.w + 63) / 64;
-  const long long units = (long long)a.dy.n * a.dy.d * a.dy.h * chunks;
+  const int hp = (a.dy.h + 1) / 2;                     // a wave takes two adjacent rows per step
+  const long long units = (long long)a.dy.n * a.dy.d * hp * chunks;
   const int xsw4 = (int)a.x.sw * 4, dsw4 = (int)a.dy.sw * 4;
   float acc[9][CS][CB];
 #pragma unroll
@@ -661,7 +695,7 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
   for (long long u0 = ufirst + wave; u0 < ulast; u0 += 4) {
     long long u = u0;
     const int chunk = (int)(u % chunks); u /= chunks;
-    const int oy = (int)(u % a.dy.h); u /= a.dy.h;
+    const int oy0 = 2 * (int)(u % hp); u /= hp;
     const int oz = (int)(u % a.dy.d);
     const int n = (int)(u / a.dy.d);
     const int iz = oz + kz - 1;
@@ -672,38 +706,55 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
     }
     const int ox = chunk * 64 + lane;
     const bool on = ox < a.dy.w;
-    const char* dyrow = reinterpret_cast<const char*>(a.dy.p + (long long)n * a.dy.sn + (long long)oz * a.dy.sd + (long long)oy * a.dy.sh);
-    const float4 g4 = *reinterpret_cast<const float4*>(dyrow + (unsigned)(min(ox, a.dy.w - 1) * dsw4));
-    const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
-    float g[3][CB];     // dy of this voxel as seen by the three kx (zero where the x neighbour does not exist)
+    // all 14 loads of the step (2 dy voxels, 4 x rows x 3 neighbours) go out before the first use, from clamped
+    // addresses; what does not exist is dropped by zeroing the dy factor
+    const char* dyb = reinterpret_cast<const char*>(a.dy.p + (long long)n * a.dy.sn + (long long)oz * a.dy.sd);
+    float4 g4[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      g4[j] = *reinterpret_cast<const float4*>(dyb + (long long)min(oy0 + j, a.dy.h - 1) * a.dy.sh * 4 +
+                                               (unsigned)(min(ox, a.dy.w - 1) * dsw4));
     unsigned boff[3];
+    bool okx[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int ix = ox + kx - 1;
-      const bool ok = on && (unsigned)ix < (unsigned)a.x.w;
+      okx[kx] = on && (unsigned)ix < (unsigned)a.x.w;
       boff[kx] = (unsigned)(min(max(ix, 0), a.x.w - 1) * xsw4);
-#pragma unroll
-      for (int j = 0; j < CB; ++j) g[kx][j] = ok ? gs[j] : 0.f;
-    }
-    if (kz == 1) {
-#pragma unroll
-      for (int j = 0; j < CB; ++j) dbs[j] += on ? gs[j] : 0.f;
     }
     const char* xb = reinterpret_cast<const char*>(a.x.p + (long long)n * a.x.sn + (long long)iz * a.x.sd);
+    float4 xr[4][3];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy + ky - 1;
-      if ((unsigned)iy >= (unsigned)a.x.h) continue;
-      const char* xrow = xb + (long long)iy * a.x.sh * 4;
+    for (int r = 0; r < 4; ++r) {
+      const char* xrow = xb + (long long)min(max(oy0 - 1 + r, 0), a.x.h - 1) * a.x.sh * 4;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const float4 x4 = *reinterpret_cast<const float4*>(xrow + boff[kx]);
-        const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+      for (int kx = 0; kx < 3; ++kx) xr[r][kx] = *reinterpret_cast<const float4*>(xrow + boff[kx]);
+    }
 #pragma unroll
-        for (int i = 0; i < CS; ++i) {
-          const float xv = HAS_T ? nl_apply(xs[i], sc[i], sh[i], a.tx.relu) : xs[i];
+    for (int j = 0; j < 2; ++j) {
+      const bool rowon = oy0 + j < a.dy.h;
+      const float gs[4] = {g4[j].x, g4[j].y, g4[j].z, g4[j].w};
+      if (kz == 1) {
 #pragma unroll
-          for (int j = 0; j < CB; ++j) acc[ky * 3 + kx][i][j] = fmaf(xv, g[kx][j], acc[ky * 3 + kx][i][j]);
+        for (int q = 0; q < CB; ++q) dbs[q] += (on && rowon) ? gs[q] : 0.f;
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int r = j + ky;                       // x row oy0 + j + ky - 1
+        const bool rok = rowon && (unsigned)(oy0 - 1 + r) < (unsigned)a.x.h;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bool ok = rok && okx[kx];
+          const float raw[4] = {xr[r][kx].x, xr[r][kx].y, xr[r][kx].z, xr[r][kx].w};
+          float g[CB];
+#pragma unroll
+          for (int q = 0; q < CB; ++q) g[q] = ok ? gs[q] : 0.f;
+#pragma unroll
+          for (int i = 0; i < CS; ++i) {
+            const float xv = HAS_T ? nl_apply(raw[i], sc[i], sh[i], a.tx.relu) : raw[i];
+#pragma unroll
+            for (int q = 0; q < CB; ++q) acc[ky * 3 + kx][i][q] = fmaf(xv, g[q], acc[ky * 3 + kx][i][q]);
+          }
         }
       }
     }
@@ -796,7 +847,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   };
   w.tiny = !w.convt && d->cin <= 4 && d->cout <= 4 && d->ksize == 3 && d->stride == 1 && al16(x) && al16(dy);
   if (w.tiny) {
-    const long long units = (long long)dy->n * dy->d * dy->h * ((dy->w + 63) / 64);
+    const long long units = (long long)dy->n * dy->d * ((dy->h + 1) / 2) * ((dy->w + 63) / 64);
     long long blocks = (units + 3) / 4;
     if (blocks > 512) blocks = 512;
     w.tiny_blocks = (int)blocks;
