@@ -76,6 +76,13 @@ typedef struct {
 const char* mmtta_last_error(void);   /* thread-local text for the last non-zero status */
 int mmtta_abi_version(void);
 
+/* Measurement aid (bench.py's roofline pass): key MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY != 0 makes the multi-kernel
+ * entry points (mmtta_conv_wgrad: main kernel + slab reductions; split-K mmtta_conv_run: main kernel + finalize)
+ * launch ONLY their main kernel, so that two events around the call time exactly the kernel rocprofv3 names.
+ * Results of such calls are not valid outputs.  Returns the previous value. */
+#define MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY 1
+int mmtta_set_option(int key, int value);
+
 /* ------------------------------------------------------------------ layout (boundary) ---- */
 /* NCDHW fp32 <-> channels-last.  Stands in for nothing in the reference: it is the price of
  * the internal layout, paid once per volume on the way in (reference tensor contract:

@@ -64,6 +64,7 @@ _P = C.POINTER
 _SIGNATURES = {
     "mmtta_last_error": (C.c_char_p, []),
     "mmtta_abi_version": (C.c_int, []),
+    "mmtta_set_option": (C.c_int, [C.c_int, C.c_int]),
     "mmtta_copy_strided": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p]),
     "mmtta_conv_packed_bytes": (C.c_int64, [_P(ConvDesc)]),
     "mmtta_conv_pack_weights": (C.c_int, [_P(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),

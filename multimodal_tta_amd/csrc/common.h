@@ -152,6 +152,7 @@ int channel_partial_rows(const mmtta_tensor* t);                        // parti
 int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s);  // part: [N*rows][2][C] (sum, sumsq)
 
 // direct path for layers producing <= 4 channels (conv_direct.hip)
+extern int g_profile_main_only;     // api.hip: mmtta_set_option(MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY)
 bool direct_applicable(const mmtta_conv_desc* d);
 int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);
 int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed,

@@ -451,6 +451,100 @@ __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
   direct_stats<NO>(a, n, ssum, ssq, red);
 }
 
+// ------------------------------------------------------------------ stride-2 up-convolution to <= 4 channels
+// ConvTranspose3d K -> R (k3, s2, p1, output_padding 1) with K = 32 / 64: the full-resolution last layer of the U-Net.
+// out[2i+p] needs in[i] (p = 0: tap 1; p = 1: tap 2) and, for p = 1, in[i+1] (tap 0), per axis.  A workgroup stages
+// the 2 x 2 input rows (iz, iz+1) x (iy, iy+1), 65 voxels each, ONCE in LDS (norm+ReLU applied, borders written
+// as zeros) and produces the 2 x 2 output rows x 128 voxels that depend on nothing else.  A wave takes one of the
+// 8 output parity classes at a time (64 voxels of that class, one per lane): its tap list is wave-uniform, so
+// the weights are SGPR operands (constant address space, 64 bytes per load) and every lane simply walks the K
+// channels of its 1 / 2 / 4 / 8 input voxels in LDS (16-byte reads, conflict-free at a 16-byte row pad).  No
+// cross-lane reduction, each input voxel is fetched from L2 once per workgroup instead of once per tap.
+template <int K, int NO, bool HAS_T>
+__global__ __launch_bounds__(256) void direct_upconv_kernel(DArgs a) {
+  extern __shared__ float lds[];
+  constexpr int VS = K + 4;                    // LDS voxel stride (floats)
+  constexpr int XV = 65;                       // staged voxels per row
+  float* red = lds + 4 * XV * VS;
+  cfloat* wc = (cfloat*)a.w;                   // [27][K][4]
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunks = (a.in.w + 63) / 64;
+  int b = blockIdx.x;
+  const int chunk = b % chunks; b /= chunks;
+  const int iy0 = b % a.in.h;
+  const int iz0 = b / a.in.h;
+  const int ix0 = chunk * 64;
+  {  // ---- stage: thread = (channel group of 4, voxel slots); all loads first (clamped), then transform + store
+    constexpr int CG = K / 4;                  // channel groups per voxel (256 % CG == 0)
+    constexpr int NIT = (4 * XV * CG + 255) / 256;
+    const int cg = tid % CG;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_T) nl_coeff_vec<4>(a.tin, n, K, cg * 4, sc, sh);
+    const float* inb = a.in.p + (long long)n * a.in.sn + cg * 4;
+    float4 raw[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int vs = min(tid / CG + q * (256 / CG), 4 * XV - 1);     // voxel slot: row * XV + x
+      const int row = vs / XV, xl = vs % XV;
+      const int iz = min(iz0 + (row >> 1), a.in.d - 1), iy = min(iy0 + (row & 1), a.in.h - 1), ix = min(ix0 + xl, a.in.w - 1);
+      raw[q] = *reinterpret_cast<const float4*>(inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw);
+    }
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int vs = tid / CG + q * (256 / CG);
+      if (vs < 4 * XV) {
+        const int row = vs / XV, xl = vs % XV;
+        const bool ok = iz0 + (row >> 1) < a.in.d && iy0 + (row & 1) < a.in.h && ix0 + xl < a.in.w;
+        float4 v;
+        v.x = ok ? (HAS_T ? nl_apply(raw[q].x, sc[0], sh[0], a.tin.relu) : raw[q].x) : 0.f;
+        v.y = ok ? (HAS_T ? nl_apply(raw[q].y, sc[1], sh[1], a.tin.relu) : raw[q].y) : 0.f;
+        v.z = ok ? (HAS_T ? nl_apply(raw[q].z, sc[2], sh[2], a.tin.relu) : raw[q].z) : 0.f;
+        v.w = ok ? (HAS_T ? nl_apply(raw[q].w, sc[3], sh[3], a.tin.relu) : raw[q].w) : 0.f;
+        *reinterpret_cast<float4*>(lds + vs * VS + cg * 4) = v;
+      }
+    }
+  }
+  __syncthreads();
+  float ssum[NO], ssq[NO];
+#pragma unroll
+  for (int c = 0; c < NO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+#pragma unroll 1
+  for (int rep = 0; rep < 2; ++rep) {
+    const int cls = wave + 4 * rep;            // (pz, py, px)
+    const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+    float acc[NO];
+#pragma unroll
+    for (int c = 0; c < NO; ++c) acc[c] = 0.f;
+    // per axis: parity 0 -> (tap 1, shift 0); parity 1 -> (tap 2, shift 0) and (tap 0, shift 1)
+    for (int tz = 0; tz <= pz; ++tz) {
+      const int kz = pz == 0 ? 1 : (tz == 0 ? 2 : 0);
+      for (int ty = 0; ty <= py; ++ty) {
+        const int ky = py == 0 ? 1 : (ty == 0 ? 2 : 0);
+        for (int tx = 0; tx <= px; ++tx) {
+          const int kx = px == 0 ? 1 : (tx == 0 ? 2 : 0);
+          const float* xv = lds + ((tz * 2 + ty) * XV + lane + tx) * VS;
+          cfloat* wt = wc + ((kz * 3 + ky) * 3 + kx) * K * 4;
+#pragma unroll
+          for (int k4 = 0; k4 < K / 4; ++k4) {
+            const float4 x4 = *reinterpret_cast<const float4*>(xv + 4 * k4);
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int c = 0; c < NO; ++c) acc[c] = fmaf(xs[j], wt[(4 * k4 + j) * 4 + c], acc[c]);
+          }
+        }
+      }
+    }
+    const int oz = 2 * iz0 + pz, oy = 2 * iy0 + py, ox = 2 * (ix0 + lane) + px;
+    if (ix0 + lane < a.in.w && oz < a.out.d && oy < a.out.h && ox < a.out.w)
+      direct_epilogue<NO>(a, n, oz, oy, ox, acc, ssum, ssq);
+  }
+  direct_stats<NO>(a, n, ssum, ssq, red);
+}
+
 static void direct_dims(const mmtta_conv_desc* d, int& K, int& N) {
   switch (d->op) {
     case MMTTA_CONV_FWD: case MMTTA_CONVT_FWD: N = d->cout; K = d->cin; break;
@@ -470,11 +564,13 @@ static bool aligned16(const mmtta_tensor* x) {
   return x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0 && ((uintptr_t)x->ptr) % 16 == 0;
 }
 
-// 0: thread per voxel (any shape); 1: lanes along K (K = 32 or 64); 2: row kernel (K <= 4, stride 1)
+// 0: thread per voxel (any shape); 1: lanes along K (K = 32 or 64); 2: row kernel (K <= 4, k3 s1);
+// 3: LDS-staged stride-2 up-convolution (ConvTranspose3d forward, K = 32 or 64)
 static int direct_variant(const mmtta_conv_desc* d, const mmtta_tensor* x) {
   int K, N;
   direct_dims(d, K, N);
   if (!aligned16(x) || (long long)x->w * x->sw * 4 >= (1LL << 31)) return 0;
+  if ((K == 32 || K == 64) && d->op == MMTTA_CONVT_FWD && d->ksize == 3 && d->stride == 2) return 3;
   if (K == 32 || K == 64) return 1;
   if (K <= 4 && d->stride == 1 && d->ksize == 3) return 2;
   return 0;
@@ -495,6 +591,7 @@ int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const m
     const long long dhw = (long long)y->d * y->h * y->w;
     return (int)((dhw + 255) / 256);
   }
+  if (v == 3) return x->d * x->h * ((x->w + 63) / 64);       // one workgroup per (input row pair, 64-voxel chunk)
   // grid-stride kernels: enough workgroups to fill the chip a few times over, never more than the work
   const long long want = (direct_units(d, v, y) + 3) / 4;
   const long long cap = v == 1 ? 1024 : 2048;
@@ -520,6 +617,26 @@ static void launch_row_n(const DArgs& a, int n, hipStream_t stream) {
     case 2: hipLaunchKernelGGL((direct_row_kernel<KI, 2, HAS_T>), grid, block, 0, stream, a); break;
     case 3: hipLaunchKernelGGL((direct_row_kernel<KI, 3, HAS_T>), grid, block, 0, stream, a); break;
     default: hipLaunchKernelGGL((direct_row_kernel<KI, 4, HAS_T>), grid, block, 0, stream, a); break;
+  }
+}
+
+template <int K, bool HAS_T>
+static void launch_upconv(const DArgs& a, int n, hipStream_t stream) {
+  const dim3 grid(a.blocks_per_n, n), block(256);
+  const size_t lds = ((size_t)4 * 65 * (K + 4) + 32) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)direct_upconv_kernel<K, 1, HAS_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)direct_upconv_kernel<K, 2, HAS_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)direct_upconv_kernel<K, 3, HAS_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)direct_upconv_kernel<K, 4, HAS_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  switch (a.N) {
+    case 1: hipLaunchKernelGGL((direct_upconv_kernel<K, 1, HAS_T>), grid, block, lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((direct_upconv_kernel<K, 2, HAS_T>), grid, block, lds, stream, a); break;
+    case 3: hipLaunchKernelGGL((direct_upconv_kernel<K, 3, HAS_T>), grid, block, lds, stream, a); break;
+    default: hipLaunchKernelGGL((direct_upconv_kernel<K, 4, HAS_T>), grid, block, lds, stream, a); break;
   }
 }
 
@@ -574,6 +691,11 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   if (variant == 2) {
     if (has_t) launch_row<true>(a, y->n, stream); else launch_row<false>(a, y->n, stream);
     return launch_status("direct conv (row)");
+  }
+  if (variant == 3) {
+    if (a.K == 64) { if (has_t) launch_upconv<64, true>(a, y->n, stream); else launch_upconv<64, false>(a, y->n, stream); }
+    else { if (has_t) launch_upconv<32, true>(a, y->n, stream); else launch_upconv<32, false>(a, y->n, stream); }
+    return launch_status("direct up-convolution");
   }
   if (has_t) hipLaunchKernelGGL(direct_conv_kernel<true>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL(direct_conv_kernel<false>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);

@@ -877,7 +877,7 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   int st = launch_status("conv igemm");
   if (st) return st;
-  if (a.ksplit > 1) {
+  if (a.ksplit > 1 && !g_profile_main_only) {
     dim3 g2(tiles * (TZ * TY * TX / 32), (a.Np + 31) / 32);
     hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX>), g2, dim3(256), 0, s, a, tiles);
     st = launch_status("conv split-K finalize");

@@ -971,7 +971,7 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
     if (t.tx.mean != nullptr || t.tx.scale != nullptr) launch_tiny<true>(t, d->cin, d->cout, w.tiny_blocks, s);
     else launch_tiny<false>(t, d->cin, d->cout, w.tiny_blocks, s);
     st = launch_status("wgrad tiny");
-    if (st) return st;
+    if (st || g_profile_main_only) return st;
     hipLaunchKernelGGL(db_reduce_kernel, dim3(t.ld), dim3(64), 0, s, t.part, dw, w.tiny_blocks, t.ld, t.ld, accumulate);
     if (db != nullptr)
       hipLaunchKernelGGL(db_reduce_kernel, dim3(d->cout), dim3(64), 0, s, t.dbpart, db, w.tiny_blocks, d->cout, 4, accumulate);
@@ -1000,7 +1000,7 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
     const size_t lds = ((size_t)BZ * BY * BX * 4 + 128 * 32) * sizeof(float);
     hipLaunchKernelGGL(wgrad_small_kernel, dim3(w.S, w.CDp / 32), dim3(256), lds, s, b);
     st = launch_status("wgrad small");
-    if (st) return st;
+    if (st || g_profile_main_only) return st;
     const int total = w.ntaps * b.Cs * b.Cb;
     const float* rsrc = b.slab;
     int rn = w.nsl;
@@ -1051,7 +1051,7 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   if (w.bf16) st = (w.si == 1) ? launch_wgrad_bf16<4, 4, 1>(a, w.S, s) : launch_wgrad_bf16<2, 4, 2>(a, w.S, s);
   else if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, w.S, s);
   else st = (w.si == 1) ? launch_wgrad<4, 4, 8, 7>(a, w.S, s) : launch_wgrad<2, 2, 8, 7>(a, w.S, s);
-  if (st) return st;
+  if (st || g_profile_main_only) return st;
   const float* rsrc = a.slab;
   int rn = w.nsl;
   if (w.pre_chunks > 0) {

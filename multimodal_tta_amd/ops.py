@@ -252,7 +252,7 @@ class ConvOp:
             e0 = PROFILER.begin()
             for _ in range(PROFILER.reps):
                 launch()
-            PROFILER.end(IGEMM_KERNELS[p.config] + ("+splitk" if p.ksplit > 1 else ""), int(p.launches) * PROFILER.reps,
+            PROFILER.end(IGEMM_KERNELS[p.config], PROFILER.reps,
                          self.flops(x, y, desc) * PROFILER.reps, e0, self._detail(desc.op, x))
 
     def _detail(self, op: int, x: torch.Tensor) -> str:
@@ -293,7 +293,7 @@ class ConvOp:
             for _ in range(PROFILER.reps):
                 launch()
             kid = lib.mmtta_conv_wgrad_kernel(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy))
-            PROFILER.end(WGRAD_KERNELS[kid] + "+reduce", PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0,
+            PROFILER.end(WGRAD_KERNELS[kid], PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0,
                          self._detail(-1, x))
 
 
