@@ -55,6 +55,10 @@ struct ClassInfo {
   int zmin, ymin, xmin;
   int zext, yext, xext;
   int Dg, Hg, Wg;
+  // box extents of this class for the launch's tile, with reciprocals for exact division of a box index < 2^16:
+  // q = __umulhi(v, ceil(2^32 / d))
+  int BX, BXY;
+  unsigned mBX, mBXY;
 };
 
 struct GArgs {
@@ -152,7 +156,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
         nl_coeff_vec<8>(a.tin, n, a.Ci, c, sc, sh);
         // U items per trip: all their global loads are issued before the first use (one exposed latency per
         // trip instead of one per item)
-        constexpr int U = 4, STEP = 256 / CV8;
+        constexpr int STEP = 256 / CV8;
+        // all of a thread's items in as few trips as the register budget allows: one exposed memory latency per trip
+        constexpr int U = MB == 4 ? 8 : 6;
         const bool tail = (a.Ci & 7) != 0;       // only then can lanes beyond Ci hold uninitialised padding
         for (int bv0 = tid / CV8; bv0 < boxvox; bv0 += U * STEP) {
           float4 x0[U], x1[U];
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int bv = bv0 + u * STEP;
-            const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+            const int bz = (int)__umulhi((unsigned)bv, ci.mBXY), brem = bv - bz * ci.BXY;
+            const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
             const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
             ok[u] = bv < boxvox && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
                     (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
@@ -198,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
         float sc, sh;
         nl_coeff_vec<1>(a.tin, n, a.Ci, c, &sc, &sh);
         for (int bv = tid / KCI; bv < boxvox; bv += 256 / KCI) {
-          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+          const int bz = (int)__umulhi((unsigned)bv, ci.mBXY), brem = bv - bz * ci.BXY;
+          const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
           const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
           float v = 0.f;
           if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi &&
@@ -221,7 +229,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int bv = bv0 + u * STEP;
-          const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+          const int bz = (int)__umulhi((unsigned)bv, ci.mBXY), brem = bv - bz * ci.BXY;
+          const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
           const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
           ok[u] = bv < boxvox && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
                   (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
@@ -715,7 +724,8 @@ static Config pick_config(int Np, int si, long long voxels, int K, bool bf) {
   // fp32 stage depth / bf16 stage depth (bf16 stages are multiples of the MFMA K = 16)
   if (si == 1) {
     if (Np == 32) return {1, 4, 8, 8, 8, bf ? 16 : 8, bf};
-    if (Np == 64) return {2, 4, 4, 8, 8, bf ? 32 : 16, bf};
+    static const int kci64 = getenv("MMTTA_KCI64") ? atoi(getenv("MMTTA_KCI64")) : 32;
+    if (Np == 64) return {2, 4, 4, 8, 8, bf ? kci64 : 16, bf};
     // wide layers on a small grid (the 8^3 / 16^3 levels): shallow stages so that split-K can reach
     // >= 256 workgroups; otherwise 32-channel stages (fewer barriers, fewer weight fetches)
     const long long tiles = (voxels + 127) / 128, colgroups = (Np + 127) / 128;
@@ -805,8 +815,10 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   const int wgs = g.tiles * ncolgroups;
   g.ksplit = 1;
   g.sps = g.nstages;
-  if (wgs < 384 && g.nstages > 1) {
-    int want = (512 + wgs - 1) / wgs;
+  static const int split_below = getenv("MMTTA_SPLIT_BELOW") ? atoi(getenv("MMTTA_SPLIT_BELOW")) : 384;
+  static const int split_target = getenv("MMTTA_SPLIT_TARGET") ? atoi(getenv("MMTTA_SPLIT_TARGET")) : 512;
+  if (wgs < split_below && g.nstages > 1) {
+    int want = (split_target + wgs - 1) / wgs;
     if (want > g.nstages) want = g.nstages;
     g.sps = (g.nstages + want - 1) / want;
     g.ksplit = (g.nstages + g.sps - 1) / g.sps;
@@ -862,6 +874,9 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
       a.toff[a.cls[c].tap0 + t] = ((tp.dz[t] - tp.zmin) * BY + (tp.dy[t] - tp.ymin)) * BX + (tp.dx[t] - tp.xmin);
       a.slab[a.cls[c].tap0 + t] = tp.slab[t];
     }
+    a.cls[c].BX = BX; a.cls[c].BXY = BX * BY;
+    a.cls[c].mBX = (unsigned)(((1ULL << 32) + BX - 1) / BX);
+    a.cls[c].mBXY = (unsigned)(((1ULL << 32) + (unsigned long long)BX * BY - 1) / ((unsigned long long)BX * BY));
     const size_t need = BF ? (size_t)BZ * BY * BX * (KCI + 8) * 2 : (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
     if (need > lds) lds = need;
   }
@@ -902,7 +917,8 @@ static int launch_any(const Config& c, const GArgs& a, const Taps* ht, int tiles
     case 4: return launch_cfg<2, 2, 4, 4, 8, 8, false>(a, ht, tiles, s);
     case 5: return launch_cfg<4, 4, 4, 4, 8, 8, false>(a, ht, tiles, s);
     case 7: return launch_cfg<1, 4, 8, 8, 8, 16, true>(a, ht, tiles, s);
-    case 8: return launch_cfg<2, 4, 4, 8, 8, 32, true>(a, ht, tiles, s);
+    case 8: return c.KCI == 16 ? launch_cfg<2, 4, 4, 8, 8, 16, true>(a, ht, tiles, s)
+                               : launch_cfg<2, 4, 4, 8, 8, 32, true>(a, ht, tiles, s);
     case 9: return launch_cfg<4, 4, 4, 4, 8, 32, true>(a, ht, tiles, s);
     case 10: return launch_cfg<1, 1, 4, 4, 8, 16, true>(a, ht, tiles, s);
     case 11: return launch_cfg<2, 2, 4, 4, 8, 16, true>(a, ht, tiles, s);

@@ -340,22 +340,23 @@ __global__ __launch_bounds__(256) void elementwise_kernel(EwArgs e) {
       const int c = c0 + j;
       if (MODE == 0) {
         float sa, ha;
-        nl_coeff(e.ta, n, C, c, sa, ha);
+        nl_coeff(e.ta, n, C, min(c, C - 1), sa, ha);
         float r = nl_apply(av[j], sa, ha, e.ta.relu);
         if (bp) {
           float sb, hb;
-          nl_coeff(e.tb, n, C, c, sb, hb);
+          nl_coeff(e.tb, n, C, min(c, C - 1), sb, hb);
           r += nl_apply(bv[j], sb, hb, e.tb.relu);
         }
         ov[j] = r;
       } else {
-        const float mu = e.ta.mean[n * C + c], rs = e.ta.rstd[n * C + c];
-        const float g = e.ta.gamma ? e.ta.gamma[c] : 1.f;
-        const float bt = e.ta.beta ? e.ta.beta[c] : 0.f;
+        const int cc = min(c, C - 1);                 // pad lanes of a padded row compute on channel C-1's values
+        const float mu = e.ta.mean[n * C + cc], rs = e.ta.rstd[n * C + cc];
+        const float g = e.ta.gamma ? e.ta.gamma[cc] : 1.f;
+        const float bt = e.ta.beta ? e.ta.beta[cc] : 0.f;
         const float xhat = (bv[j] - mu) * rs;
         float dz = av[j];
         if (e.ta.relu && !(fmaf(g, xhat, bt) > 0.f)) dz = 0.f;
-        ov[j] = rs * (g * dz - e.m1[n * C + c] - xhat * e.m2[n * C + c]);
+        ov[j] = rs * (g * dz - e.m1[n * C + cc] - xhat * e.m2[n * C + cc]);
       }
     }
     float* op = e.o.p + vox_addr(e.o, n, z, y, x) + c0;
@@ -496,9 +497,14 @@ static inline int grid_for(long long total, int cap = 8192) {
   return (int)b;
 }
 
-static inline bool vec4_ok(const mmtta_tensor* t) {
-  return t->c % 4 == 0 && ((uintptr_t)t->ptr) % 16 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 &&
-         t->sn % 4 == 0 && t->sc == 1;
+// 16-byte access to 4 channels at a time.  C need not be a multiple of 4 when the voxel row is padded to one
+// (sw >= roundup(C,4)): READING the pad lanes is always harmless; WRITING them needs a view that owns its pad.
+static inline bool vec4_rd(const mmtta_tensor* t) {
+  return ((uintptr_t)t->ptr) % 16 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 && t->sc == 1 &&
+         (t->c % 4 == 0 || t->sw >= (t->c + 3) / 4 * 4);
+}
+static inline bool vec4_wr(const mmtta_tensor* t) {
+  return vec4_rd(t) && (t->c % 4 == 0 || (t->flags & MMTTA_TENSOR_OWNS_PAD));
 }
 
 static inline bool same_shape(const mmtta_tensor* a, const mmtta_tensor* b) {
@@ -524,7 +530,7 @@ int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s) {
   RedArgs a;
   a.x = tv(x); a.dout = tv(x); a.t = nl(nullptr); a.part = part;
   rows_geometry(x, a.rows_per_n, a.vox_per_row);
-  if (vec4_ok(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4>), dim3(x->n * a.rows_per_n), dim3(256), 0, s, a);
+  if (vec4_rd(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4>), dim3(x->n * a.rows_per_n), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((channel_reduce_kernel<0, 1>), dim3(x->n * a.rows_per_n), dim3(256), 0, s, a);
   return launch_status("channel sums");
 }
@@ -554,7 +560,7 @@ extern "C" int mmtta_channel_stats(const mmtta_tensor* x, float* part, void* str
   RedArgs a;
   a.x = tv(x); a.dout = tv(x); a.t = nl(nullptr); a.part = part;
   rows_geometry(x, a.rows_per_n, a.vox_per_row);
-  if (vec4_ok(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4>), dim3(x->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
+  if (vec4_rd(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4>), dim3(x->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((channel_reduce_kernel<0, 1>), dim3(x->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status("channel_stats");
 }
@@ -601,8 +607,8 @@ extern "C" int mmtta_combine(const mmtta_tensor* a, const mmtta_norm_on_load* ta
   MMTTA_CHECK(is_cl(a) && is_cl(out) && (!b || is_cl(b)), MMTTA_ERR_UNSUPPORTED, "combine: channels-last only");
   EwArgs e;
   e.a = tv(a); e.b = b ? tv(b) : tv(a); e.o = tv(out); e.ta = nl(ta); e.tb = nl(tb); e.m1 = e.m2 = nullptr; e.hasb = b ? 1 : 0;
-  const bool v4 = vec4_ok(a) && vec4_ok(out) && (!b || vec4_ok(b));
-  const long long total = (long long)out->n * out->d * out->h * out->w * (v4 ? out->c / 4 : out->c);
+  const bool v4 = vec4_rd(a) && vec4_wr(out) && (!b || vec4_rd(b));
+  const long long total = (long long)out->n * out->d * out->h * out->w * (v4 ? (out->c + 3) / 4 : out->c);
   if (v4) hipLaunchKernelGGL((elementwise_kernel<0, 4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
   else hipLaunchKernelGGL((elementwise_kernel<0, 1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
   return launch_status("combine");
@@ -615,7 +621,7 @@ extern "C" int mmtta_norm_bwd_reduce(const mmtta_tensor* dout, const mmtta_tenso
   RedArgs a;
   a.x = tv(y); a.dout = tv(dout); a.t = nl(t); a.part = part;
   rows_geometry(y, a.rows_per_n, a.vox_per_row);
-  if (vec4_ok(y) && vec4_ok(dout)) hipLaunchKernelGGL((channel_reduce_kernel<1, 4>), dim3(y->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
+  if (vec4_rd(y) && vec4_rd(dout)) hipLaunchKernelGGL((channel_reduce_kernel<1, 4>), dim3(y->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((channel_reduce_kernel<1, 1>), dim3(y->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status("norm bwd reduce");
 }
@@ -650,8 +656,8 @@ extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor
   MMTTA_CHECK(is_cl(dout) && is_cl(y) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "norm bwd apply: channels-last only");
   EwArgs e;
   e.a = tv(dout); e.b = tv(y); e.o = tv(dy); e.ta = nl(t); e.tb = nl(nullptr); e.m1 = m1; e.m2 = m2; e.hasb = 1;
-  const bool v4 = vec4_ok(dout) && vec4_ok(y) && vec4_ok(dy);
-  const long long total = (long long)y->n * y->d * y->h * y->w * (v4 ? y->c / 4 : y->c);
+  const bool v4 = vec4_rd(dout) && vec4_rd(y) && vec4_wr(dy);
+  const long long total = (long long)y->n * y->d * y->h * y->w * (v4 ? (y->c + 3) / 4 : y->c);
   if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
   else hipLaunchKernelGGL((elementwise_kernel<1, 1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
   return launch_status("norm bwd apply");
@@ -681,17 +687,17 @@ extern "C" int mmtta_lincomb(int count, const mmtta_tensor* const* in, const flo
                              int accumulate, void* stream) {
   MMTTA_CHECK(count >= 1 && count <= 8 && in && w && out && out->ptr, MMTTA_ERR_INVALID, "lincomb: bad argument");
   LinArgs e;
-  bool v4 = vec4_ok(out);
+  bool v4 = vec4_wr(out);
   for (int k = 0; k < count; ++k) {
     MMTTA_CHECK(in[k] && in[k]->ptr && same_shape(in[k], out) && is_cl(in[k]), MMTTA_ERR_INVALID, "lincomb: input %d mismatch", k);
     e.in[k] = tv(in[k]);
     e.w[k] = w[k];
-    v4 = v4 && vec4_ok(in[k]);
+    v4 = v4 && vec4_rd(in[k]);
   }
   for (int k = count; k < 8; ++k) { e.in[k] = e.in[0]; e.w[k] = 0.f; }
   MMTTA_CHECK(is_cl(out), MMTTA_ERR_UNSUPPORTED, "lincomb: channels-last only");
   e.count = count; e.o = tv(out); e.accumulate = accumulate;
-  const long long total = (long long)out->n * out->d * out->h * out->w * (v4 ? out->c / 4 : out->c);
+  const long long total = (long long)out->n * out->d * out->h * out->w * (v4 ? (out->c + 3) / 4 : out->c);
   if (v4) hipLaunchKernelGGL(lincomb_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
   else hipLaunchKernelGGL(lincomb_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
   return launch_status("lincomb");
