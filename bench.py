@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="D H W (default: 128^3 brats, 48x144x144 hecktor)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="bf16 (BASELINE configs[1]): bf16 MFMA operands, fp32 accumulate/storage; fp32: exact fp32 MFMA")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="volumes adapted concurrently per GPU, each with its own weights, buffers, graph and stream "
+                         "(episodic adaptation has no cross-volume state; one volume alone leaves most CUs waiting)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -132,6 +135,15 @@ def main():
     torch.manual_seed(42)
     model = get_model(cfg["model"]["name"])(cfg["model"])
     plug = get_plugin("entmin_tta")(cfg).setup(model, device)
+    lanes = max(1, int(args.lanes))
+    plugs, streams = [plug], [torch.cuda.Stream(device=device)]
+    for lane in range(1, lanes):          # same source weights in every lane (episodic: restored per volume)
+        m2 = get_model(cfg["model"]["name"])(cfg["model"])
+        m2.load_state_dict(model.state_dict())
+        p2 = get_plugin("entmin_tta")(cfg)
+        p2.lane = lane
+        plugs.append(p2.setup(m2, device))
+        streams.append(torch.cuda.Stream(device=device))
     C = int(cfg["model"].get("in_channels", cfg["model"].get("num_modalities", 4)))
     R = int(cfg["model"]["num_classes"])
     thr = float(cfg["evaluation"]["seg"]["threshold"])
@@ -143,12 +155,14 @@ def main():
     counts = torch.zeros((nvol, R, 3), dtype=torch.int64, device=device)
 
     def one_volume(i):
+        lane = i % lanes
         x, y = vols[i]
-        res = plug.adapt_volume(x)
-        ops.mask_dice_counts(res["logits_cl"], y, thr, counts[i:i + 1], None)
+        with torch.cuda.stream(streams[lane]):
+            res = plugs[lane].adapt_volume(x)
+            ops.mask_dice_counts(res["logits_cl"], y, thr, counts[i:i + 1], None)
 
-    for i in range(args.warmup):
-        one_volume(i)
+    for i in range(max(args.warmup, lanes)):      # every lane captures its graph before the timed region
+        one_volume(i % nvol)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -156,6 +170,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, nvol):
         one_volume(i)
+    torch.cuda.synchronize()
     dice, iou, valid = dice_iou_from_counts(counts[args.warmup:].cpu())
     rows = torch.cat([torch.arange(args.steps, dtype=torch.float64).view(-1, 1) * world + rank,
                       torch.zeros(args.steps, 2, dtype=torch.float64), dice.double(), iou.double(), valid.double()], dim=1)
@@ -187,8 +202,9 @@ def main():
             "precision": ("bf16 MFMA operands (v_mfma_f32_32x32x16_bf16) for forward/input-gradient convs, fp32 accumulate; "
                           "fp32 storage, norms, loss, weight gradients, Adam") if args.precision == "bf16"
             else "fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32)", "weights": "seeded default init (no checkpoint offline)",
-            "parallelism": f"{world} rank(s), one per GPU, volumes sharded round-robin, one all_gather of the Dice table",
-            "graph": bool(plug.use_graph),
+            "parallelism": f"{world} rank(s), one per GPU, volumes sharded round-robin, one all_gather of the Dice table; "
+                           f"{lanes} volume(s) in flight per GPU on separate streams",
+            "graph": bool(plug.use_graph), "lanes": lanes,
         },
     }
 

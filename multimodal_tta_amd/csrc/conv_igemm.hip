@@ -81,12 +81,25 @@ struct GArgs {
   int slab[27];   // weight slab of each tap
 };
 
-template <int TZ, int TY, int TX>
+// MFMA row index v of a tile -> local voxel.  PERM (bf16 images): inside every 32-row block (4 y-rows x 8 x) the
+// rows are permuted so that the 16 lanes ds_read_b128 services together ({0-3,12-15,20-27} and {4-11,16-19,28-31})
+// hold the voxels of y-rows {0,2} and {1,3}: with an LDS x-row pitch of LP = 12 voxels of 48 bytes their
+// 16-byte slots are all distinct modulo 16 - the A-fragment reads are bank-conflict free (3-way before).
+template <int TZ, int TY, int TX, bool PERM>
 __device__ __forceinline__ void row_to_local(int v, int& zl, int& yl, int& xl) {
+  if (PERM) {
+    static_assert(TX == 8 && TY % 4 == 0, "the permutation assumes 4 x 8 row blocks");
+    const int r = v & 31, q = r >> 2;
+    const int y = (0xEB14 >> (2 * q)) & 3;           // q: 0 1 2 3 4 5 6 7 -> y: 0 1 1 0 3 2 2 3
+    const int xh = (q >> 1) & 1;
+    v = (v & ~31) + y * 8 + xh * 4 + (r & 3);
+  }
   xl = v % TX;
   yl = (v / TX) % TY;
   zl = v / (TX * TY);
 }
+
+constexpr int LDS_PITCH_BF16 = 12;   // x-row pitch (voxels) of the bf16 LDS image of stride-1 gathers
 
 // BF == false: fp32 operands, v_mfma_f32_32x32x2_f32 (bit-exact fp32 products, the parity path).
 // BF == true : activations are rounded to bf16 while they are staged, weights come from a bf16 image,
@@ -120,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
   const int BY = (TY - 1) * a.si + ci.yext + 1;
   const int BX = (TX - 1) * a.si + ci.xext + 1;
   const int boxvox = BZ * BY * BX;
+  const int LP = (BF && a.si == 1) ? LDS_PITCH_BF16 : BX;      // LDS x-row pitch in voxels
   const int iz0 = gz0 * a.si + ci.zmin, iy0 = gy0 * a.si + ci.ymin, ix0 = gx0 * a.si + ci.xmin;
 
   const int colbase = (blockIdx.y * NB + cb) * 32;
@@ -129,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     int zl, yl, xl;
-    row_to_local<TZ, TY, TX>((mg * MB + mb) * 32 + r, zl, yl, xl);
-    rowaddr[mb] = (((zl * a.si) * BY + yl * a.si) * BX + xl * a.si) * VS + (BF ? 8 * h : h);
+    row_to_local<TZ, TY, TX, BF>((mg * MB + mb) * 32 + r, zl, yl, xl);
+    rowaddr[mb] = (((zl * a.si) * BY + yl * a.si) * LP + xl * a.si) * VS + (BF ? 8 * h : h);
   }
 
   f32x16 acc[MB];
@@ -195,7 +209,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
                 pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
                 pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
               }
-              *reinterpret_cast<uint4*>(lh + bv * VS + cv * 8) = pk;
+              const int bz = (int)__umulhi((unsigned)bv, ci.mBXY), brem = bv - bz * ci.BXY;
+              const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
+              *reinterpret_cast<uint4*>(lh + ((bz * BY + by) * LP + bx) * VS + cv * 8) = pk;
             }
           }
         }
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
           if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi &&
               c < a.Ci)
             v = nl_apply(inb[iz * a.isd + iy * a.ish + ix * a.isw + c], sc, sh, a.tin.relu);
-          lh[bv * VS + cc] = __builtin_bit_cast(unsigned short, (__bf16)v);
+          lh[((bz * BY + by) * LP + bx) * VS + cc] = __builtin_bit_cast(unsigned short, (__bf16)v);
         }
       }
     } else {
@@ -285,7 +301,48 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
         const int ntap = ci.ntaps;
         const int* tslab = a.slab + ci.tap0;
         const int* ttoff = a.toff + ci.tap0;
-        if (nks == KS && ntap >= 4) {
+        if (nks == KS && ntap == 27) {
+          // Full 27-tap stage: the weight fragments of G taps are fetched as a group while the previous group's
+          // G*KS*MB MFMAs run - two register sets, straight-line code, scheduling barriers so the loads stay ahead
+          // (the scheduler otherwise sinks each load next to its use and every tap exposes an L2 round trip:
+          // measured 15-18k cycles per stage against 3.5k cycles of MFMA).
+          constexpr int G = KS == 1 ? 9 : 5;
+          constexpr int NG = (27 + G - 1) / G;
+          uint4 wset[2][G][KS];
+#pragma unroll
+          for (int t = 0; t < G; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wset[0][t][ks] = wcol[tslab[t] * slabsz8 + ks * np2];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+#pragma unroll
+              for (int t = 0; t < G; ++t) {
+                if ((g + 1) * G + t < 27) {
+#pragma unroll
+                  for (int ks = 0; ks < KS; ++ks) wset[(g + 1) & 1][t][ks] = wcol[tslab[(g + 1) * G + t] * slabsz8 + ks * np2];
+                }
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+              if (g * G + t < 27) {
+                const int ta = ttoff[g * G + t] * VS;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                  const bf16x8 bfr = __builtin_bit_cast(bf16x8, wset[g & 1][t][ks]);
+#pragma unroll
+                  for (int mb = 0; mb < MB; ++mb) {
+                    const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + ks * 16);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfr, acc[mb], 0, 0, 0);
+                  }
+                }
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else if (nks == KS && ntap >= 4) {
           // A tap is only MB*KS MFMAs of 32 cycles: far less than an L2 round trip, so the weight fragments run
           // through a ring of D taps in flight.  The body is branch-free (a load behind a branch is waited for on
           // the spot): the tap count is padded to a multiple of D, a padded tap multiplies by a zero fragment and
@@ -437,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
         const int i = half * 8 + j;
         const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
         int zl, yl, xl;
-        row_to_local<TZ, TY, TX>((mg * MB + mb) * 32 + row, zl, yl, xl);
+        row_to_local<TZ, TY, TX, BF>((mg * MB + mb) * 32 + row, zl, yl, xl);
         const int gz = gz0 + zl, gy = gy0 + yl, gx = gx0 + xl;
         const int oz = gz * a.so + ci.oz, oy = gy * a.so + ci.oy, ox = gx * a.so + ci.ox;
         ok[j] = colok && gz < ci.Dg && gy < ci.Hg && gx < ci.Wg && oz < a.Do && oy < a.Ho && ox < a.Wo;
@@ -494,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
 // Reduce split-K slabs: sum over splits, then the same epilogue as above.
 // grid (tiles * MT/32, ceil(Np/32)); 256 threads = 8 row lanes x 32 columns, 4 rows per thread, i.e. one
 // block per 32 rows x 32 columns; each block writes ONE statistics row (rows per tile = MT/32).
-template <int TZ, int TY, int TX>
+template <int TZ, int TY, int TX, bool PERM>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles) {
   __shared__ float red[2][8][32];
   constexpr int MT = TZ * TY * TX;
@@ -528,7 +585,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
   for (int q = 0; q < 4; ++q) {
     const int v = rb * 32 + rg * 4 + q;
     int zl, yl, xl;
-    row_to_local<TZ, TY, TX>(v, zl, yl, xl);
+    row_to_local<TZ, TY, TX, PERM>(v, zl, yl, xl);
     const int gz = tzi * TZ + zl, gy = tyi * TY + yl, gx = txi * TX + xl;
     const int oz = gz * a.so + ci.oz, oy = gy * a.so + ci.oy, ox = gx * a.so + ci.ox;
     ok[q] = colok && gz < ci.Dg && gy < ci.Hg && gx < ci.Wg && oz < a.Do && oy < a.Ho && ox < a.Wo;
@@ -724,8 +781,7 @@ static Config pick_config(int Np, int si, long long voxels, int K, bool bf) {
   // fp32 stage depth / bf16 stage depth (bf16 stages are multiples of the MFMA K = 16)
   if (si == 1) {
     if (Np == 32) return {1, 4, 8, 8, 8, bf ? 16 : 8, bf};
-    static const int kci64 = getenv("MMTTA_KCI64") ? atoi(getenv("MMTTA_KCI64")) : 32;
-    if (Np == 64) return {2, 4, 4, 8, 8, bf ? kci64 : 16, bf};
+    if (Np == 64) return {2, 4, 4, 8, 8, bf ? 32 : 16, bf};
     // wide layers on a small grid (the 8^3 / 16^3 levels): shallow stages so that split-K can reach
     // >= 256 workgroups; otherwise 32-channel stages (fewer barriers, fewer weight fetches)
     const long long tiles = (voxels + 127) / 128, colgroups = (Np + 127) / 128;
@@ -815,10 +871,10 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   const int wgs = g.tiles * ncolgroups;
   g.ksplit = 1;
   g.sps = g.nstages;
-  static const int split_below = getenv("MMTTA_SPLIT_BELOW") ? atoi(getenv("MMTTA_SPLIT_BELOW")) : 384;
-  static const int split_target = getenv("MMTTA_SPLIT_TARGET") ? atoi(getenv("MMTTA_SPLIT_TARGET")) : 512;
-  if (wgs < split_below && g.nstages > 1) {
-    int want = (split_target + wgs - 1) / wgs;
+  // measured on the U-Net (scripts/exp_split.sh, round 1): splitting below 384 workgroups up to ~512 is the optimum;
+  // 1024 costs +6 %, 256 +2 %, no split-K +80 % of the step's conv time
+  if (wgs < 384 && g.nstages > 1) {
+    int want = (512 + wgs - 1) / wgs;
     if (want > g.nstages) want = g.nstages;
     g.sps = (g.nstages + want - 1) / want;
     g.ksplit = (g.nstages + g.sps - 1) / g.sps;
@@ -870,14 +926,15 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
   for (int c = 0; c < a.ncls; ++c) {
     const Taps& tp = ht[c];
     const int BZ = (TZ - 1) * a.si + tp.zext + 1, BY = (TY - 1) * a.si + tp.yext + 1, BX = (TX - 1) * a.si + tp.xext + 1;
+    const int LP = (BF && a.si == 1) ? LDS_PITCH_BF16 : BX;
     for (int t = 0; t < tp.n; ++t) {
-      a.toff[a.cls[c].tap0 + t] = ((tp.dz[t] - tp.zmin) * BY + (tp.dy[t] - tp.ymin)) * BX + (tp.dx[t] - tp.xmin);
+      a.toff[a.cls[c].tap0 + t] = ((tp.dz[t] - tp.zmin) * BY + (tp.dy[t] - tp.ymin)) * LP + (tp.dx[t] - tp.xmin);
       a.slab[a.cls[c].tap0 + t] = tp.slab[t];
     }
     a.cls[c].BX = BX; a.cls[c].BXY = BX * BY;
     a.cls[c].mBX = (unsigned)(((1ULL << 32) + BX - 1) / BX);
     a.cls[c].mBXY = (unsigned)(((1ULL << 32) + (unsigned long long)BX * BY - 1) / ((unsigned long long)BX * BY));
-    const size_t need = BF ? (size_t)BZ * BY * BX * (KCI + 8) * 2 : (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
+    const size_t need = BF ? (size_t)BZ * BY * LP * (KCI + 8) * 2 : (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
     if (need > lds) lds = need;
   }
   if (lds < 4 * 2 * 32 * sizeof(float)) lds = 4 * 2 * 32 * sizeof(float);
@@ -894,7 +951,7 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
   if (st) return st;
   if (a.ksplit > 1 && !g_profile_main_only) {
     dim3 g2(tiles * (TZ * TY * TX / 32), (a.Np + 31) / 32);
-    hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX>), g2, dim3(256), 0, s, a, tiles);
+    hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX, BF>), g2, dim3(256), 0, s, a, tiles);
     st = launch_status("conv split-K finalize");
   }
   return st;
@@ -917,8 +974,7 @@ static int launch_any(const Config& c, const GArgs& a, const Taps* ht, int tiles
     case 4: return launch_cfg<2, 2, 4, 4, 8, 8, false>(a, ht, tiles, s);
     case 5: return launch_cfg<4, 4, 4, 4, 8, 8, false>(a, ht, tiles, s);
     case 7: return launch_cfg<1, 4, 8, 8, 8, 16, true>(a, ht, tiles, s);
-    case 8: return c.KCI == 16 ? launch_cfg<2, 4, 4, 8, 8, 16, true>(a, ht, tiles, s)
-                               : launch_cfg<2, 4, 4, 8, 8, 32, true>(a, ht, tiles, s);
+    case 8: return launch_cfg<2, 4, 4, 8, 8, 32, true>(a, ht, tiles, s);
     case 9: return launch_cfg<4, 4, 4, 4, 8, 32, true>(a, ht, tiles, s);
     case 10: return launch_cfg<1, 1, 4, 4, 8, 16, true>(a, ht, tiles, s);
     case 11: return launch_cfg<2, 2, 4, 4, 8, 16, true>(a, ht, tiles, s);

@@ -338,6 +338,23 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WArgs a) {
     const int tzi = t / a.ty;
     const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * 8;
     const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
+    // ---- D tile loads go out first, together with the first G trip (one exposed latency, not two)
+    constexpr int ND = (G::NXR + 7) / 8;          // x-rows per thread
+    float dv[ND][8];
+    float dsc = 0.f, dsh = 0.f;
+    const int dc = cd0 + cs;
+    const bool dcok = dc < a.Cd;
+    {
+      nl_coeff_vec<1>(a.td, n, a.Cd, dc, &dsc, &dsh);
+      const float* db = a.dn + (long long)n * a.dsn + min(dc, a.Cd - 1);
+#pragma unroll
+      for (int q = 0; q < ND; ++q) {
+        const int xr = min((tid >> 5) + 8 * q, G::NXR - 1);
+        const float* rp = db + (long long)min(oz0 + xr / TY, a.Dd - 1) * a.dsd + (long long)min(oy0 + xr % TY, a.Hd - 1) * a.dsh;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) dv[q][x] = rp[(long long)min(ox0 + x, a.Wd - 1) * a.dsw];
+      }
+    }
     {  // ---- G box: thread = (channel, box row); builds the three x-shifted 8-voxel copies
       // Every load is issued unconditionally from a clamped (always valid) address and masked afterwards (a load
       // inside a branch is followed by its own s_waitcnt, which serialises the round trips), RB box rows at a
@@ -383,34 +400,20 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WArgs a) {
       }
     }
     {  // ---- D tile: thread = (channel, x-row)
-      const int c = cd0 + cs;
-      float sc = 0.f, sh = 0.f;
-      const bool cok = c < a.Cd;
-      nl_coeff_vec<1>(a.td, n, a.Cd, c, &sc, &sh);
-      const float* db = a.dn + (long long)n * a.dsn + min(c, a.Cd - 1);
-      constexpr int ND = (G::NXR + 7) / 8;          // x-rows per thread: all their loads go out together
-      float v[ND][8];
-#pragma unroll
-      for (int q = 0; q < ND; ++q) {
-        const int xr = min((tid >> 5) + 8 * q, G::NXR - 1);
-        const float* rp = db + (long long)min(oz0 + xr / TY, a.Dd - 1) * a.dsd + (long long)min(oy0 + xr % TY, a.Hd - 1) * a.dsh;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) v[q][x] = rp[(long long)min(ox0 + x, a.Wd - 1) * a.dsw];
-      }
 #pragma unroll
       for (int q = 0; q < ND; ++q) {
         const int xr = (tid >> 5) + 8 * q;
         if (xr < G::NXR) {
           const int oz = oz0 + xr / TY, oy = oy0 + xr % TY;
-          const bool rok = cok && oz < a.Dd && oy < a.Hd;
+          const bool rok = dcok && oz < a.Dd && oy < a.Hd;
 #pragma unroll
           for (int x = 0; x < 8; ++x) {
-            v[q][x] = (rok && ox0 + x < a.Wd) ? nl_apply(v[q][x], sc, sh, a.td.relu) : 0.f;
-            dbsum += v[q][x];
+            dv[q][x] = (rok && ox0 + x < a.Wd) ? nl_apply(dv[q][x], dsc, dsh, a.td.relu) : 0.f;
+            dbsum += dv[q][x];
           }
           uint4 pk;
-          pk.x = wpack2(v[q][0], v[q][1]); pk.y = wpack2(v[q][2], v[q][3]);
-          pk.z = wpack2(v[q][4], v[q][5]); pk.w = wpack2(v[q][6], v[q][7]);
+          pk.x = wpack2(dv[q][0], dv[q][1]); pk.y = wpack2(dv[q][2], dv[q][3]);
+          pk.z = wpack2(dv[q][4], dv[q][5]); pk.w = wpack2(dv[q][6], dv[q][7]);
           *reinterpret_cast<uint4*>(dl + cs * G::CHS_D + xr * 16) = pk;
         }
       }

@@ -374,7 +374,9 @@ struct LinArgs {
   int accumulate;
 };
 
-template <int VEC>
+// COUNT inputs are a template parameter: their loads are straight-line (a load behind a run-time `k < count`
+// branch is waited for before the next one is issued)
+template <int VEC, int COUNT>
 __global__ __launch_bounds__(256) void lincomb_kernel(LinArgs e) {
   const int C = e.o.c;
   const int CV = (C + VEC - 1) / VEC;
@@ -394,17 +396,21 @@ __global__ __launch_bounds__(256) void lincomb_kernel(LinArgs e) {
       if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(op); acc[0] = t.x; acc[1] = t.y; acc[2] = t.z; acc[3] = t.w; }
       else acc[0] = op[0];
     }
+    float4 tv4[COUNT];
+    float ts[COUNT];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k < e.count) {
-        const float* ip = e.in[k].p + vox_addr(e.in[k], n, z, y, x) + c0;
-        if (VEC == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(ip);
-          acc[0] = fmaf(e.w[k], t.x, acc[0]); acc[1] = fmaf(e.w[k], t.y, acc[1]);
-          acc[2] = fmaf(e.w[k], t.z, acc[2]); acc[3] = fmaf(e.w[k], t.w, acc[3]);
-        } else {
-          acc[0] = fmaf(e.w[k], ip[0], acc[0]);
-        }
+    for (int k = 0; k < COUNT; ++k) {
+      const float* ip = e.in[k].p + vox_addr(e.in[k], n, z, y, x) + c0;
+      if (VEC == 4) tv4[k] = *reinterpret_cast<const float4*>(ip);
+      else ts[k] = ip[0];
+    }
+#pragma unroll
+    for (int k = 0; k < COUNT; ++k) {
+      if (VEC == 4) {
+        acc[0] = fmaf(e.w[k], tv4[k].x, acc[0]); acc[1] = fmaf(e.w[k], tv4[k].y, acc[1]);
+        acc[2] = fmaf(e.w[k], tv4[k].z, acc[2]); acc[3] = fmaf(e.w[k], tv4[k].w, acc[3]);
+      } else {
+        acc[0] = fmaf(e.w[k], ts[k], acc[0]);
       }
     }
     if (VEC == 4) *reinterpret_cast<float4*>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -698,7 +704,15 @@ extern "C" int mmtta_lincomb(int count, const mmtta_tensor* const* in, const flo
   MMTTA_CHECK(is_cl(out), MMTTA_ERR_UNSUPPORTED, "lincomb: channels-last only");
   e.count = count; e.o = tv(out); e.accumulate = accumulate;
   const long long total = (long long)out->n * out->d * out->h * out->w * (v4 ? (out->c + 3) / 4 : out->c);
-  if (v4) hipLaunchKernelGGL(lincomb_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
-  else hipLaunchKernelGGL(lincomb_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
+  const dim3 grid(grid_for(total)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define MMTTA_LINCOMB(N) \
+  case N: if (v4) hipLaunchKernelGGL((lincomb_kernel<4, N>), grid, block, 0, st, e); \
+          else hipLaunchKernelGGL((lincomb_kernel<1, N>), grid, block, 0, st, e); break;
+  switch (count) {
+    MMTTA_LINCOMB(1) MMTTA_LINCOMB(2) MMTTA_LINCOMB(3) MMTTA_LINCOMB(4)
+    MMTTA_LINCOMB(5) MMTTA_LINCOMB(6) MMTTA_LINCOMB(7) MMTTA_LINCOMB(8)
+  }
+#undef MMTTA_LINCOMB
   return launch_status("lincomb");
 }

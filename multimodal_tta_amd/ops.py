@@ -32,16 +32,17 @@ class Workspace:
     """One grow-only scratch buffer per device, shared by split-K convs and weight gradients
     (stream ordered).  It must reach its final size before a graph capture starts."""
 
-    _buffers: Dict[Tuple[int, int], torch.Tensor] = {}
+    _buffers: Dict[Tuple[int, int, int], torch.Tensor] = {}
     frozen = False
-    slot = 0        # 0: main launch sequence; 1: the side stream of the weight gradients (engine.ConvLayer.wgrad)
+    slot = 0        # 0: main launch sequence; 1..: the side streams of the weight gradients (engine.ConvLayer.wgrad)
+    lane = 0        # runtimes that run concurrently on different streams (bench.py --lanes) keep separate scratch
 
     @classmethod
     def get(cls, nbytes: int, device: torch.device) -> torch.Tensor:
         """The scratch buffer of the current slot: kernels of the two streams run concurrently and must not share
         scratch."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        key = (idx, cls.slot)
+        key = (idx, cls.slot, cls.lane)
         buf = cls._buffers.get(key)
         if buf is None or buf.numel() < nbytes:
             if cls.frozen:

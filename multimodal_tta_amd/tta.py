@@ -107,6 +107,7 @@ class EntropyMinimizationTTA:
         self.rt = None
         self._graphs: Dict[Tuple, torch.cuda.CUDAGraph] = {}
         self._gen: Optional[torch.Generator] = None
+        self.lane = 0      # plugins that adapt different volumes concurrently (own stream each) take distinct lanes
 
     # ------------------------------------------------------------------ setup
     def setup(self, model: HipSegModel, device) -> "EntropyMinimizationTTA":
@@ -128,6 +129,7 @@ class EntropyMinimizationTTA:
     # ------------------------------------------------------------------ one step
     def _step_launches(self, x_cl: torch.Tensor, present: Optional[Sequence[bool]]) -> None:
         rt, ar = self.rt, self.rt.arena
+        ops.Workspace.lane = self.lane
         rt.training = True
         rt.pack_all()
         logits = rt.forward_cl(x_cl) if present is None else rt.forward_cl(x_cl, present=present)
@@ -203,6 +205,7 @@ class EntropyMinimizationTTA:
         if masked and self.moddrop_p > 0.0:
             rt.stage_input(drop_modality(x, base_present))
         rt.training = False
+        ops.Workspace.lane = self.lane
         rt.pack_all()
         logits_cl = (rt.forward_cl(x_cl, present=base_present) if wants_present else rt.forward_cl(x_cl))
         return {"logits_cl": logits_cl, "losses": loss_hist[:steps]}
