@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=1,
                     help="volumes adapted concurrently per GPU, each with its own weights, buffers, graph and stream "
                          "(episodic adaptation has no cross-volume state; one volume alone leaves most CUs waiting)")
+    ap.add_argument("--side-streams", type=int, default=None, help="side streams for the weight gradients (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -69,6 +70,8 @@ def build_cfg(args):
         ov += ["model.num_modalities=2", "model.num_classes=1"]
     if args.no_graph:
         ov += ["method.use_graph=false"]
+    if getattr(args, "side_streams", None) is not None:
+        ov += [f"method.side_streams={args.side_streams}"]
     cfg = compose(overrides=ov)
     shape = args.shape or ([128, 128, 128] if args.task == "brats" else [48, 144, 144])
     cfg["dataset"]["synthetic"]["shape"] = list(shape)

@@ -594,9 +594,16 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
     aoff[q] = (long long)n * a.asn + cz * a.asd + cy * a.ash + cx * a.asw + colc;
     wsp[q] = a.ws + ((long long)tile * MT + v) * a.Np + min(col, a.Np - 1);
   }
-  for (int kz = 0; kz < a.ksplit; ++kz) {
+  for (int kz = 0; kz < a.ksplit; kz += 4) {        // 4 splits x 4 rows = 16 independent loads per trip
+    float v[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s4[q] += wsp[q][kz * kstride];
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q][u] = wsp[q][(long long)min(kz + u, a.ksplit - 1) * kstride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s4[q] += kz + u < a.ksplit ? v[q][u] : 0.f;
   }
   float addv[4] = {0.f, 0.f, 0.f, 0.f}, oldv[4] = {0.f, 0.f, 0.f, 0.f};
   if (a.add) {
@@ -871,7 +878,7 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   const int wgs = g.tiles * ncolgroups;
   g.ksplit = 1;
   g.sps = g.nstages;
-  // measured on the U-Net (scripts/exp_split.sh, round 1): splitting below 384 workgroups up to ~512 is the optimum;
+  // measured on the U-Net (round 1 sweep of threshold / target): splitting below 384 workgroups up to ~512 is the optimum;
   // 1024 costs +6 %, 256 +2 %, no split-K +80 % of the step's conv time
   if (wgs < 384 && g.nstages > 1) {
     int want = (512 + wgs - 1) / wgs;

@@ -189,29 +189,68 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
 // The transpose goes through LDS so that both sides stay coalesced: reads run along cd, writes are runs of
 // `ntaps` consecutive floats per (cd, cg).  27 taps: one block = one cg x 64 cd;  1 tap: 32 cg x 32 cd.
 __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                             int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate) {
-  __shared__ float tile[64][28];
-  const int cg = blockIdx.x, cd0 = blockIdx.y * 64;
-  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-    const int cdl = i & 63, tap = i >> 6;
-    const int cd = cd0 + cdl;
-    float s = 0.f;
-    if (cd < Cd) {
-      const float* p = slab + ((long long)tap * CGp + cg) * CDp + cd;
-      const long long st = (long long)27 * CGp * CDp;
-      int sl = 0;
-      float s4[4] = {0.f, 0.f, 0.f, 0.f};
-      for (; sl + 4 <= nsl; sl += 4) {
+                                                             int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate,
+                                                             const float* __restrict__ dbpart, float* __restrict__ db,
+                                                             int db_nsl) {
+  __shared__ float tile[32][28];
+  const int cd0 = blockIdx.y * 32;
+  if ((int)blockIdx.x == Cg) {
+    // bias gradient rows ride in the same launch: db[cd] (+)= sum_sl dbpart[sl][cd]; 8 threads per channel
+    const int cdl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int cd = min(cd0 + cdl, Cd - 1);
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int sl = part; sl < db_nsl; sl += 32) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s4[u] += p[(sl + u) * st];
+      for (int u = 0; u < 4; ++u) {
+        const int q = sl + 8 * u;
+        const float v = dbpart[(long long)min(q, db_nsl - 1) * CDp + cd];
+        s4[u] += q < db_nsl ? v : 0.f;
       }
-      for (; sl < nsl; ++sl) s4[0] += p[sl * st];
-      s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
-    tile[cdl][tap] = s;
+    float* red = &tile[0][0];
+    red[threadIdx.x] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    __syncthreads();
+    if (threadIdx.x < 32 && cd0 + (int)threadIdx.x < Cd) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q * 32 + threadIdx.x];
+      float* o = db + cd0 + threadIdx.x;
+      *o = accumulate ? (*o + t) : t;
+    }
+    return;
+  }
+  // one block = one cg x 32 cd x 27 taps = 864 sums: up to 4 per thread, all advancing together through the slabs
+  // (4 slabs x 4 items = 16 independent loads per trip, unconditional from clamped addresses)
+  const int cg = blockIdx.x;
+  const long long st = (long long)27 * CGp * CDp;
+  const float* pit[4];
+  bool live[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = threadIdx.x + 256 * it;
+    const int cdl = i & 31, tap = min(i >> 5, 26);
+    live[it] = i < 27 * 32 && cd0 + cdl < Cd;
+    pit[it] = slab + ((long long)tap * CGp + cg) * CDp + min(cd0 + cdl, CDp - 1);
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < nsl; sl += 4) {
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) v[it][u] = pit[it][(long long)min(sl + u, nsl - 1) * st];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) acc[it] += sl + u < nsl ? v[it][u] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = threadIdx.x + 256 * it;
+    if (i < 27 * 32) tile[i & 31][i >> 5] = live[it] ? acc[it] : 0.f;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+  for (int i = threadIdx.x; i < 27 * 32; i += 256) {
     const int cdl = i / 27, tap = i % 27;
     const int cd = cd0 + cdl;
     if (cd < Cd) {
@@ -250,14 +289,15 @@ __global__ __launch_bounds__(256) void slab_prereduce_kernel(const float* __rest
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= elems) return;
   const int s0 = blockIdx.y * 32, s1 = min(nsl, s0 + 32);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int sl = s0;
-  for (; sl + 4 <= s1; sl += 4) {
-    a0 += slab[(long long)sl * elems + e]; a1 += slab[(long long)(sl + 1) * elems + e];
-    a2 += slab[(long long)(sl + 2) * elems + e]; a3 += slab[(long long)(sl + 3) * elems + e];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int sl = s0; sl < s1; sl += 8) {          // 8 independent loads per trip (clamped, masked)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slab[(long long)min(sl + u, s1 - 1) * elems + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += sl + u < s1 ? v[u] : 0.f;
   }
-  for (; sl < s1; ++sl) a0 += slab[(long long)sl * elems + e];
-  out[(long long)blockIdx.y * elems + e] = (a0 + a1) + (a2 + a3);
+  out[(long long)blockIdx.y * elems + e] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
 // db[c] (+)= sum_sl part[sl*ld + c]: one wave per channel, lanes stride the partial rows
@@ -1066,9 +1106,10 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
     if (st) return st;
     rsrc = pre; rn = w.pre_chunks;
   }
+  const bool db_here = db != nullptr && !w.convt;      // bias partials written by the main kernel: [nsl][CDp]
   if (w.ntaps == 27)
-    hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3(a.Cg, (a.Cd + 63) / 64), dim3(256), 0, s, rsrc, dw, rn, a.Cg, a.Cd,
-                       w.CGp, w.CDp, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3(a.Cg + (db_here ? 1 : 0), (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
+                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, dbws, db, w.nsl);
   else
     hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((a.Cg + 31) / 32, (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
                        a.Cg, a.Cd, w.CGp, w.CDp, accumulate);
@@ -1076,7 +1117,8 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   if (st) return st;
   if (db != nullptr) {
     if (!w.convt) {
-      hipLaunchKernelGGL(db_reduce_kernel, dim3(a.Cd), dim3(64), 0, s, dbws, db, w.nsl, a.Cd, w.CDp, accumulate);
+      if (w.ntaps != 27)
+        hipLaunchKernelGGL(db_reduce_kernel, dim3(a.Cd), dim3(64), 0, s, dbws, db, w.nsl, a.Cd, w.CDp, accumulate);
     } else {
       // ConvTranspose3d bias gradient = per-channel sum of dy over the fine grid
       st = launch_channel_sums(dy, dbws, s);
