@@ -233,9 +233,17 @@ def main():
         name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         peak = mfma_peak(name)
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this build
+        # (scripts/pmc_layers.sh -> scripts/pmc_summary.py --json; FETCH_SIZE x2 on gfx950 + WRITE_SIZE), else null
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath)).get(name)
+            if t:
+                traffic = t["fetch_bytes"] + t["write_bytes"]
         out["roofline"] = {
             "bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": None,
+            "frac": achieved / peak, "traffic": traffic,
             "avg_launch_us": 1000.0 * d["ms"] / d["launches"], "launches": d["launches"],
             "flops_per_launch": d["flops"] / d["launches"],
             "share_of_conv_time": d["ms"] / total_ms,

@@ -351,6 +351,8 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
 // partial sum per kx and dropping the invalid ones at the end.  The input gradient is the same loop with the tap
 // index mirrored (26 - tap).
 typedef const __attribute__((address_space(4))) float cfloat;
+typedef float cf16 __attribute__((ext_vector_type(16)));
+typedef float cf4 __attribute__((ext_vector_type(4)));
 
 template <int KI, int NO, bool HAS_T>
 __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
@@ -430,13 +432,14 @@ __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
           const int t = (dz * 3 + dy) * 3 + dx;
           cfloat* wt = wc + (a.transposed ? 26 - t : t) * KI * 4;
 #pragma unroll
-          for (int k = 0; k < KI; ++k)
+          for (int k = 0; k < KI; ++k) {
+            const cf4 wv = *reinterpret_cast<const __attribute__((address_space(4))) cf4*>(wt + k * 4);   // one s_load_dwordx4
 #pragma unroll
             for (int c = 0; c < NO; ++c) {
-              const float w = wt[k * 4 + c];
-              acc[0][dx][c] = fmaf(xs[dy][dx][k], w, acc[0][dx][c]);
-              acc[1][dx][c] = fmaf(xs[dy + 1][dx][k], w, acc[1][dx][c]);
+              acc[0][dx][c] = fmaf(xs[dy][dx][k], wv[c], acc[0][dx][c]);
+              acc[1][dx][c] = fmaf(xs[dy + 1][dx][k], wv[c], acc[1][dx][c]);
             }
+          }
         }
     }
 #pragma unroll
@@ -530,10 +533,13 @@ __global__ __launch_bounds__(256) void direct_upconv_kernel(DArgs a) {
           for (int k4 = 0; k4 < K / 4; ++k4) {
             const float4 x4 = *reinterpret_cast<const float4*>(xv + 4 * k4);
             const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+            // the 4 x 4 weights of this channel group as ONE 64-byte scalar load (element-wise indexing makes the
+            // compiler fetch the NO used dwords of every row separately: 8x the scalar-memory instructions)
+            const cf16 wv = *reinterpret_cast<const __attribute__((address_space(4))) cf16*>(wt + 16 * k4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-              for (int c = 0; c < NO; ++c) acc[c] = fmaf(xs[j], wt[(4 * k4 + j) * 4 + c], acc[c]);
+              for (int c = 0; c < NO; ++c) acc[c] = fmaf(xs[j], wv[j * 4 + c], acc[c]);
           }
         }
       }

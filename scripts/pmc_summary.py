@@ -15,7 +15,24 @@ def short(name):
     return name.replace("mmtta::", "")
 
 
+def bench_name(k):
+    """Trace kernel name -> the name bench.py's profiler uses (ops.IGEMM_KERNELS / WGRAD_KERNELS)."""
+    k = k.replace(" ", "")
+    m = re.match(r"igemm_kernel<(.*),(true|false)>$", k)
+    if m:
+        return f"igemm_kernel<{m.group(1)},bf16>" if m.group(2) == "true" else f"igemm_f32_kernel<{m.group(1)}>"
+    m = re.match(r"wgrad_f32_kernel<(\d+),(\d+),(\d+),(\d+)>$", k)
+    if m:
+        return k
+    return re.sub(r"<.*>$", "", k) if k.startswith(("wgrad_small", "wgrad_tiny")) else k
+
+
 def main(paths):
+    json_out = None
+    if "--json" in paths:
+        i = paths.index("--json")
+        json_out = paths[i + 1]
+        paths = paths[:i] + paths[i + 2:]
     vals = defaultdict(lambda: defaultdict(float))   # kernel -> counter -> sum over dispatches (and over SE instances)
     calls = defaultdict(lambda: defaultdict(set))
     dur = defaultdict(lambda: [0, 0])
@@ -39,6 +56,19 @@ def main(paths):
             n = len(calls[k][c])
             row.append(f"{vals[k][c] / n:.4g}" if n else "-")
         print(" | ".join(row))
+    if json_out:
+        import json
+        out = {}
+        for k in vals:
+            f, w = vals[k].get("FETCH_SIZE"), vals[k].get("WRITE_SIZE")
+            if f is None and w is None:
+                continue
+            nf, nw = len(calls[k]["FETCH_SIZE"]) or 1, len(calls[k]["WRITE_SIZE"]) or 1
+            # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies a 128-byte read request as 64 bytes: reads x2
+            # (MI355X_MICROARCH.md, HBM section)
+            out[bench_name(k)] = {"fetch_bytes": (f or 0.0) / nf * 1024.0 * 2.0, "write_bytes": (w or 0.0) / nw * 1024.0,
+                                  "launches_averaged": int(dur[k][0] // max(1, len(paths)))}
+        json.dump(out, open(json_out, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
