@@ -155,6 +155,11 @@ int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s);  // 
 extern int g_profile_main_only;     // api.hip: mmtta_set_option(MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY)
 bool direct_applicable(const mmtta_conv_desc* d);
 int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);
+bool chan_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);
+int chan_tiles_per_n(const mmtta_tensor* y);
+int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed, int Kp,
+                  int Np, const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
+                  hipStream_t stream);
 int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed,
                     const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
                     hipStream_t stream);

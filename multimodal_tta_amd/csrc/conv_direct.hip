@@ -570,6 +570,179 @@ static bool aligned16(const mmtta_tensor* x) {
   return x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0 && ((uintptr_t)x->ptr) % 16 == 0;
 }
 
+// ------------------------------------------------------------------ lanes along N (K <= 4 gathered, N = 32 / 64)
+// The first layers (Conv3d 4->32 k3 s2 and its strided residual conv) and the input gradient of the last
+// up-convolution (ConvTranspose3d 64->R: a stride-2 gather of R = 3 channels into 64).  Their whole reduction is
+// 27 taps x <= 4 channels, so a lane owns ONE output channel and keeps its 27 x KI weights in registers; the
+// input halo box of a 4x4x8 output tile (16-byte voxels) sits in LDS and is read by broadcast (every lane of a
+// voxel's group reads the same 16 bytes); one coalesced store per voxel; the statistics of the following norm are
+// plain per-lane sums.  On the fp32 matrix cores these layers ran with 4 of 8 staged channels empty.
+struct CArgs {
+  TV in; NL tin;
+  TV out;
+  const float* w; int Kp, Np;     // implicit-GEMM fp32 image [27][Kp][Np]
+  const float* bias;
+  const float* add; long long asn, asd, ash, asw; NL tadd;
+  int accumulate;
+  float* stats; int tiles_per_n;
+  int tz, ty, tx;
+};
+
+template <int S, int KI, int NLN, bool HAS_T>
+__global__ __launch_bounds__(256) void direct_chan_kernel(CArgs a) {
+  constexpr int TZ = 4, TY = 4, TX = 8;
+  constexpr int BZ = (TZ - 1) * S + 3, BY = (TY - 1) * S + 3, BX = (TX - 1) * S + 3, BOX = BZ * BY * BX;
+  constexpr int VP = 64 / NLN, NPASS = 32 / VP;          // voxels per pass, passes per wave (32 voxels per wave)
+  __shared__ float4 box[BOX];
+  __shared__ float red[2][4][NLN];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int tile_in_n = t % a.tiles_per_n;
+  const int txi = t % a.tx; t /= a.tx;
+  const int tyi = t % a.ty; t /= a.ty;
+  const int tzi = t % a.tz;
+  const int n = t / a.tz;
+  const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
+  const int iz0 = oz0 * S - 1, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill
+    constexpr int NQ = (BOX + 255) / 256;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_T) nl_coeff_vec<4>(a.tin, n, KI, 0, sc, sh);
+    const float* inb = a.in.p + (long long)n * a.in.sn;
+    float4 raw[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int bv = min(tid + 256 * q, BOX - 1);
+      const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+      const int iz = min(max(iz0 + bz, 0), a.in.d - 1), iy = min(max(iy0 + by, 0), a.in.h - 1), ix = min(max(ix0 + bx, 0), a.in.w - 1);
+      raw[q] = *reinterpret_cast<const float4*>(inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int bv = tid + 256 * q;
+      if (bv < BOX) {
+        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+        const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
+        const float r4[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[k] = (ok && k < KI) ? (HAS_T ? nl_apply(r4[k], sc[k], sh[k], a.tin.relu) : r4[k]) : 0.f;
+        box[bv] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  // ---- this lane's output channel and its weights
+  const int nl = lane % NLN, vslot = lane / NLN;
+  const int N = a.out.c;
+  const bool nok = nl < N;
+  float w[27][KI];
+  {
+    const float* wp = a.w + min(nl, a.Np - 1);
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp)
+#pragma unroll
+      for (int k = 0; k < KI; ++k) w[tp][k] = wp[((long long)tp * a.Kp + k) * a.Np];
+  }
+  float bias = 0.f, asc = 1.f, ash = 0.f;
+  if (a.bias) bias = a.bias[min(nl, N - 1)];
+  if (a.add) nl_coeff(a.tadd, n, N, min(nl, N - 1), asc, ash);
+  __syncthreads();
+  float ssum = 0.f, ssq = 0.f;
+#pragma unroll 2
+  for (int p = 0; p < NPASS; ++p) {
+    const int vloc = wave * 32 + p * VP + vslot;
+    const int xl = vloc % TX, yl = (vloc / TX) % TY, zl = vloc / (TX * TY);
+    const float4* bp = box + ((zl * S) * BY + yl * S) * BX + xl * S;
+    float acc = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float4 x4 = bp[(dz * BY + dy) * BX + dx];
+          const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+          for (int k = 0; k < KI; ++k) acc = fmaf(xs[k], w[(dz * 3 + dy) * 3 + dx][k], acc);
+        }
+    const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
+    if (nok && oz < a.out.d && oy < a.out.h && ox < a.out.w) {
+      float val = acc + bias;
+      if (a.add) val += nl_apply(a.add[(long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash + (long long)ox * a.asw + nl], asc, ash, a.tadd.relu);
+      float* op = a.out.p + (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh + (long long)ox * a.out.sw + nl;
+      if (a.accumulate) val += *op;
+      *op = val;
+      ssum += val; ssq += val * val;
+    }
+  }
+  if (a.stats != nullptr) {
+    if (NLN == 32) { ssum += __shfl_xor(ssum, 32, 64); ssq += __shfl_xor(ssq, 32, 64); }
+    if (lane < NLN) { red[0][wave][lane] = ssum; red[1][wave][lane] = ssq; }
+    __syncthreads();
+    if (tid < NLN && tid < N) {
+      const float s0 = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+      const float s1 = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+      const long long row = (long long)n * a.tiles_per_n + tile_in_n;
+      a.stats[(row * 2 + 0) * N + tid] = s0;
+      a.stats[(row * 2 + 1) * N + tid] = s1;
+    }
+  }
+}
+
+bool chan_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y) {
+  if (!(d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_DGRAD) || d->ksize != 3) return false;
+  const int K = x->c, N = y->c;
+  // N = 64 (one voxel per pass) measured slower than the fp32 implicit GEMM (109 vs 80 us on the 64->3 up-convolution's
+  // input gradient: 27 LDS reads per voxel and wave); kept for N = 32, two voxels per pass
+  return K <= 4 && N == 32 && aligned16(x) && x->sw >= 4;
+}
+
+int chan_tiles_per_n(const mmtta_tensor* y) { return ((y->d + 3) / 4) * ((y->h + 3) / 4) * ((y->w + 7) / 8); }
+
+template <int S, int KI, bool HAS_T>
+static void launch_chan_n(const CArgs& a, int N, int blocks, hipStream_t s) {
+  if (N == 64) hipLaunchKernelGGL((direct_chan_kernel<S, KI, 64, HAS_T>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((direct_chan_kernel<S, KI, 32, HAS_T>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+template <int S, bool HAS_T>
+static void launch_chan_k(const CArgs& a, int K, int N, int blocks, hipStream_t s) {
+  switch (K) {
+    case 1: launch_chan_n<S, 1, HAS_T>(a, N, blocks, s); break;
+    case 2: launch_chan_n<S, 2, HAS_T>(a, N, blocks, s); break;
+    case 3: launch_chan_n<S, 3, HAS_T>(a, N, blocks, s); break;
+    default: launch_chan_n<S, 4, HAS_T>(a, N, blocks, s); break;
+  }
+}
+
+int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed, int Kp,
+                  int Np, const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
+                  hipStream_t stream) {
+  CArgs a;
+  a.in = tv(x); a.tin = nl(x_norm); a.out = tv(y);
+  a.w = (const float*)packed; a.Kp = Kp; a.Np = Np; a.bias = bias;
+  a.add = nullptr; a.asn = a.asd = a.ash = a.asw = 0; a.tadd = nl(nullptr);
+  if (epi && epi->add) {
+    const mmtta_tensor* ad = epi->add;
+    MMTTA_CHECK(ad->ptr && is_cl(ad) && ad->n == y->n && ad->c == y->c && ad->d == y->d && ad->h == y->h && ad->w == y->w,
+                MMTTA_ERR_INVALID, "conv: epilogue `add` must be channels-last with the shape of y");
+    a.add = (const float*)ad->ptr; a.asn = ad->sn; a.asd = ad->sd; a.ash = ad->sh; a.asw = ad->sw;
+    a.tadd = nl(&epi->add_norm);
+  }
+  a.accumulate = accumulate; a.stats = stats;
+  a.tz = (y->d + 3) / 4; a.ty = (y->h + 3) / 4; a.tx = (y->w + 7) / 8;
+  a.tiles_per_n = a.tz * a.ty * a.tx;
+  const int blocks = a.tiles_per_n * y->n;
+  const bool has_t = a.tin.mean != nullptr || a.tin.scale != nullptr;
+  const int S = d->op == MMTTA_CONV_FWD ? d->stride : 2;       // CONVT_DGRAD: stride-2 gather
+  if (S == 1) { if (has_t) launch_chan_k<1, true>(a, x->c, y->c, blocks, stream); else launch_chan_k<1, false>(a, x->c, y->c, blocks, stream); }
+  else { if (has_t) launch_chan_k<2, true>(a, x->c, y->c, blocks, stream); else launch_chan_k<2, false>(a, x->c, y->c, blocks, stream); }
+  return launch_status("direct conv (lanes along N)");
+}
+
 // 0: thread per voxel (any shape); 1: lanes along K (K = 32 or 64); 2: row kernel (K <= 4, k3 s1);
 // 3: LDS-staged stride-2 up-convolution (ConvTranspose3d forward, K = 32 or 64)
 static int direct_variant(const mmtta_conv_desc* d, const mmtta_tensor* x) {

@@ -1087,6 +1087,16 @@ extern "C" int mmtta_conv_plan(const mmtta_conv_desc* d, const mmtta_tensor* x, 
     plan->workspace_bytes = 0;
     return MMTTA_OK;
   }
+  if (chan_applicable(d, x, y) && !use_bf16(d, g.K)) {
+    plan->tiles = chan_tiles_per_n(y) * y->n;
+    plan->launches = 1;
+    plan->ksplit = 1;
+    plan->stats_rows = plan->tiles;
+    plan->config = 13;
+    plan->_pad = 0;
+    plan->workspace_bytes = 0;
+    return MMTTA_OK;
+  }
   plan->tiles = g.tiles;
   plan->launches = g.launches;
   plan->ksplit = g.ksplit;
@@ -1107,6 +1117,8 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   if (st) return st;
   MMTTA_CHECK(packed != nullptr, MMTTA_ERR_INVALID, "conv: null packed weights");
   if (direct_applicable(d)) return direct_conv_run(d, x, x_norm, packed, bias, epi, y, accumulate, stats, (hipStream_t)stream);
+  if (chan_applicable(d, x, y) && !use_bf16(d, g.K))
+    return chan_conv_run(d, x, x_norm, packed, g.Kp, g.Np, bias, epi, y, accumulate, stats, (hipStream_t)stream);
   const int64_t need = g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * 4 : 0;
   MMTTA_CHECK(need == 0 || (workspace != nullptr && workspace_bytes >= need), MMTTA_ERR_WORKSPACE,
               "conv: workspace %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
