@@ -340,7 +340,7 @@ struct WBGeo {
 };
 
 template <int TZ, int TY, int SI>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WArgs a) {   // two workgroups per CU (LDS allows two)
   using G = WBGeo<TZ, TY, SI>;
   extern __shared__ float lds[];
   unsigned char* lb = reinterpret_cast<unsigned char*>(lds);
@@ -370,42 +370,79 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WArgs a) {
   const int t0 = blockIdx.x * a.tiles_per_split;
   const int t1 = min(a.tiles, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
-  for (int tile = t0; tile < t1; ++tile) {
-    const int n = tile / tpn;
+  // Software pipeline over the tiles of this workgroup: the global loads of tile i+1 (the whole D tile and the first
+  // RB box rows per thread - all of them for stride 1) are issued right after tile i's LDS image is complete and land
+  // while its MFMAs run (the MFMA loop reads LDS only, so no vmcnt wait sits in between).  Loads are unconditional
+  // from clamped addresses and masked at commit time (a load inside a branch is waited for on the spot).
+  constexpr int ND = (G::NXR + 7) / 8;          // D x-rows per thread
+  constexpr int RB = SI == 1 ? 5 : 2;           // G box rows per thread and trip
+  const int gc = cg0 + cs, dc = cd0 + cs;
+  const bool gcok = gc < a.Cg, dcok = dc < a.Cd;
+  float gv[RB][G::NX], dv[ND][8];
+  float gsc = 0.f, gsh = 0.f, dsc = 0.f, dsh = 0.f;
+  int pn = 0, poz0 = 0, poy0 = 0, pox0 = 0;     // coordinates of the tile whose loads are in gv / dv
+
+  auto issue = [&](int tile) {
+    pn = tile / tpn;
     int t = tile % tpn;
     const int txi = t % a.tx; t /= a.tx;
     const int tyi = t % a.ty;
     const int tzi = t / a.ty;
-    const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * 8;
-    const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
-    // ---- D tile loads go out first, together with the first G trip (one exposed latency, not two)
-    constexpr int ND = (G::NXR + 7) / 8;          // x-rows per thread
-    float dv[ND][8];
-    float dsc = 0.f, dsh = 0.f;
-    const int dc = cd0 + cs;
-    const bool dcok = dc < a.Cd;
-    {
-      nl_coeff_vec<1>(a.td, n, a.Cd, dc, &dsc, &dsh);
-      const float* db = a.dn + (long long)n * a.dsn + min(dc, a.Cd - 1);
+    poz0 = tzi * TZ; poy0 = tyi * TY; pox0 = txi * 8;
+    const int iz0 = poz0 * SI - 1, iy0 = poy0 * SI - 1, ix0 = pox0 * SI - 1;
+    nl_coeff_vec<1>(a.td, pn, a.Cd, dc, &dsc, &dsh);
+    nl_coeff_vec<1>(a.tg, pn, a.Cg, gc, &gsc, &gsh);
+    const float* db = a.dn + (long long)pn * a.dsn + min(dc, a.Cd - 1);
 #pragma unroll
-      for (int q = 0; q < ND; ++q) {
-        const int xr = min((tid >> 5) + 8 * q, G::NXR - 1);
-        const float* rp = db + (long long)min(oz0 + xr / TY, a.Dd - 1) * a.dsd + (long long)min(oy0 + xr % TY, a.Hd - 1) * a.dsh;
+    for (int q = 0; q < ND; ++q) {
+      const int xr = min((tid >> 5) + 8 * q, G::NXR - 1);
+      const float* rp = db + (long long)min(poz0 + xr / TY, a.Dd - 1) * a.dsd + (long long)min(poy0 + xr % TY, a.Hd - 1) * a.dsh;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) dv[q][x] = rp[(long long)min(ox0 + x, a.Wd - 1) * a.dsw];
+      for (int x = 0; x < 8; ++x) dv[q][x] = rp[(long long)min(pox0 + x, a.Wd - 1) * a.dsw];
+    }
+    const float* gb = a.g + (long long)pn * a.gsn + min(gc, a.Cg - 1);
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int row = min((tid >> 5) + 8 * q, G::RG - 1);
+      const int bz = row / G::BYr, by = row % G::BYr;
+      const float* rp = gb + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd + (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
+#pragma unroll
+      for (int x = 0; x < G::NX; ++x) gv[q][x] = rp[(long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw];
+    }
+  };
+  // transform + pack + LDS write of RB box rows starting at row0 (values in v)
+  auto commit_g = [&](float (&v)[RB][G::NX], int row0, int iz0, int iy0, int ix0) {
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int row = row0 + 8 * q;
+      if (row < G::RG) {
+        const int bz = row / G::BYr, by = row % G::BYr;
+        const int iz = iz0 + bz, iy = iy0 + by;
+        const bool rok = gcok && (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg;
+#pragma unroll
+        for (int x = 0; x < G::NX; ++x) {
+          const int ix = ix0 + x;
+          v[q][x] = (rok && (unsigned)ix < (unsigned)a.Wgg) ? nl_apply(v[q][x], gsc, gsh, a.tg.relu) : 0.f;
+        }
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+          uint4 pk;
+          pk.x = wpack2(v[q][0 * SI + dxi], v[q][1 * SI + dxi]); pk.y = wpack2(v[q][2 * SI + dxi], v[q][3 * SI + dxi]);
+          pk.z = wpack2(v[q][4 * SI + dxi], v[q][5 * SI + dxi]); pk.w = wpack2(v[q][6 * SI + dxi], v[q][7 * SI + dxi]);
+          *reinterpret_cast<uint4*>(gl + dxi * G::COPY + cs * G::CHS_G + row * 16) = pk;
+        }
       }
     }
-    {  // ---- G box: thread = (channel, box row); builds the three x-shifted 8-voxel copies
-      // Every load is issued unconditionally from a clamped (always valid) address and masked afterwards (a load
-      // inside a branch is followed by its own s_waitcnt, which serialises the round trips), RB box rows at a
-      // time: RB*NX loads in flight per thread.
-      const int c = cg0 + cs;
-      float sc = 0.f, sh = 0.f;
-      const bool cok = c < a.Cg;
-      nl_coeff_vec<1>(a.tg, n, a.Cg, c, &sc, &sh);
-      const float* gb = a.g + (long long)n * a.gsn + min(c, a.Cg - 1);
-      constexpr int RB = SI == 1 ? 5 : 2;
-      for (int row0 = tid >> 5; row0 < G::RG; row0 += 8 * RB) {
+  };
+
+  if (t0 < t1) issue(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+    const int n = pn, oz0 = poz0, oy0 = poy0, ox0 = pox0;
+    const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
+    commit_g(gv, tid >> 5, iz0, iy0, ix0);                       // the prefetched trip
+    if (8 * RB < G::RG) {                                        // stride 2: the remaining box rows, RB at a time
+      const float* gb = a.g + (long long)n * a.gsn + min(gc, a.Cg - 1);
+      for (int row0 = (tid >> 5) + 8 * RB; row0 < G::RG; row0 += 8 * RB) {
         float v[RB][G::NX];
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
@@ -416,27 +453,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WArgs a) {
 #pragma unroll
           for (int x = 0; x < G::NX; ++x) v[q][x] = rp[(long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw];
         }
-#pragma unroll
-        for (int q = 0; q < RB; ++q) {
-          const int row = row0 + 8 * q;
-          if (row < G::RG) {
-            const int bz = row / G::BYr, by = row % G::BYr;
-            const int iz = iz0 + bz, iy = iy0 + by;
-            const bool rok = cok && (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg;
-#pragma unroll
-            for (int x = 0; x < G::NX; ++x) {
-              const int ix = ix0 + x;
-              v[q][x] = (rok && (unsigned)ix < (unsigned)a.Wgg) ? nl_apply(v[q][x], sc, sh, a.tg.relu) : 0.f;
-            }
-#pragma unroll
-            for (int dxi = 0; dxi < 3; ++dxi) {
-              uint4 pk;
-              pk.x = wpack2(v[q][0 * SI + dxi], v[q][1 * SI + dxi]); pk.y = wpack2(v[q][2 * SI + dxi], v[q][3 * SI + dxi]);
-              pk.z = wpack2(v[q][4 * SI + dxi], v[q][5 * SI + dxi]); pk.w = wpack2(v[q][6 * SI + dxi], v[q][7 * SI + dxi]);
-              *reinterpret_cast<uint4*>(gl + dxi * G::COPY + cs * G::CHS_G + row * 16) = pk;
-            }
-          }
-        }
+        commit_g(v, row0, iz0, iy0, ix0);
       }
     }
     {  // ---- D tile: thread = (channel, x-row)
@@ -459,6 +476,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WArgs a) {
       }
     }
     __syncthreads();
+    if (tile + 1 < t1) issue(tile + 1);                          // lands during the MFMAs below
 #pragma unroll 2
     for (int ks = 0; ks < G::NXR / 2; ++ks) {
       const int xr = 2 * ks + h;
