@@ -218,3 +218,31 @@ def test_bf16_precision_tracks_the_fp32_oracle(lr):
         assert err < 3e-2 and mism <= 1e-2 and ddice <= 2e-2
     else:
         assert ddice <= 5e-2
+
+
+def test_concurrent_lanes_equal_sequential_runs():
+    """Two plugin instances adapting different volumes on two streams at the same time (bench.py --lanes 2) use
+    separate scratch / side streams / graphs: each must return bitwise what it returns when run alone."""
+    from multimodal_tta_amd.models import UNet
+    from multimodal_tta_amd.registry import get_plugin
+
+    cfg = root_cfg(SMALL, steps=3)
+    ref, hip_a = build_pair(SMALL)
+    hip_b = UNet(SMALL)
+    hip_b.load_state_dict(ref.state_dict())
+    pa = get_plugin("entmin_tta")(cfg).setup(hip_a, "cuda")
+    pb = get_plugin("entmin_tta")(cfg)
+    pb.lane = 1
+    pb.setup(hip_b, "cuda")
+    xa, xb = volume(11)[0].cuda(), volume(12)[0].cuda()
+    za = pa.logits(pa.adapt_volume(xa)).clone()          # alone (this also captures the graphs)
+    zb = pb.logits(pb.adapt_volume(xb)).clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(2):
+        with torch.cuda.stream(sa):
+            ra = pa.adapt_volume(xa)
+        with torch.cuda.stream(sb):
+            rb = pb.adapt_volume(xb)
+        torch.cuda.synchronize()
+        assert torch.equal(pa.logits(ra), za) and torch.equal(pb.logits(rb), zb)
