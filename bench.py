@@ -257,6 +257,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()            # rank 0 may still have been in its profile pass
         dist.destroy_process_group()
 
 
