@@ -707,17 +707,18 @@ __device__ __forceinline__ void pack_tile(const PackEntry& e, int lb, float* til
     for (int idx = threadIdx.x; idx < PN * PK * T; idx += 256) {
       const int nn = idx / (PK * T), r = idx % (PK * T);
       const int kk = r / T;
-      float v = 0.f;
-      if (n0 + nn < N && k0 + kk < K) v = e.w[((long long)(n0 + nn) * e.B + k0) * T + r];
-      tile[nn * RS + r] = v;
+      // unconditional load from a clamped address, masked afterwards (a load behind a branch is waited for at once)
+      const bool ok = n0 + nn < N && k0 + kk < K;
+      const float v = e.w[((long long)min(n0 + nn, N - 1) * e.B + min(k0 + kk, K - 1)) * T + (r - kk * T)];
+      tile[nn * RS + r] = ok ? v : 0.f;
     }
   } else {                                       // a = k, b = n: per k a run of PN*T contiguous floats
     for (int idx = threadIdx.x; idx < PK * PN * T; idx += 256) {
       const int kk = idx / (PN * T), r = idx % (PN * T);
       const int nn = r / T;
-      float v = 0.f;
-      if (k0 + kk < K && n0 + nn < N) v = e.w[((long long)(k0 + kk) * e.B + n0) * T + r];
-      tile[kk * (PN * T) + r] = v;
+      const bool ok = k0 + kk < K && n0 + nn < N;
+      const float v = e.w[((long long)min(k0 + kk, K - 1) * e.B + min(n0 + nn, N - 1)) * T + (r - nn * T)];
+      tile[kk * (PN * T) + r] = ok ? v : 0.f;
     }
   }
   __syncthreads();
