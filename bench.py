@@ -230,6 +230,18 @@ def main():
         ops.PROFILER = None
         summ = prof.summary()
         total_ms = sum(d["ms"] for d in summ.values())
+        # algorithmic conv FLOPs of one adapted volume from the same pass (2 steps + 1 final forward were recorded)
+        per_kind = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+        for rname, _launches, rflops, _e0, _e1, detail in prof.records:
+            kind = detail.split(" ")[0]
+            kind = "fwd" if kind.startswith("fwd") else ("dgrad" if kind.startswith("dgrad") else "wgrad")
+            per_kind[kind] += rflops / prof.reps
+        f_fwd = per_kind["fwd"] / 3.0
+        f_vol = args.tta_steps * (f_fwd + per_kind["dgrad"] / 2.0 + per_kind["wgrad"] / 2.0) + f_fwd
+        eff = f_vol / (elapsed / (args.steps * world) * world) / 1e12     # per GPU: one volume's FLOPs / its wall time
+        out["config"]["algorithmic_conv_tflop_per_volume"] = f_vol / 1e12
+        whole = {"effective_tflops_per_gpu": eff,
+                 "frac_of_mfma_peak": eff / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS)}
         name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         peak = mfma_peak(name)
@@ -251,6 +263,7 @@ def main():
                                      "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / mfma_peak(k), "ms": v["ms"],
                                      "launches": v["launches"]} for k, v in sorted(summ.items())},
             "conv_tflops_overall": sum(v["flops"] for v in summ.values()) / (total_ms * 1e-3) / 1e12,
+            "whole_volume": whole,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, shape, args.tta_steps)

@@ -159,6 +159,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
 
   for (int ks = ks0; ks < ks1; ++ks) {
     const int c0 = ks * KCI;
+    // the first group of weight fragments of this stage is requested before the staging pass, so its L2 round trip
+    // hides behind the box loads instead of opening the MFMA phase (full 27-tap stages of the bf16 path only)
+    constexpr int WG0 = BF ? (KCI == 16 ? 9 : 5) : 1;
+    constexpr int WKS = BF ? KCI / 16 : 1;
+    uint4 wfirst[WG0][WKS];
+    bool wfirst_ok = false;
+    if constexpr (BF) {
+      if (colact && ci.ntaps == 27 && ((min(KCI, a.Ci - c0) + 15) >> 4) == WKS) {   // same test as the MFMA section
+        wfirst_ok = true;
+        const uint4* wq0 = reinterpret_cast<const uint4*>(a.wp) + (long long)(c0 / 8 + h) * a.Np + colbase + r;
+        const long long slabsz8 = (long long)(a.Kp / 8) * a.Np;
+#pragma unroll
+        for (int t = 0; t < WG0; ++t)
+#pragma unroll
+          for (int k2 = 0; k2 < WKS; ++k2) wfirst[t][k2] = wq0[(a.slab + ci.tap0)[t] * slabsz8 + k2 * 2 * a.Np];
+      }
+    }
     // ---------------- stage the input box (KCI channels) into LDS ----------------
     if constexpr (BF) {
       unsigned short* lh = reinterpret_cast<unsigned short*>(lds);
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
         // trip instead of one per item)
         constexpr int STEP = 256 / CV8;
         // all of a thread's items in as few trips as the register budget allows: one exposed memory latency per trip
-        constexpr int U = MB == 4 ? 8 : 6;
+        constexpr int U = 4;
         const bool tail = (a.Ci & 7) != 0;       // only then can lanes beyond Ci hold uninitialised padding
         for (int bv0 = tid / CV8; bv0 < boxvox; bv0 += U * STEP) {
           float4 x0[U], x1[U];
@@ -308,11 +325,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
           // measured 15-18k cycles per stage against 3.5k cycles of MFMA).
           constexpr int G = KS == 1 ? 9 : 5;
           constexpr int NG = (27 + G - 1) / G;
+          static_assert(G == WG0 && KS == WKS, "first-group prefetch must match the group shape");
           uint4 wset[2][G][KS];
 #pragma unroll
           for (int t = 0; t < G; ++t)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wset[0][t][ks] = wcol[tslab[t] * slabsz8 + ks * np2];
+            for (int ks = 0; ks < KS; ++ks) wset[0][t][ks] = wfirst[t][ks];     // requested before the staging pass
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) {
