@@ -189,6 +189,22 @@ int mmtta_conv_wgrad(const mmtta_conv_desc* desc, const mmtta_tensor* x, const m
                      const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
                      int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ input pre-pass -------- */
+/* Per-channel intensity rule of one image [C,D,H,W] (reference src/datasets/transforms.py:129-223).
+ *   legacy != 0: y = (x - mean) / std                                            (:202-223)
+ *   else: optional clip to [lo,hi], then optional z-score with mean / std(unbiased=False, floor eps) taken over the
+ *   clipped voxels > mask_gt when `masked` and at least min_count of them exist, over all voxels otherwise (:163-198) */
+typedef struct {
+  int32_t clip, zscore, masked, min_count;
+  float lo, hi, mask_gt, eps;
+  float mean, std;
+  int32_t legacy, _pad;
+} mmtta_intensity_rule;
+int64_t mmtta_intensity_scratch_bytes(int channels);
+/* x, y: n == 1, NCDHW boundary layout (dense voxels per channel); rules: HOST array of x->c entries. */
+int mmtta_intensity_normalize(const mmtta_tensor* x, const mmtta_intensity_rule* rules, const mmtta_tensor* y,
+                              void* scratch, void* stream);
+
 /* ------------------------------------------------------------------ normalisation -------- */
 typedef enum {
   MMTTA_NORM_INSTANCE = 0, /* torch.nn.InstanceNorm3d(affine=False): statistics per (n,c)      */

@@ -43,10 +43,9 @@ def main(argv=None) -> dict:
     model = get_model(cfg.model.name)(cfg.model)
     weights = get_config(cfg, "model.weights", None)
     if weights:
-        # CheckpointHook format (reference src/core/hooks.py:55-62); DataParallel prefix stripped (:57)
-        ckpt = torch.load(weights, map_location="cpu", weights_only=True)
-        sd = ckpt.get("model_state_dict", ckpt)
-        model.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in sd.items()})
+        # CheckpointHook format (reference src/core/hooks.py:55-62); DataParallel prefix stripped
+        from multimodal_tta_amd.checkpoint import load_source_weights
+        load_source_weights(model, str(weights))
     model.to(device)
     # setup_data('test') (reference :164-196): builder lookup by task name with the "default" fallback (:120-124)
     tname = str(get_config(cfg, "task.name", "default"))

@@ -60,11 +60,19 @@ class ConvEpilogue(C.Structure):
     _fields_ = [("add", C.POINTER(Tensor)), ("add_norm", NormOnLoad)]
 
 
+class IntensityRule(C.Structure):      # mmtta_intensity_rule
+    _fields_ = [("clip", C.c_int32), ("zscore", C.c_int32), ("masked", C.c_int32), ("min_count", C.c_int32),
+                ("lo", C.c_float), ("hi", C.c_float), ("mask_gt", C.c_float), ("eps", C.c_float),
+                ("mean", C.c_float), ("std", C.c_float), ("legacy", C.c_int32), ("_pad", C.c_int32)]
+
+
 _P = C.POINTER
 _SIGNATURES = {
     "mmtta_last_error": (C.c_char_p, []),
     "mmtta_abi_version": (C.c_int, []),
     "mmtta_set_option": (C.c_int, [C.c_int, C.c_int]),
+    "mmtta_intensity_scratch_bytes": (C.c_int64, [C.c_int]),
+    "mmtta_intensity_normalize": (C.c_int, [_P(Tensor), _P(IntensityRule), _P(Tensor), C.c_void_p, C.c_void_p]),
     "mmtta_copy_strided": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p]),
     "mmtta_conv_packed_bytes": (C.c_int64, [_P(ConvDesc)]),
     "mmtta_conv_pack_weights": (C.c_int, [_P(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -171,10 +171,27 @@ class SegmentationEvaluationStrategy:
                 "evaluation.surface.enable: HD95/ASD are outside the adaptation hot path (SURVEY.md section 8f, row 4); "
                 "the reference leaves them off by default (src/evaluation/seg_eval.py:195)")
         self.loss_fn = DiceCEReport(get_config(self.config, "training.criterion", {}) or {})
+        # optional input pre-pass on the GPU (raw volumes in, the reference's `_normalize_img` applied here instead of
+        # in the dataset worker; reference src/datasets/transforms.py:129-223).  Off by default: the synthetic source
+        # and the reference's own datasets hand over normalised images.
+        tcfg = get_config(self.config, "training.data.transforms", {}) or {}
+        self.normalize_on_device = bool(get_config(tcfg, "normalize_on_device", False))
+        self._tcfg = tcfg
+
+    def prepare_image(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.normalize_on_device:
+            return x
+        from .transforms import normalize_image
+        t = self._tcfg
+        names = get_config(self.config, "dataset.modality_order", None)
+        return torch.stack([normalize_image(x[b].float(), bool(get_config(t, "normalize", True)),
+                                            get_config(t, "intensity_policy", None), get_config(t, "mean", None),
+                                            get_config(t, "std", None), list(names) if names else None)
+                            for b in range(x.size(0))], 0)
 
     # -- per batch
     def check_batch(self, batch: Dict[str, Any], device) -> Tuple[torch.Tensor, torch.Tensor]:
-        x = batch["image"].to(device)
+        x = self.prepare_image(batch["image"].to(device))
         B = x.size(0)
         if "label" not in batch:
             raise KeyError("[BratsSegEval] batch must contain 'label' for region-based eval.")

@@ -38,3 +38,4 @@ MODELS = {
     "unet_multimodal_deepfusion": MultimodalUNetDeepFusion,
     "unet_multimodal_midfusion": MultimodalUNetDeepFusion,
 }
+from .transforms import normalize_image  # noqa: F401,E402

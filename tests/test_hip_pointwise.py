@@ -260,3 +260,33 @@ def test_mask_dice_counts_exact(R, thr, shape):
     assert mism <= 1, f"{mism} mask voxels differ (only the exact-threshold voxel may, by 1 ulp of expf)"
     if mism == 0:
         assert torch.equal(counts.cpu(), ref)
+
+
+def test_intensity_normalisation_matches_the_oracle():
+    """Input pre-pass (reference src/datasets/transforms.py:129-223): clip + masked z-score per channel, the
+    min_count fallback, clip only, and the legacy mean/std branch.  The statistics are fp64 sums on the GPU and a
+    two-pass fp32 mean / std in torch: agreement to 2e-5 relative of the normalised range."""
+    import oracle
+    from multimodal_tta_amd.transforms import normalize_image
+    torch.manual_seed(21)
+    ct = torch.randn(1, 12, 36, 40) * 600 - 300
+    ct[:, :3] = -1024.0                                       # air: below mask_gt
+    pt = torch.rand(1, 12, 36, 40) * 20
+    pt[:, :, :18] = 0.0                                       # background
+    img = torch.cat([ct, pt], 0)
+    pol = {"enabled": True, "channel_names": ["ct", "pt"],
+           "channels": {"ct": {"clip": [-1000, 1000], "zscore": {"masked": True, "mask_gt": -900, "eps": 1.0e-6}},
+                        "pt": {"clip": [0.0, 15.0], "zscore": {"masked": True, "mask_gt": 0.0, "eps": 1.0e-6}}}}
+    close("hecktor policy", normalize_image(img.cuda(), intensity_policy=pol), oracle.normalize_image(img, intensity_policy=pol),
+          rel=2e-5, abs_=2e-5)
+    sparse = torch.zeros(2, 4, 8, 8)
+    sparse[0, 0, 0, :5] = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0])     # 5 voxels > 0 < min_count 16: all-voxel statistics
+    sparse[1] = 7.0                                                    # constant channel: sd -> eps
+    pol2 = {"enabled": True, "channels": {"0": {"zscore": {"masked": True, "mask_gt": 0.0}},
+                                          "1": {"clip": [0.0, 5.0]}}}
+    close("fallbacks", normalize_image(sparse.cuda(), intensity_policy=pol2), oracle.normalize_image(sparse, intensity_policy=pol2),
+          rel=2e-5, abs_=2e-5)
+    x4 = torch.randn(4, 6, 10, 12)
+    close("legacy", normalize_image(x4.cuda(), mean=[0.1, 0.2, 0.3, 0.4], std=[1.0, 2.0, 0.5, 4.0]),
+          oracle.normalize_image(x4, mean=[0.1, 0.2, 0.3, 0.4], std=[1.0, 2.0, 0.5, 4.0]), rel=1e-6, abs_=1e-6)
+    assert normalize_image(x4.cuda(), normalize=False).data_ptr() != 0

@@ -144,3 +144,76 @@ def test_synthetic_volume_contract():
     assert not torch.equal(a["image"], synth_volume(4, 4, (16, 20, 24), 3)["image"])
     h = synth_volume(0, 2, (12, 36, 36), 1)
     assert h["label"].shape == (1, 12, 36, 36) and isinstance(h["domain"], str) and h["index"] == 0
+
+
+def test_checkpoint_interchange_with_the_reference_format(tmp_path):
+    """A CheckpointHook-format file written from the oracle model (MONAI key names, optionally with the
+    DataParallel ``module.`` prefix, reference src/core/hooks.py:53-93) loads into the product containers, and a
+    file saved by the product reads back into the oracle model."""
+    import torch
+    import oracle
+    from multimodal_tta_amd.checkpoint import load_source_weights, read_state_dict, save_checkpoint
+    from multimodal_tta_amd.models import UNet
+
+    cfg = dict(name="unet", in_channels=2, num_classes=1, spatial_dims=3, channels=[4, 8, 16], strides=[2, 2],
+               num_res_units=2, norm="BATCH", act="RELU", dropout=0.0)
+    torch.manual_seed(0)
+    ref = oracle.UNet(cfg)
+    path = tmp_path / "checkpoints" / "best_model.pth"
+    path.parent.mkdir()
+    torch.save({"epoch": 7, "model_state_dict": {"module." + k: v for k, v in ref.state_dict().items()},
+                "optimizer_state_dict": {"state": {}, "param_groups": []}, "best_metrics": {"avg_dc": 0.5}}, path)
+    hip = UNet(cfg)
+    meta = load_source_weights(hip, str(path))
+    assert meta == {"epoch": 7, "best_metrics": {"avg_dc": 0.5}}
+    for (ka, va), (kb, vb) in zip(ref.state_dict().items(), hip.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    out = tmp_path / "out" / "checkpoint_epoch_0.pth"
+    save_checkpoint(str(out), hip, epoch=0, best_metrics={"avg_dc": 0.25})
+    ref2 = oracle.UNet(cfg)
+    ref2.load_state_dict(read_state_dict(str(out)))
+    assert all(torch.equal(a, b) for a, b in zip(ref.state_dict().values(), ref2.state_dict().values()))
+    ck = torch.load(str(out), weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "best_metrics"}
+
+
+HECKTOR_POLICY = {"enabled": True, "channel_names": ["ct", "pt"],
+                  "channels": {"ct": {"clip": [-1000, 1000], "zscore": {"masked": True, "mask_gt": -900, "eps": 1.0e-6}},
+                               "pt": {"clip": [0.0, 15.0], "zscore": {"masked": True, "mask_gt": 0.0, "eps": 1.0e-6}}}}
+
+
+def test_intensity_rules_follow_the_reference_policy_keys():
+    """The rule table handed to libmmtta mirrors reference configs/_global_patches/hecktor21.yaml:26-46 and the
+    defaults of reference src/datasets/transforms.py:178-183 (masked True, mask_gt -inf, eps 1e-6, min_count 16)."""
+    import pytest
+    from multimodal_tta_amd.transforms import build_rules
+    r = build_rules(2, HECKTOR_POLICY, mean=[0, 0], std=[1, 1])
+    assert [x.clip for x in r] == [1, 1] and (r[0].lo, r[0].hi) == (-1000.0, 1000.0) and (r[1].lo, r[1].hi) == (0.0, 15.0)
+    assert all(x.zscore == 1 and x.masked == 1 and x.min_count == 16 and x.legacy == 0 for x in r)
+    assert r[0].mask_gt == -900.0 and r[1].mask_gt == 0.0 and abs(r[0].eps - 1e-6) < 1e-12
+    r = build_rules(3, {"enabled": True, "channels": {"1": {"zscore": {"masked": False}}}})
+    assert [x.zscore for x in r] == [0, 1, 0] and r[1].masked == 0 and r[1].mask_gt == float("-inf")
+    r = build_rules(4, {"enabled": False}, mean=[0.5], std=[2.0])
+    assert all(x.legacy == 1 and x.mean == 0.5 and x.std == 2.0 for x in r)
+    with pytest.raises(RuntimeError, match="channel_names"):
+        build_rules(3, HECKTOR_POLICY)
+    with pytest.raises(RuntimeError, match="mean/std"):
+        build_rules(3, None, mean=[0.0, 1.0])
+
+
+def test_oracle_normalize_image_semantics():
+    """Known answers of the restated reference transform (reference src/datasets/transforms.py:163-223)."""
+    import torch
+    import oracle
+    x = torch.tensor([[[[-2000.0, -950.0, 0.0, 100.0, 3000.0]]], [[[0.0, 0.0, 1.0, 3.0, 20.0]]]])   # [2,1,1,5]
+    pol = {"enabled": True, "channel_names": ["ct", "pt"],
+           "channels": {"ct": {"clip": [-1000, 1000], "zscore": {"masked": True, "mask_gt": -900, "min_count": 2}},
+                        "pt": {"clip": [0.0, 15.0], "zscore": {"masked": True, "mask_gt": 0.0, "min_count": 4}}}}
+    y = oracle.normalize_image(x, intensity_policy=pol)
+    ct = torch.tensor([-1000.0, -950.0, 0.0, 100.0, 1000.0])
+    vals = ct[ct > -900]                                     # 0, 100, 1000
+    assert torch.allclose(y[0].flatten(), (ct - vals.mean()) / vals.std(unbiased=False))
+    pt = torch.tensor([0.0, 0.0, 1.0, 3.0, 15.0])            # only 3 voxels > 0 < min_count 4: statistics over all five
+    assert torch.allclose(y[1].flatten(), (pt - pt.mean()) / pt.std(unbiased=False))
+    z = oracle.normalize_image(x, intensity_policy={"enabled": False}, mean=[1.0, 2.0], std=[2.0, 4.0])
+    assert torch.allclose(z[1], (x[1] - 2.0) / 4.0) and torch.equal(oracle.normalize_image(x, normalize=False), x)
