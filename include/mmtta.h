@@ -313,6 +313,14 @@ int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label
 int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight,
                        int squared_pred, double* out, void* stream);
 
+/* d(lambda_dice * Dice + lambda_ce * CE)/d(logits) of the same loss (reduction mean), from the sums above (left
+ * on the device): the supervised step of reference src/core/trainers/seg_trainer.py:141-142 without autograd.
+ * Class weights scale the Dice terms only when more than one Dice channel exists (monai); include_background == 0
+ * drops channel 0 from the Dice mean when R > 1. */
+int mmtta_dice_ce_grad(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight, int squared_pred,
+                       int jaccard, int include_background, float lambda_dice, float lambda_ce, float smooth_nr,
+                       float smooth_dr, const double* sums, const mmtta_tensor* dlogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -266,6 +266,77 @@ __global__ __launch_bounds__(256) void dice_ce_sums_kernel(TV z, TV lab, const f
   }
 }
 
+// Gradient of DiceCE (lambda_dice * Dice + lambda_ce * CE, reduction mean) with respect to the logits, from the
+// per-(n,r) sums of dice_ce_sums_kernel (monai DiceCELoss as built at reference
+// src/core/trainers/seg_trainer.py:59-79).  One thread per voxel, all R channels.
+struct DceGradArgs {
+  TV z, lab, dz;
+  const float* weight;
+  const double* sums;       // [N][R*3+1]
+  int squared, jaccard, include_background;
+  float lambda_dice, lambda_ce, smooth_nr, smooth_dr;
+};
+
+__global__ __launch_bounds__(256) void dice_ce_grad_kernel(DceGradArgs a) {
+  const int R = a.z.c;
+  const long long dhw = (long long)a.z.d * a.z.h * a.z.w;
+  const long long total = (long long)a.z.n * dhw;
+  const int r0 = (!a.include_background && R > 1) ? 1 : 0;
+  const int Rd = R - r0;                                  // channels in the Dice mean
+  const float dice_scale = a.lambda_dice / (float)((long long)a.z.n * Rd);
+  const float ce_scale = a.lambda_ce / (float)((long long)a.z.n * dhw * (R == 1 ? 1 : 1));
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / dhw);
+    long long t = i - (long long)n * dhw;
+    const int x = (int)(t % a.z.w); t /= a.z.w;
+    const int y = (int)(t % a.z.h);
+    const int zz = (int)(t / a.z.h);
+    float lg[DCE_MAX_R], yv[DCE_MAX_R], g[DCE_MAX_R];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < DCE_MAX_R; ++r)
+      if (r < R) {
+        lg[r] = a.z.p[n * a.z.sn + (long long)r * a.z.sc + zz * a.z.sd + y * a.z.sh + x * a.z.sw];
+        yv[r] = a.lab.p[n * a.lab.sn + (long long)r * a.lab.sc + zz * a.lab.sd + y * a.lab.sh + x * a.lab.sw];
+        m = fmaxf(m, lg[r]);
+      }
+    float se = 0.f, S = 0.f;
+#pragma unroll
+    for (int r = 0; r < DCE_MAX_R; ++r)
+      if (r < R) { se += expf(lg[r] - m); S += (a.weight ? a.weight[r] : 1.f) * yv[r]; }
+#pragma unroll
+    for (int r = 0; r < DCE_MAX_R; ++r)
+      if (r < R) {
+        const float e = expf(-fabsf(lg[r]));
+        const float p = lg[r] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        float gd = 0.f;
+        if (r >= r0) {
+          const double* sm = a.sums + (long long)n * (R * 3 + 1) + r * 3;
+          const float I = (float)sm[0], Q = (float)sm[1], G = (float)sm[2];
+          const float A = 2.f * I + a.smooth_nr;
+          float den = G + Q;
+          float dden = a.squared ? 2.f * p : 1.f;            // d(sum p or p^2)/dp
+          if (a.jaccard) { den = 2.f * (den - I); dden = 2.f * (dden - yv[r]); }
+          const float Dn = den + a.smooth_dr;
+          const float dfdp = -(2.f * yv[r] * Dn - A * dden) / (Dn * Dn);
+          // class weights scale the Dice terms only when there is more than one Dice channel (monai)
+          const float cw = (a.weight != nullptr && Rd != 1) ? a.weight[r] : 1.f;
+          gd = dice_scale * cw * dfdp * p * (1.f - p);
+        }
+        float gc;
+        if (R == 1) {
+          const float pw = a.weight ? a.weight[0] : 1.f;
+          gc = -pw * yv[r] * (1.f - p) + (1.f - yv[r]) * p;
+        } else {
+          const float sp = expf(lg[r] - m) / se;
+          gc = sp * S - (a.weight ? a.weight[r] : 1.f) * yv[r];
+        }
+        g[r] = gd + ce_scale * gc;
+        a.dz.p[n * a.dz.sn + (long long)r * a.dz.sc + zz * a.dz.sd + y * a.dz.sh + x * a.dz.sw] = g[r];
+      }
+  }
+}
+
 }  // namespace mmtta
 
 using namespace mmtta;
@@ -360,4 +431,24 @@ extern "C" int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor
   hipLaunchKernelGGL(dice_ce_sums_kernel, dim3((unsigned)(bpn * logits->n)), dim3(256), 0, s, tv(logits), tv(label), weight,
                      squared_pred, out, (int)bpn);
   return launch_status("dice_ce sums");
+}
+
+extern "C" int mmtta_dice_ce_grad(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight, int squared_pred,
+                                  int jaccard, int include_background, float lambda_dice, float lambda_ce, float smooth_nr,
+                                  float smooth_dr, const double* sums, const mmtta_tensor* dlogits, void* stream) {
+  MMTTA_CHECK(logits && label && dlogits && sums && logits->ptr && label->ptr && dlogits->ptr, MMTTA_ERR_INVALID,
+              "dice_ce grad: null argument");
+  MMTTA_CHECK(logits->n == label->n && logits->c == label->c && logits->d == label->d && logits->h == label->h &&
+                  logits->w == label->w && logits->n == dlogits->n && logits->c == dlogits->c && logits->d == dlogits->d &&
+                  logits->h == dlogits->h && logits->w == dlogits->w, MMTTA_ERR_INVALID, "dice_ce grad: shape mismatch");
+  MMTTA_CHECK(logits->c <= DCE_MAX_R, MMTTA_ERR_UNSUPPORTED, "dice_ce grad: more than %d regions", DCE_MAX_R);
+  DceGradArgs a;
+  a.z = tv(logits); a.lab = tv(label); a.dz = tv(dlogits); a.weight = weight; a.sums = sums;
+  a.squared = squared_pred; a.jaccard = jaccard; a.include_background = include_background;
+  a.lambda_dice = lambda_dice; a.lambda_ce = lambda_ce; a.smooth_nr = smooth_nr; a.smooth_dr = smooth_dr;
+  const long long total = (long long)logits->n * logits->d * logits->h * logits->w;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dice_ce_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status("dice_ce grad");
 }

@@ -443,3 +443,17 @@ def dice_ce_sums(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Option
     tl = desc_ncdhw(label_ncdhw)
     check(_lib.load().mmtta_dice_ce_sums(C.byref(tz), C.byref(tl), ptr(weight), 1 if squared_pred else 0, ptr(out),
                                          stream_ptr()), "dice_ce_sums")
+
+
+def dice_ce_grad(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Optional[torch.Tensor], squared_pred: bool,
+                 jaccard: bool, include_background: bool, lambda_dice: float, lambda_ce: float, sums: torch.Tensor,
+                 dlogits: torch.Tensor, logits_channels_last: bool = True, smooth_nr: float = 1e-5,
+                 smooth_dr: float = 1e-5) -> None:
+    """d DiceCE / d logits from the device-resident sums of ``dice_ce_sums`` (same layouts as there)."""
+    tz = _desc_any(logits, logits_channels_last)
+    tg = _desc_any(dlogits, logits_channels_last)
+    tl = desc_ncdhw(label_ncdhw)
+    check(_lib.load().mmtta_dice_ce_grad(C.byref(tz), C.byref(tl), ptr(weight), 1 if squared_pred else 0,
+                                         1 if jaccard else 0, 1 if include_background else 0, float(lambda_dice),
+                                         float(lambda_ce), float(smooth_nr), float(smooth_dr), ptr(sums), C.byref(tg),
+                                         stream_ptr()), "dice_ce_grad")

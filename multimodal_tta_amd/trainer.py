@@ -1,0 +1,93 @@
+"""``seg_supervised_step``: the reference's supervised step (reference src/core/trainers/seg_trainer.py:97-145:
+``zero_grad -> model(x) -> DiceCELoss -> backward -> optimizer.step``) on the native engine, registered in the
+PLUGINS table.
+
+The loss and its gradient come from two HIP kernels (``mmtta_dice_ce_sums`` + ``mmtta_dice_ce_grad``), the
+backward and the optimizer are the ones the adaptation loop uses; no autograd graph is built.  The criterion keys
+are the reference's (``training.criterion.{lambda_dice,lambda_ce,include_background,squared_pred,jaccard,weight}``,
+reference seg_trainer.py:59-79); ``sigmoid: true`` heads only (every shipped config).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+
+from . import ops
+from .config import as_cfg, get_config
+from .models.base import HipSegModel
+from .ops import MmttaError
+from .registry import register_plugin
+from .tta import EntropyMinimizationTTA, select_params
+
+
+@register_plugin("seg_supervised_step")
+class SupervisedSegStep(EntropyMinimizationTTA):
+    """Shares construction (optimizer hyper-parameters, parameter groups, precision) with the adaptation plugin;
+    only the objective differs."""
+
+    def __init__(self, config: Any = None):
+        super().__init__(config)
+        crit = get_config(as_cfg(config), "training.criterion", {}) or {}
+        if not bool(get_config(crit, "sigmoid", True)) or bool(get_config(crit, "softmax", False)):
+            raise NotImplementedError("seg_supervised_step implements the sigmoid (multilabel) DiceCE of the shipped configs")
+        self.include_background = bool(get_config(crit, "include_background", True))
+        self.squared_pred = bool(get_config(crit, "squared_pred", False))
+        self.jaccard = bool(get_config(crit, "jaccard", False))
+        self.lambda_dice = float(get_config(crit, "lambda_dice", 1.0))
+        self.lambda_ce = float(get_config(crit, "lambda_ce", 1.0))
+        w = get_config(crit, "weight", None)
+        self.ce_weight = [float(v) for v in list(w)] if w is not None and len(list(w)) > 0 else None
+        self._w_dev: Optional[torch.Tensor] = None
+
+    def loss_value(self, sums: torch.Tensor, B: int, R: int, nvox: int) -> float:
+        """Host arithmetic from the sums (the reference syncs once per step as well: ``loss.item()``, :145)."""
+        s = sums.cpu().view(B, R * 3 + 1)
+        per = s[:, :R * 3].view(B, R, 3).to(torch.float32)
+        inter, ps, gs = per[..., 0], per[..., 1], per[..., 2]
+        if not self.include_background and R > 1:
+            inter, ps, gs = inter[:, 1:], ps[:, 1:], gs[:, 1:]
+        den = gs + ps
+        if self.jaccard:
+            den = 2.0 * (den - inter)
+        f = 1.0 - (2.0 * inter + 1e-5) / (den + 1e-5)
+        if self.ce_weight is not None and f.shape[1] != 1:
+            dw = torch.tensor(self.ce_weight[1:] if not self.include_background else self.ce_weight, dtype=torch.float32)
+            if dw.numel() == f.shape[1]:
+                f = f * dw
+        ce = float((s[:, R * 3].sum() / (B * nvox)).item())
+        return self.lambda_dice * float(f.mean().item()) + self.lambda_ce * ce
+
+    @torch.no_grad()
+    def run_step(self, batch: Dict[str, Any]) -> Dict[str, float]:
+        """One supervised step on ``batch = {"image": [B,C,D,H,W], "label": [B,R,D,H,W]}`` (reference :97-145)."""
+        if self.rt is None:
+            raise MmttaError("call setup(model, device) first")
+        rt, ar = self.rt, self.rt.arena
+        dev = rt.device
+        x = batch["image"].to(dev).float()
+        y = batch["label"].to(dev).float().contiguous()
+        if y.ndim == 4:
+            y = y.unsqueeze(0).expand(x.size(0), -1, -1, -1, -1).contiguous()
+        ops.Workspace.lane = self.lane
+        rt.training = True
+        rt.pack_all()
+        logits = rt.forward_cl(rt.stage_input(x))
+        n, d, h, w, r = logits.shape
+        if tuple(y.shape) != (n, r, d, h, w):
+            raise ValueError(f"[SegTrainer] model logits must be [B,{y.shape[1]},D,H,W], got {(n, r, d, h, w)}")
+        if self.ce_weight is not None and self._w_dev is None:
+            if len(self.ce_weight) != r:
+                raise ValueError(f"criterion.weight has {len(self.ce_weight)} entries for {r} channels")
+            self._w_dev = torch.tensor(self.ce_weight, dtype=torch.float32, device=dev)
+        sums = rt.pool.flat("dce_sums", n * (r * 3 + 1), dtype=torch.float64)
+        ops.dice_ce_sums(logits, y, self._w_dev, self.squared_pred, sums, logits_channels_last=True)
+        dlogits = rt.pool.cl("dlogits", n, d, h, w, r, ldc=(r + 3) // 4 * 4)
+        ops.dice_ce_grad(logits, y, self._w_dev, self.squared_pred, self.jaccard, self.include_background,
+                         self.lambda_dice, self.lambda_ce, sums, dlogits, logits_channels_last=True)
+        if ar.n_train > 0:
+            rt.run_backward(dlogits)
+            ops.adam_step(ar.params[:ar.n_train], ar.grads[:ar.n_train], ar.exp_avg[:ar.n_train],
+                          ar.exp_avg_sq[:ar.n_train], ar.n_decay, self.lr, self.beta1, self.beta2, self.eps,
+                          self.weight_decay, ar.step)
+        return {"loss": self.loss_value(sums, n, r, d * h * w)}

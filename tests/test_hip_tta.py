@@ -246,3 +246,42 @@ def test_concurrent_lanes_equal_sequential_runs():
             rb = pb.adapt_volume(xb)
         torch.cuda.synchronize()
         assert torch.equal(pa.logits(ra), za) and torch.equal(pb.logits(rb), zb)
+
+
+@pytest.mark.parametrize("crit", [
+    dict(lambda_dice=1.0, lambda_ce=1.0, include_background=True, squared_pred=False, jaccard=False),
+    dict(lambda_dice=5.0, lambda_ce=1.0, include_background=False, squared_pred=True, jaccard=True, weight=[1.0, 2.0, 0.5]),
+])
+def test_supervised_dicece_step_matches_autograd(crit):
+    """The reference's supervised step (reference src/core/trainers/seg_trainer.py:97-145) with the loss gradient
+    from mmtta_dice_ce_grad: loss value and the logits after two Adam steps against torch autograd on the oracle
+    (oracle.DiceCELoss + oracle.build_adam)."""
+    import oracle
+    from multimodal_tta_amd.registry import get_plugin
+
+    cfg = root_cfg(SMALL, steps=1, lr=1e-3)
+    cfg["training"]["criterion"].update(crit)
+    cfg["training"]["criterion"]["sigmoid"] = True
+    ref, hip = build_pair(SMALL)
+    x, y = volume(3)
+    w = torch.tensor(crit["weight"]) if "weight" in crit else None
+    loss_fn = oracle.DiceCELoss(include_background=crit["include_background"], sigmoid=True, squared_pred=crit["squared_pred"],
+                                jaccard=crit["jaccard"], weight=w, lambda_dice=crit["lambda_dice"], lambda_ce=crit["lambda_ce"])
+    opt = oracle.build_adam(list(ref.named_parameters()), cfg["training"])
+    ref.train()
+    ref_losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        loss = loss_fn(ref(x), y)
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss.item()))
+    plug = get_plugin("seg_supervised_step")(cfg).setup(hip, "cuda")
+    hip_losses = [plug.run_step({"image": x, "label": y})["loss"] for _ in range(2)]
+    for a, b in zip(hip_losses, ref_losses):
+        assert abs(a - b) <= 2e-4 * abs(b) + 1e-6, (hip_losses, ref_losses)
+    ref.eval(); hip.eval()
+    with torch.no_grad():
+        z_ref, z_hip = ref(x), hip(x.cuda()).cpu()
+    err = (z_hip - z_ref).abs().max().item() / z_ref.abs().max().item()
+    assert err < 5e-3, f"logits after two supervised steps: rel err {err:.3e}"
