@@ -48,6 +48,17 @@ inline TV tv(const mmtta_tensor* t) {
   return v;
 }
 
+// linear voxel index (n, z, y, x order) <-> coordinates / element offset of a view
+__device__ __forceinline__ void vox_decompose(const TV& t, long long v, int& n, int& z, int& y, int& x) {
+  x = (int)(v % t.w); v /= t.w;
+  y = (int)(v % t.h); v /= t.h;
+  z = (int)(v % t.d);
+  n = (int)(v / t.d);
+}
+__device__ __forceinline__ long long vox_addr(const TV& t, int n, int z, int y, int x) {
+  return (long long)n * t.sn + (long long)z * t.sd + (long long)y * t.sh + (long long)x * t.sw;
+}
+
 // Device-side norm-on-load descriptor.
 struct NL {
   const float* mean;
@@ -155,6 +166,10 @@ int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s);  // 
 extern int g_profile_main_only;     // api.hip: mmtta_set_option(MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY)
 bool direct_applicable(const mmtta_conv_desc* d);
 int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);
+bool pointwise_small_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y, const float* stats,
+                                const mmtta_conv_epilogue* epi, const mmtta_norm_on_load* x_norm);
+int pointwise_small_run(const mmtta_tensor* x, const void* packed, int Kp, int Np, const float* bias, const mmtta_tensor* y,
+                        int accumulate, hipStream_t stream);
 bool chan_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);
 int chan_tiles_per_n(const mmtta_tensor* y);
 int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed, int Kp,

@@ -1136,6 +1136,8 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   if (st) return st;
   MMTTA_CHECK(packed != nullptr, MMTTA_ERR_INVALID, "conv: null packed weights");
   if (direct_applicable(d)) return direct_conv_run(d, x, x_norm, packed, bias, epi, y, accumulate, stats, (hipStream_t)stream);
+  if (pointwise_small_applicable(d, x, y, stats, epi, x_norm) && !use_bf16(d, g.K))
+    return pointwise_small_run(x, packed, g.Kp, g.Np, bias, y, accumulate, (hipStream_t)stream);
   if (chan_applicable(d, x, y) && !use_bf16(d, g.K))
     return chan_conv_run(d, x, x_norm, packed, g.Kp, g.Np, bias, epi, y, accumulate, stats, (hipStream_t)stream);
   const int64_t need = g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * 4 : 0;

@@ -97,8 +97,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
             const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
             ok[u] = bv < boxvox && (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg &&
                     (unsigned)ix < (unsigned)a.Wgg && c < a.Cg;
-            xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok[u]) xin[u] = *reinterpret_cast<const float4*>(gb + iz * a.gsd + iy * a.gsh + ix * a.gsw + c);
+            xin[u] = *reinterpret_cast<const float4*>(gb + (long long)min(max(iz, 0), a.Dgg - 1) * a.gsd +
+                                                      (long long)min(max(iy, 0), a.Hgg - 1) * a.gsh +
+                                                      (long long)min(max(ix, 0), a.Wgg - 1) * a.gsw + min(c, (a.Cg - 1) & ~3));
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
@@ -131,20 +132,61 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
         }
       }
     }
-    // ---- stage D tile: [MT][32 channels cd0..cd0+31]
+    // ---- stage D tile: [MT][32 channels cd0..cd0+31]; every load unconditional from a clamped address, all of a
+    // thread's loads in flight together (a load behind a per-item branch is waited for at once: 16 exposed round
+    // trips per tile before)
     {
       const float* db = a.dn + (long long)n * a.dsn;
-      const int cc = tid & 31;
-      const int c = cd0 + cc;
-      float sc = 0.f, sh = 0.f;
-      nl_coeff_vec<1>(a.td, n, a.Cd, c, &sc, &sh);
-      for (int v = tid >> 5; v < MT; v += 8) {
-        const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
-        const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
-        float val = 0.f;
-        if (oz < a.Dd && oy < a.Hd && ox < a.Wd && c < a.Cd)
-          val = nl_apply(db[oz * a.dsd + oy * a.dsh + ox * a.dsw + c], sc, sh, a.td.relu);
-        dl[v * 32 + cc] = val;
+      if (a.dvec4) {
+        const int cv = tid & 7;
+        const int c = cd0 + cv * 4;
+        float sc[4], sh[4];
+        nl_coeff_vec<4>(a.td, n, a.Cd, c, sc, sh);
+        const int cl4 = min(c, (a.Cd - 1) & ~3);
+        constexpr int NQ = MT / 32;
+        float4 raw[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int v = (tid >> 3) + 32 * q;
+          const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+          raw[q] = *reinterpret_cast<const float4*>(db + (long long)min(oz0 + zl, a.Dd - 1) * a.dsd +
+                                                   (long long)min(oy0 + yl, a.Hd - 1) * a.dsh +
+                                                   (long long)min(ox0 + xl, a.Wd - 1) * a.dsw + cl4);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int v = (tid >> 3) + 32 * q;
+          const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+          const bool ok = oz0 + zl < a.Dd && oy0 + yl < a.Hd && ox0 + xl < a.Wd;
+          float4 o;
+          o.x = (ok && c < a.Cd) ? nl_apply(raw[q].x, sc[0], sh[0], a.td.relu) : 0.f;
+          o.y = (ok && c + 1 < a.Cd) ? nl_apply(raw[q].y, sc[1], sh[1], a.td.relu) : 0.f;
+          o.z = (ok && c + 2 < a.Cd) ? nl_apply(raw[q].z, sc[2], sh[2], a.td.relu) : 0.f;
+          o.w = (ok && c + 3 < a.Cd) ? nl_apply(raw[q].w, sc[3], sh[3], a.td.relu) : 0.f;
+          *reinterpret_cast<float4*>(dl + v * 32 + cv * 4) = o;
+        }
+      } else {
+        const int cc = tid & 31;
+        const int c = cd0 + cc;
+        float sc = 0.f, sh = 0.f;
+        nl_coeff_vec<1>(a.td, n, a.Cd, c, &sc, &sh);
+        const int cl = min(c, a.Cd - 1);
+        constexpr int NQ = MT / 8;
+        float raw[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int v = (tid >> 5) + 8 * q;
+          const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+          raw[q] = db[(long long)min(oz0 + zl, a.Dd - 1) * a.dsd + (long long)min(oy0 + yl, a.Hd - 1) * a.dsh +
+                      (long long)min(ox0 + xl, a.Wd - 1) * a.dsw + cl];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int v = (tid >> 5) + 8 * q;
+          const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+          const bool ok = oz0 + zl < a.Dd && oy0 + yl < a.Hd && ox0 + xl < a.Wd && c < a.Cd;
+          dl[v * 32 + cc] = ok ? nl_apply(raw[q], sc, sh, a.td.relu) : 0.f;
+        }
       }
     }
     __syncthreads();
@@ -1108,7 +1150,8 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   a.CGp = w.CGp; a.CDp = w.CDp;
   a.gvec4 = ((((uintptr_t)w.g->ptr) % 16 == 0) && w.g->sw % 4 == 0 && w.g->sh % 4 == 0 && w.g->sd % 4 == 0 &&
              w.g->sn % 4 == 0) ? 1 : 0;
-  a.dvec4 = 0;
+  a.dvec4 = ((((uintptr_t)w.dn->ptr) % 16 == 0) && w.dn->sw % 4 == 0 && w.dn->sh % 4 == 0 && w.dn->sd % 4 == 0 &&
+             w.dn->sn % 4 == 0) ? 1 : 0;
   if (w.bf16) st = (w.si == 1) ? launch_wgrad_bf16<4, 4, 1>(a, w.S, s) : launch_wgrad_bf16<2, 4, 2>(a, w.S, s);
   else if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, w.S, s);
   else st = (w.si == 1) ? launch_wgrad<4, 4, 8, 7>(a, w.S, s) : launch_wgrad<2, 2, 8, 7>(a, w.S, s);

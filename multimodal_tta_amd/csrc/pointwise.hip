@@ -8,15 +8,6 @@
 
 namespace mmtta {
 
-__device__ __forceinline__ void vox_decompose(const TV& t, long long v, int& n, int& z, int& y, int& x) {
-  x = (int)(v % t.w); v /= t.w;
-  y = (int)(v % t.h); v /= t.h;
-  z = (int)(v % t.d);
-  n = (int)(v / t.d);
-}
-__device__ __forceinline__ long long vox_addr(const TV& t, int n, int z, int y, int x) {
-  return (long long)n * t.sn + (long long)z * t.sd + (long long)y * t.sh + (long long)x * t.sw;
-}
 
 // ------------------------------------------------------------------ strided copy
 __global__ void copy_strided_kernel(TV s, TV d) {
@@ -429,25 +420,43 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, int& i0, int
   lam = src - (float)i0;
 }
 
+// VEC = 4: a thread owns 4 consecutive channels of one output voxel (16-byte accesses, index arithmetic amortised);
+// VEC = 1: scalar fallback for unaligned views.
+template <int VEC>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(TV x, TV y) {
   const int C = y.c;
-  const long long total = (long long)y.n * y.d * y.h * y.w * C;
+  const int CV = (C + VEC - 1) / VEC;
+  const long long total = (long long)y.n * y.d * y.h * y.w * CV;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
+    const int c = (int)(i % CV) * VEC;
     int n, oz, oy, ox;
-    vox_decompose(y, i / C, n, oz, oy, ox);
+    vox_decompose(y, i / CV, n, oz, oy, ox);
     int z0, z1, y0, y1, x0, x1;
     float lz, ly, lx;
     src_index(oz, x.d, y.d, z0, z1, lz);
     src_index(oy, x.h, y.h, y0, y1, ly);
     src_index(ox, x.w, y.w, x0, x1, lx);
     const float* xp = x.p + (long long)n * x.sn + c;
-    auto at = [&](int zz, int yy, int xx) { return xp[(long long)zz * x.sd + (long long)yy * x.sh + (long long)xx * x.sw]; };
     const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
-    const float v = wz0 * (wy0 * (wx0 * at(z0, y0, x0) + lx * at(z0, y0, x1)) + ly * (wx0 * at(z0, y1, x0) + lx * at(z0, y1, x1))) +
-                    lz * (wy0 * (wx0 * at(z1, y0, x0) + lx * at(z1, y0, x1)) + ly * (wx0 * at(z1, y1, x0) + lx * at(z1, y1, x1)));
-    y.p[vox_addr(y, n, oz, oy, ox) + c] = v;
+    const long long o00 = (long long)z0 * x.sd + (long long)y0 * x.sh, o01 = (long long)z0 * x.sd + (long long)y1 * x.sh;
+    const long long o10 = (long long)z1 * x.sd + (long long)y0 * x.sh, o11 = (long long)z1 * x.sd + (long long)y1 * x.sh;
+    const long long a0 = (long long)x0 * x.sw, a1 = (long long)x1 * x.sw;
+    float* op = y.p + vox_addr(y, n, oz, oy, ox) + c;
+    if (VEC == 4) {
+      const float4 v000 = *reinterpret_cast<const float4*>(xp + o00 + a0), v001 = *reinterpret_cast<const float4*>(xp + o00 + a1);
+      const float4 v010 = *reinterpret_cast<const float4*>(xp + o01 + a0), v011 = *reinterpret_cast<const float4*>(xp + o01 + a1);
+      const float4 v100 = *reinterpret_cast<const float4*>(xp + o10 + a0), v101 = *reinterpret_cast<const float4*>(xp + o10 + a1);
+      const float4 v110 = *reinterpret_cast<const float4*>(xp + o11 + a0), v111 = *reinterpret_cast<const float4*>(xp + o11 + a1);
+#define MMTTA_TRI(f) (wz0 * (wy0 * (wx0 * v000.f + lx * v001.f) + ly * (wx0 * v010.f + lx * v011.f)) + \
+                      lz * (wy0 * (wx0 * v100.f + lx * v101.f) + ly * (wx0 * v110.f + lx * v111.f)))
+      *reinterpret_cast<float4*>(op) = make_float4(MMTTA_TRI(x), MMTTA_TRI(y), MMTTA_TRI(z), MMTTA_TRI(w));
+#undef MMTTA_TRI
+    } else {
+      const float v = wz0 * (wy0 * (wx0 * xp[o00 + a0] + lx * xp[o00 + a1]) + ly * (wx0 * xp[o01 + a0] + lx * xp[o01 + a1])) +
+                      lz * (wy0 * (wx0 * xp[o10 + a0] + lx * xp[o10 + a1]) + ly * (wx0 * xp[o11 + a0] + lx * xp[o11 + a1]));
+      op[0] = v;
+    }
   }
 }
 
@@ -470,29 +479,47 @@ __device__ __forceinline__ int axis_weights(int i, int in, int out, int* os, flo
   return cnt;
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(TV dy, TV dx, int accumulate) {
   const int C = dx.c;
-  const long long total = (long long)dx.n * dx.d * dx.h * dx.w * C;
+  const int CV = (C + VEC - 1) / VEC;
+  const long long total = (long long)dx.n * dx.d * dx.h * dx.w * CV;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
+    const int c = (int)(i % CV) * VEC;
     int n, iz, iy, ix;
-    vox_decompose(dx, i / C, n, iz, iy, ix);
+    vox_decompose(dx, i / CV, n, iz, iy, ix);
     int oz[5], oy[5], ox[5];
     float wz[5], wy[5], wx[5];
     const int nz = axis_weights(iz, dx.d, dy.d, oz, wz);
     const int ny = axis_weights(iy, dx.h, dy.h, oy, wy);
     const int nx = axis_weights(ix, dx.w, dy.w, ox, wx);
     const float* gp = dy.p + (long long)n * dy.sn + c;
-    float s = 0.f;
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
     for (int a = 0; a < nz; ++a)
       for (int b = 0; b < ny; ++b) {
         const float wzy = wz[a] * wy[b];
         const float* row = gp + (long long)oz[a] * dy.sd + (long long)oy[b] * dy.sh;
-        for (int k = 0; k < nx; ++k) s += wzy * wx[k] * row[(long long)ox[k] * dy.sw];
+        for (int k = 0; k < nx; ++k) {
+          const float wgt = wzy * wx[k];
+          if (VEC == 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(row + (long long)ox[k] * dy.sw);
+            s[0] = fmaf(wgt, g4.x, s[0]); s[1] = fmaf(wgt, g4.y, s[1]); s[2] = fmaf(wgt, g4.z, s[2]); s[3] = fmaf(wgt, g4.w, s[3]);
+          } else {
+            s[0] += wgt * row[(long long)ox[k] * dy.sw];
+          }
+        }
       }
     float* o = dx.p + vox_addr(dx, n, iz, iy, ix) + c;
-    *o = accumulate ? *o + s : s;
+    if (VEC == 4) {
+      float4 r = make_float4(s[0], s[1], s[2], s[3]);
+      if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(o); r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+      *reinterpret_cast<float4*>(o) = r;
+    } else {
+      *o = accumulate ? *o + s[0] : s[0];
+    }
   }
 }
 
@@ -674,8 +701,10 @@ extern "C" int mmtta_upsample2x_fwd(const mmtta_tensor* x, const mmtta_tensor* y
   MMTTA_CHECK(y->n == x->n && y->c == x->c && y->d == 2 * x->d && y->h == 2 * x->h && y->w == 2 * x->w, MMTTA_ERR_INVALID,
               "upsample: y must be exactly 2x of x");
   MMTTA_CHECK(is_cl(x) && is_cl(y), MMTTA_ERR_UNSUPPORTED, "upsample: channels-last only");
-  const long long total = (long long)y->n * y->d * y->h * y->w * y->c;
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
+  const bool v4 = vec4_rd(x) && vec4_wr(y);
+  const long long total = (long long)y->n * y->d * y->h * y->w * (v4 ? (y->c + 3) / 4 : y->c);
+  if (v4) hipLaunchKernelGGL(upsample_fwd_kernel<4>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
+  else hipLaunchKernelGGL(upsample_fwd_kernel<1>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
   return launch_status("upsample fwd");
 }
 
@@ -684,8 +713,10 @@ extern "C" int mmtta_upsample2x_bwd(const mmtta_tensor* dy, const mmtta_tensor* 
   MMTTA_CHECK(dy->n == dx->n && dy->c == dx->c && dy->d == 2 * dx->d && dy->h == 2 * dx->h && dy->w == 2 * dx->w,
               MMTTA_ERR_INVALID, "upsample bwd: dy must be exactly 2x of dx");
   MMTTA_CHECK(is_cl(dx) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "upsample bwd: channels-last only");
-  const long long total = (long long)dx->n * dx->d * dx->h * dx->w * dx->c;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
+  const bool v4 = vec4_rd(dy) && vec4_wr(dx);
+  const long long total = (long long)dx->n * dx->d * dx->h * dx->w * (v4 ? (dx->c + 3) / 4 : dx->c);
+  if (v4) hipLaunchKernelGGL(upsample_bwd_kernel<4>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
+  else hipLaunchKernelGGL(upsample_bwd_kernel<1>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
   return launch_status("upsample bwd");
 }
 
