@@ -757,12 +757,24 @@ struct PArgs {
 template <int KI>
 __global__ __launch_bounds__(256) void pointwise_small_k_kernel(PArgs a) {
   const int NV = a.out.c / 4;
-  const long long total = (long long)a.out.n * a.out.d * a.out.h * a.out.w * NV;
+  const long long dhw = (long long)a.out.d * a.out.h * a.out.w;
+  const long long total = (long long)a.out.n * dhw * NV;
+  const bool dense = a.in.sh == (long long)a.in.w * a.in.sw && a.in.sd == (long long)a.in.h * a.in.sh &&
+                     a.out.sh == (long long)a.out.w * a.out.sw && a.out.sd == (long long)a.out.h * a.out.sh;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int n0 = (int)(i % NV) * 4;
-    int n, z, y, x;
-    vox_decompose(a.out, i / NV, n, z, y, x);
-    const float4 x4 = *reinterpret_cast<const float4*>(a.in.p + vox_addr(a.in, n, z, y, x));
+    long long ioff, ooff;
+    if (dense) {                                   // dense voxel order on both sides: no coordinate arithmetic
+      const long long v = i / NV, n = v / dhw, r = v - n * dhw;
+      ioff = n * a.in.sn + r * a.in.sw;
+      ooff = n * a.out.sn + r * a.out.sw;
+    } else {
+      int n, z, y, x;
+      vox_decompose(a.out, i / NV, n, z, y, x);
+      ioff = vox_addr(a.in, n, z, y, x);
+      ooff = vox_addr(a.out, n, z, y, x);
+    }
+    const float4 x4 = *reinterpret_cast<const float4*>(a.in.p + ioff);
     const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(256) void pointwise_small_k_kernel(PArgs a) {
       const float4 w4 = *reinterpret_cast<const float4*>(a.w + (long long)k * a.Np + n0);
       o[0] = fmaf(xs[k], w4.x, o[0]); o[1] = fmaf(xs[k], w4.y, o[1]); o[2] = fmaf(xs[k], w4.z, o[2]); o[3] = fmaf(xs[k], w4.w, o[3]);
     }
-    float* op = a.out.p + vox_addr(a.out, n, z, y, x) + n0;
+    float* op = a.out.p + ooff + n0;
     if (a.accumulate) {
       const float4 t = *reinterpret_cast<const float4*>(op);
       o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
