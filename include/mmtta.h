@@ -306,12 +306,14 @@ int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label
 
 /* Sums behind monai DiceCELoss(sigmoid=True) as the reference evaluator builds it for
  * ``evaluation.loss.report_loss`` (reference src/evaluation/seg_eval.py:209-220,395-400; SURVEY.md
- * Appendix A.5).  out fp64 [N][R*3+1], zeroed by this call: per region (sum p*y, sum p, sum y) with
+ * Appendix A.5).  out fp64 [N][R*3+1] (block partials go through `scratch`, mmtta_dice_ce_scratch_bytes; they are
+ * summed in a fixed order: reproducible): per region (sum p*y, sum p, sum y) with
  * p = sigmoid(z) (squares of p, y when squared_pred), then the CE numerator: BCE-with-logits with
  * pos_weight = weight[0] when R == 1, soft-label softmax cross entropy with class weights otherwise.
  * The few scalar operations that turn the sums into the loss value are host arithmetic. */
+int64_t mmtta_dice_ce_scratch_bytes(const mmtta_tensor* logits);
 int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight,
-                       int squared_pred, double* out, void* stream);
+                       int squared_pred, double* out, void* scratch, void* stream);
 
 /* d(lambda_dice * Dice + lambda_ce * CE)/d(logits) of the same loss (reduction mean), from the sums above (left
  * on the device): the supervised step of reference src/core/trainers/seg_trainer.py:141-142 without autograd.

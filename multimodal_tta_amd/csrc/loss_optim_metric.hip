@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void dice_counts_kernel(TV z, TV lab, float th
 // ------------------------------------------------------------------ DiceCE sums (evaluation report_loss)
 // per (n,r): sum p*y, sum p (or p^2), sum y (or y^2), p = sigmoid(z); plus the CE numerator:
 // R == 1: BCE-with-logits (pos_weight);  R > 1: soft-label softmax CE  -sum_r w_r y_r log_softmax(z)_r.
-// out fp64 [N][R*3 + 1], zeroed by the host wrapper; fp64 atomics (deterministic enough for a report).
+// Block partials [N][blocks_per_n][R*3 + 1] in the scratch buffer, summed in block order by dice_ce_finish_kernel:
+// no atomics, the sums (and the gradient built from them) are bitwise reproducible.
 constexpr int DCE_MAX_R = 8;
 __global__ __launch_bounds__(256) void dice_ce_sums_kernel(TV z, TV lab, const float* weight, int squared,
                                                            double* out, int blocks_per_n) {
@@ -260,10 +261,19 @@ __global__ __launch_bounds__(256) void dice_ce_sums_kernel(TV z, TV lab, const f
     const double t = block_sum_d(acc[i], sh);
     if (threadIdx.x == 0) {
       const int col = (i == DCE_MAX_R * 3) ? R * 3 : i;
-      atomicAdd(out + (long long)n * (R * 3 + 1) + col, t);
+      out[((long long)n * blocks_per_n + bn) * (R * 3 + 1) + col] = t;     // block partial: no atomics, fixed order later
     }
     __syncthreads();
   }
+}
+
+// out[n][col] = sum over the block partials of batch item n, in block order (deterministic)
+__global__ __launch_bounds__(64) void dice_ce_finish_kernel(const double* part, int blocks_per_n, int cols, double* out) {
+  const int n = blockIdx.x / cols, col = blockIdx.x % cols;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < blocks_per_n; b += 64) s += part[((long long)n * blocks_per_n + b) * cols + col];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[(long long)n * cols + col] = s;
 }
 
 // Gradient of DiceCE (lambda_dice * Dice + lambda_ce * CE, reduction mean) with respect to the logits, from the
@@ -415,22 +425,34 @@ extern "C" int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_te
   return launch_status("dice counts");
 }
 
+static long long dice_ce_blocks_per_n(const mmtta_tensor* logits) {
+  const long long dhw = (long long)logits->d * logits->h * logits->w;
+  long long bpn = (dhw + 256 * 4 - 1) / (256 * 4);
+  if (bpn < 1) bpn = 1;
+  if (bpn > 1024) bpn = 1024;
+  return bpn;
+}
+
+extern "C" int64_t mmtta_dice_ce_scratch_bytes(const mmtta_tensor* logits) {
+  if (logits == nullptr || logits->c < 1 || logits->c > DCE_MAX_R) return -1;
+  return (int64_t)logits->n * dice_ce_blocks_per_n(logits) * (logits->c * 3 + 1) * (int64_t)sizeof(double);
+}
+
 extern "C" int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight,
-                                  int squared_pred, double* out, void* stream) {
-  MMTTA_CHECK(logits && label && out && logits->ptr && label->ptr, MMTTA_ERR_INVALID, "dice_ce: null argument");
+                                  int squared_pred, double* out, void* scratch, void* stream) {
+  MMTTA_CHECK(logits && label && out && scratch && logits->ptr && label->ptr, MMTTA_ERR_INVALID, "dice_ce: null argument");
   MMTTA_CHECK(logits->n == label->n && logits->c == label->c && logits->d == label->d && logits->h == label->h &&
                   logits->w == label->w, MMTTA_ERR_INVALID, "dice_ce: logits/label shape mismatch");
   MMTTA_CHECK(logits->c <= DCE_MAX_R, MMTTA_ERR_UNSUPPORTED, "dice_ce: more than %d regions", DCE_MAX_R);
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)logits->n * (logits->c * 3 + 1) * sizeof(double), s);
-  MMTTA_CHECK(e == hipSuccess, MMTTA_ERR_LAUNCH, "dice_ce: memset failed: %s", hipGetErrorString(e));
-  const long long dhw = (long long)logits->d * logits->h * logits->w;
-  long long bpn = (dhw + 256 * 8 - 1) / (256 * 8);
-  if (bpn < 1) bpn = 1;
-  if (bpn > 512) bpn = 512;
+  const long long bpn = dice_ce_blocks_per_n(logits);
+  const int cols = logits->c * 3 + 1;
   hipLaunchKernelGGL(dice_ce_sums_kernel, dim3((unsigned)(bpn * logits->n)), dim3(256), 0, s, tv(logits), tv(label), weight,
-                     squared_pred, out, (int)bpn);
-  return launch_status("dice_ce sums");
+                     squared_pred, (double*)scratch, (int)bpn);
+  int st = launch_status("dice_ce sums");
+  if (st) return st;
+  hipLaunchKernelGGL(dice_ce_finish_kernel, dim3(logits->n * cols), dim3(64), 0, s, (const double*)scratch, (int)bpn, cols, out);
+  return launch_status("dice_ce finish");
 }
 
 extern "C" int mmtta_dice_ce_grad(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight, int squared_pred,

@@ -437,12 +437,23 @@ def mask_dice_counts(logits: torch.Tensor, label_ncdhw: torch.Tensor, threshold:
                                              stream_ptr()), "mask_dice_counts")
 
 
+_DCE_SCRATCH: Dict[Tuple, torch.Tensor] = {}     # block partials of dice_ce_sums, per (device, size)
+
+
 def dice_ce_sums(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Optional[torch.Tensor], squared_pred: bool,
                  out: torch.Tensor, logits_channels_last: bool = True) -> None:
     tz = _desc_any(logits, logits_channels_last)
     tl = desc_ncdhw(label_ncdhw)
-    check(_lib.load().mmtta_dice_ce_sums(C.byref(tz), C.byref(tl), ptr(weight), 1 if squared_pred else 0, ptr(out),
-                                         stream_ptr()), "dice_ce_sums")
+    lib = _lib.load()
+    nbytes = int(lib.mmtta_dice_ce_scratch_bytes(C.byref(tz)))
+    if nbytes < 0:
+        check(-2, "dice_ce_scratch_bytes")
+    key = (logits.device.index, nbytes)
+    scratch = _DCE_SCRATCH.get(key)
+    if scratch is None:
+        scratch = _DCE_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=logits.device)
+    check(lib.mmtta_dice_ce_sums(C.byref(tz), C.byref(tl), ptr(weight), 1 if squared_pred else 0, ptr(out), ptr(scratch),
+                                 stream_ptr()), "dice_ce_sums")
 
 
 def dice_ce_grad(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Optional[torch.Tensor], squared_pred: bool,
