@@ -323,6 +323,24 @@ int mmtta_dice_ce_grad(const mmtta_tensor* logits, const mmtta_tensor* label, co
                        int jaccard, int include_background, float lambda_dice, float lambda_ce, float smooth_nr,
                        float smooth_dr, const double* sums, const mmtta_tensor* dlogits, void* stream);
 
+/* Surface metrics of the evaluation tail: percentile Hausdorff distance and average surface distance per
+ * (volume, region).  Replaces the MONAI calls of reference src/evaluation/seg_eval.py:312-340
+ * (`HausdorffDistanceMetric(include_background=True, reduction="none", percentile=95, directed=False)` built at
+ * :226-234 and `compute_average_surface_distance(..., symmetric=evaluation.surface.asd_symmetric)`), which run
+ * scipy on the host.  Edge voxels = mask minus its 6-neighbourhood erosion; distances are exact Euclidean, weighted
+ * by `spacing` (host pointer, 3 doubles in D,H,W order: the order the reference hands `evaluation.seg.spacing` to
+ * MONAI); the quantile interpolates linearly in float32 like torch.quantile.
+ *   pred_mask  uint8 [N,R,D,H,W] dense (the `mask` output of mmtta_mask_dice_counts)
+ *   label      fp32 any strides, ground truth = label > 0.5 (reference :306)
+ *   hd, asd    fp32 [N*R] on the device.  Both edge sets empty: hd = asd = NaN; exactly one empty: hd = NaN,
+ *              asd = +inf (MONAI returns inf distances there); the caller applies the reference's penalty and
+ *              sanitising (:342-355).
+ *   scratch    mmtta_surface_scratch_bytes(N*R, D, H, W) bytes (negative: extent above 1024 per axis).
+ * Results do not depend on scheduling (radix select + integer fixed-point sum): bitwise reproducible. */
+int64_t mmtta_surface_scratch_bytes(int64_t n_masks, int64_t d, int64_t h, int64_t w);
+int mmtta_surface_distances(const uint8_t* pred_mask, const mmtta_tensor* label, const double* spacing,
+                            double percentile, int asd_symmetric, float* hd, float* asd, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

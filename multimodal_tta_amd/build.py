@@ -15,7 +15,8 @@ from typing import List
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmmtta.so")
-SOURCES = ["api.hip", "conv_igemm.hip", "conv_direct.hip", "conv_wgrad.hip", "pointwise.hip", "loss_optim_metric.hip", "preproc.hip"]
+SOURCES = ["api.hip", "conv_igemm.hip", "conv_direct.hip", "conv_wgrad.hip", "pointwise.hip", "loss_optim_metric.hip", "preproc.hip",
+           "surface.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable",
          "-Wno-unused-but-set-variable"]
 

@@ -14,6 +14,7 @@ volumes across ranks (one process per GPU) and merges the per-volume table with 
 """
 from __future__ import annotations
 
+import math
 from collections import defaultdict
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -58,15 +59,18 @@ def dice_iou_from_counts(counts: torch.Tensor) -> Tuple[torch.Tensor, torch.Tens
 class RegionAccumulator:
     """float64 sums / counts per region, overall and per domain (reference seg_eval.py:250-270,363-378)."""
 
-    def __init__(self, region_order: Sequence[str]):
+    def __init__(self, region_order: Sequence[str], surface: bool = False):
         self.regions = list(region_order)
+        self.surface = bool(surface)
         R = len(self.regions)
         self._z = lambda: torch.zeros(R, dtype=torch.float64)
-        self.tot = [self._z() for _ in range(4)]       # sum_dice, cnt_dice, sum_iou, cnt_iou
-        self.dom: Dict[str, List[torch.Tensor]] = defaultdict(lambda: [self._z() for _ in range(4)])
+        # sum_dice, cnt_dice, sum_iou, cnt_iou, then (surface) sum_hd95, cnt_hd95, sum_asd, cnt_asd
+        self.tot = [self._z() for _ in range(8)]
+        self.dom: Dict[str, List[torch.Tensor]] = defaultdict(lambda: [self._z() for _ in range(8)])
         self.total_loss, self.n_samples = 0.0, 0
 
-    def add_row(self, dice: Sequence[float], iou: Sequence[float], valid: Sequence[bool], domain: str) -> None:
+    def add_row(self, dice: Sequence[float], iou: Sequence[float], valid: Sequence[bool], domain: str,
+                hd95: Optional[Sequence[float]] = None, asd: Optional[Sequence[float]] = None) -> None:
         d = self.dom[domain]
         for c in range(len(self.regions)):
             if bool(valid[c]):
@@ -76,6 +80,13 @@ class RegionAccumulator:
                     acc[1][c] += 1.0
                     acc[2][c] += iv
                     acc[3][c] += 1.0
+                if self.surface:
+                    hv, av = float(hd95[c]), float(asd[c])
+                    for acc in (self.tot, d):
+                        acc[4][c] += hv
+                        acc[5][c] += 1.0
+                        acc[6][c] += av
+                        acc[7][c] += 1.0
 
     def add_loss(self, loss: float, batch: int) -> None:
         self.total_loss += float(loss) * batch
@@ -99,15 +110,28 @@ class RegionAccumulator:
         out["miou"] = self._avg(mi, self.tot[3])
         out["jc"] = out["miou"]
         out["loss"] = float(self.total_loss / max(1, self.n_samples)) if report_loss else 0.0
+        if self.surface:        # reference seg_eval.py:424-440
+            self._surface_keys(out, "", self.tot)
         for dom in sorted(self.dom.keys()):
-            sd, cd, si, ci = self.dom[dom]
+            sd, cd, si, ci = self.dom[dom][:4]
             safe = dom if dom != "" else "unknown"
             dm, dim_ = self._fin(sd, cd), self._fin(si, ci)
             for name, v in zip(self.regions, dm):
                 out[f"dom/{safe}/{name.lower()}_dc"] = v
             out[f"dom/{safe}/avg_dc"] = self._avg(dm, cd)
             out[f"dom/{safe}/miou"] = self._avg(dim_, ci)
+            if self.surface:    # reference seg_eval.py:459-476
+                self._surface_keys(out, f"dom/{safe}/", self.dom[dom])
         return out
+
+    def _surface_keys(self, out: Dict[str, float], prefix: str, acc: List[torch.Tensor]) -> None:
+        mh, ma = self._fin(acc[4], acc[5]), self._fin(acc[6], acc[7])
+        for name, v in zip(self.regions, mh):
+            out[f"{prefix}{name.lower()}_hd95"] = v
+        out[f"{prefix}avg_hd95"] = self._avg(mh, acc[5])
+        for name, v in zip(self.regions, ma):
+            out[f"{prefix}{name.lower()}_asd"] = v
+        out[f"{prefix}avg_asd"] = self._avg(ma, acc[7])
 
 
 class DiceCEReport:
@@ -166,10 +190,10 @@ class SegmentationEvaluationStrategy:
             raise ValueError(f"[BratsSegEval] evaluation.seg.spacing must have length 3, got {sp}")
         self.spacing = tuple(float(v) for v in sp)
         self.report_loss = bool(get_config(self.config, "evaluation.loss.report_loss", False))
-        if bool(get_config(self.config, "evaluation.surface.enable", False)):
-            raise NotImplementedError(
-                "evaluation.surface.enable: HD95/ASD are outside the adaptation hot path (SURVEY.md section 8f, row 4); "
-                "the reference leaves them off by default (src/evaluation/seg_eval.py:195)")
+        # HD95 / ASD, off by default like the reference (src/evaluation/seg_eval.py:193-196)
+        surf = get_config(self.config, "evaluation.surface", {}) or {}
+        self.enable_surface = bool(get_config(surf, "enable", False))
+        self.asd_symmetric = bool(get_config(surf, "asd_symmetric", False))
         self.loss_fn = DiceCEReport(get_config(self.config, "training.criterion", {}) or {})
         # optional input pre-pass on the GPU (raw volumes in, the reference's `_normalize_img` applied here instead of
         # in the dataset worker; reference src/datasets/transforms.py:129-223).  Off by default: the synthetic source
@@ -207,28 +231,51 @@ class SegmentationEvaluationStrategy:
         return x, y.float()
 
     def score(self, logits: torch.Tensor, y: torch.Tensor, channels_last: bool = False) -> torch.Tensor:
-        """logits [B,R,D,H,W] (or channels-last view) + labels -> exact counts int64 [B,R,3] on the host."""
+        """logits [B,R,D,H,W] (or channels-last view) + labels -> exact counts int64 [B,R,3] on the host.
+        With ``evaluation.surface.enable`` the prediction mask is kept for :meth:`surface`."""
         R = y.shape[1]
         shape_ok = (logits.ndim == 5 and (logits.shape[-1] if channels_last else logits.shape[1]) == R)
         if not shape_ok:
             raise ValueError(f"[BratsSegEval] model logits must be [B,{R},D,H,W], got {tuple(logits.shape)}")
         counts = torch.empty((y.shape[0], R, 3), dtype=torch.int64, device=y.device)
-        ops.mask_dice_counts(logits, y, self.threshold, counts, None, logits_channels_last=channels_last)
+        self._mask = torch.empty(tuple(y.shape), dtype=torch.uint8, device=y.device) if self.enable_surface else None
+        ops.mask_dice_counts(logits, y, self.threshold, counts, self._mask, logits_channels_last=channels_last)
         return counts.cpu()
+
+    def surface(self, y: torch.Tensor, counts: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """HD95 / ASD [B,R] (host, fp32) of the masks of the last :meth:`score` call, with the reference's penalty
+        (GT non-empty, prediction empty -> volume diagonal in mm) and sanitising (non-finite -> diagonal) applied to
+        the valid entries (reference src/evaluation/seg_eval.py:312-355)."""
+        D, H, W = (int(v) for v in y.shape[2:])
+        sd, sh, sw = self.spacing
+        dd, hh, ww = max(D - 1, 0) * sd, max(H - 1, 0) * sh, max(W - 1, 0) * sw
+        diag_mm = float(math.sqrt(dd * dd + hh * hh + ww * ww))
+        hd, asd = ops.surface_distances(self._mask, y, self.spacing, 95.0, self.asd_symmetric)
+        hd, asd = hd.cpu(), asd.cpu()
+        valid = counts[..., 2] > 0
+        pred_empty = counts[..., 1] == 0
+        pen = valid & pred_empty
+        hd[pen] = diag_mm
+        asd[pen] = diag_mm
+        hd[(~torch.isfinite(hd)) & valid] = diag_mm
+        asd[(~torch.isfinite(asd)) & valid] = diag_mm
+        return hd, asd
 
     @torch.no_grad()
     def evaluate_epoch(self, model: torch.nn.Module, data_loader: Iterable, device) -> Dict[str, float]:
         model.eval()
         model.to(device)
-        acc = RegionAccumulator(self.region_order)
+        acc = RegionAccumulator(self.region_order, self.enable_surface)
         for batch in data_loader:
             x, y = self.check_batch(batch, device)
             logits = model(x)
             counts = self.score(logits.float(), y)
             dice, iou, valid = dice_iou_from_counts(counts)
+            hd, asd = self.surface(y, counts) if self.enable_surface else (None, None)
             domains = as_list_str(batch.get("domain", None), batch_size=x.size(0))
             for i in range(x.size(0)):
-                acc.add_row(dice[i].tolist(), iou[i].tolist(), valid[i].tolist(), domains[i])
+                acc.add_row(dice[i].tolist(), iou[i].tolist(), valid[i].tolist(), domains[i],
+                            hd[i].tolist() if hd is not None else None, asd[i].tolist() if asd is not None else None)
             if self.report_loss:
                 acc.add_loss(self.loss_fn(logits.float(), y), x.size(0))
         return acc.metrics(self.report_loss)
@@ -240,8 +287,8 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
-def table_width(R: int) -> int:
-    return 3 + 3 * R  # index, domain_id, loss, then dice[R], iou[R], valid[R]
+def table_width(R: int, surface: bool = False) -> int:
+    return 3 + (5 if surface else 3) * R  # index, domain_id, loss, then dice[R], iou[R], valid[R] (, hd95[R], asd[R])
 
 
 def gather_table(rows: torch.Tensor, n_items: int, world: int, group=None) -> torch.Tensor:
@@ -265,17 +312,19 @@ def gather_table(rows: torch.Tensor, n_items: int, world: int, group=None) -> to
 
 
 def metrics_from_table(table: torch.Tensor, region_order: Sequence[str], domain_names: Sequence[str],
-                       report_loss: bool) -> Dict[str, float]:
+                       report_loss: bool, surface: bool = False) -> Dict[str, float]:
     """Replay the reference aggregation over gathered rows in volume-index order: the result is
     identical to a single-process run (float64 sums, order fixed by index)."""
     R = len(region_order)
-    acc = RegionAccumulator(region_order)
+    acc = RegionAccumulator(region_order, surface)
     for row in table:
         dom = domain_names[int(row[1].item())] if 0 <= int(row[1].item()) < len(domain_names) else ""
         dice = row[3:3 + R].to(torch.float32).tolist()
         iou = row[3 + R:3 + 2 * R].to(torch.float32).tolist()
         valid = (row[3 + 2 * R:3 + 3 * R] > 0.5).tolist()
-        acc.add_row(dice, iou, valid, dom)
+        hd = row[3 + 3 * R:3 + 4 * R].to(torch.float32).tolist() if surface else None
+        asd = row[3 + 4 * R:3 + 5 * R].to(torch.float32).tolist() if surface else None
+        acc.add_row(dice, iou, valid, dom, hd, asd)
         if report_loss:
             acc.add_loss(float(row[2].item()), 1)
     return acc.metrics(report_loss)
@@ -314,11 +363,15 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
                 if domains[i] not in domain_names:
                     domain_names.append(domains[i])
                 gi = int(idx[i]) if idx is not None else n_local
-                row = torch.cat([torch.tensor([gi, domain_names.index(domains[i]), loss], dtype=torch.float64),
-                                 dice[0].double(), iou[0].double(), valid[0].double()])
+                parts = [torch.tensor([gi, domain_names.index(domains[i]), loss], dtype=torch.float64),
+                         dice[0].double(), iou[0].double(), valid[0].double()]
+                if self.enable_surface:
+                    hd, asd = self.surface(y[i:i + 1], counts)
+                    parts += [hd[0].double(), asd[0].double()]
+                row = torch.cat(parts)
                 rows.append(row)
                 n_local += 1
-        table = torch.stack(rows) if rows else torch.empty((0, table_width(R)), dtype=torch.float64)
+        table = torch.stack(rows) if rows else torch.empty((0, table_width(R, self.enable_surface)), dtype=torch.float64)
         if world > 1:
             # domain ids must mean the same on every rank: exchange the name lists
             names: List[Optional[List[str]]] = [None] * world
@@ -336,4 +389,4 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
             # ranks may hold unequal shares; gather_table pads to ceil(N/W) which bounds every share of a
             # round-robin shard
         self.last_table = table
-        return metrics_from_table(table, self.region_order, domain_names, self.report_loss)
+        return metrics_from_table(table, self.region_order, domain_names, self.report_loss, self.enable_surface)

@@ -468,3 +468,32 @@ def dice_ce_grad(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Option
                                          1 if jaccard else 0, 1 if include_background else 0, float(lambda_dice),
                                          float(lambda_ce), float(smooth_nr), float(smooth_dr), ptr(sums), C.byref(tg),
                                          stream_ptr()), "dice_ce_grad")
+
+
+_SURF_SCRATCH: Dict[Tuple, torch.Tensor] = {}    # working set of surface_distances, per (device, size)
+
+
+def surface_distances(pred_mask: torch.Tensor, label_ncdhw: torch.Tensor, spacing: Sequence[float],
+                      percentile: float = 95.0, asd_symmetric: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pred_mask uint8 [B,R,D,H,W] (dense; from ``mask_dice_counts``) + labels -> (hd, asd) fp32 [B,R] on the device,
+    as MONAI returns them (reference src/evaluation/seg_eval.py:327-341); the evaluator applies the fix-ups."""
+    if pred_mask.dtype != torch.uint8 or not pred_mask.is_contiguous() or pred_mask.shape != label_ncdhw.shape:
+        raise MmttaError(f"surface_distances: mask must be dense uint8 of the label's shape, got {pred_mask.dtype} "
+                         f"{tuple(pred_mask.shape)} vs {tuple(label_ncdhw.shape)}")
+    B, R, D, H, W = (int(v) for v in pred_mask.shape)
+    lib = _lib.load()
+    nbytes = int(lib.mmtta_surface_scratch_bytes(B * R, D, H, W))
+    if nbytes < 0:
+        raise MmttaError(f"surface_distances: extent {(D, H, W)} unsupported (at most 1024 per axis)")
+    key = (pred_mask.device.index, nbytes)
+    scratch = _SURF_SCRATCH.get(key)
+    if scratch is None:
+        _SURF_SCRATCH.clear()
+        scratch = _SURF_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=pred_mask.device)
+    hd = torch.empty((B, R), dtype=torch.float32, device=pred_mask.device)
+    asd = torch.empty((B, R), dtype=torch.float32, device=pred_mask.device)
+    sp = (C.c_double * 3)(*[float(v) for v in spacing])
+    tl = desc_ncdhw(label_ncdhw)
+    check(lib.mmtta_surface_distances(ptr(pred_mask), C.byref(tl), sp, float(percentile), 1 if asd_symmetric else 0,
+                                      ptr(hd), ptr(asd), ptr(scratch), stream_ptr()), "surface_distances")
+    return hd, asd

@@ -39,3 +39,4 @@ MODELS = {
     "unet_multimodal_midfusion": MultimodalUNetDeepFusion,
 }
 from .transforms import normalize_image  # noqa: F401,E402
+from .surface import hd_asd, evaluator_surface, mask_edges, diag_mm  # noqa: F401,E402

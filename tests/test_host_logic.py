@@ -109,8 +109,9 @@ def test_evaluator_config_and_batch_checks():
     assert s.loss_fn.lambda_dice == 5.0 and s.loss_fn.weight == [50.0] and not s.loss_fn.include_background
     with pytest.raises(ValueError, match="spacing"):
         SegmentationEvaluationStrategy({"evaluation": {"seg": {"spacing": [1, 1]}}})
-    with pytest.raises(NotImplementedError):
-        SegmentationEvaluationStrategy({"evaluation": {"surface": {"enable": True}}})
+    assert not s.enable_surface and not s.asd_symmetric                   # off by default (reference seg_eval.py:193-196)
+    on = SegmentationEvaluationStrategy({"evaluation": {"surface": {"enable": True, "asd_symmetric": True}}})
+    assert on.enable_surface and on.asd_symmetric
     with pytest.raises(KeyError, match="label"):
         s.check_batch({"image": torch.zeros(1, 2, 4, 4, 4)}, "cpu")
     with pytest.raises(ValueError, match="channels=3"):
@@ -217,3 +218,23 @@ def test_oracle_normalize_image_semantics():
     assert torch.allclose(y[1].flatten(), (pt - pt.mean()) / pt.std(unbiased=False))
     z = oracle.normalize_image(x, intensity_policy={"enabled": False}, mean=[1.0, 2.0], std=[2.0, 4.0])
     assert torch.allclose(z[1], (x[1] - 2.0) / 4.0) and torch.equal(oracle.normalize_image(x, normalize=False), x)
+
+
+def test_surface_columns_travel_through_the_gather_table():
+    """With evaluation.surface.enable the per-volume table grows by hd95[R] + asd[R] and the replayed aggregation
+    emits the reference's key set (src/evaluation/seg_eval.py:424-440,459-476)."""
+    from multimodal_tta_amd.evaluation import RegionAccumulator, metrics_from_table, table_width
+    regions = ["ET", "TC", "WT"]
+    R = 3
+    assert table_width(R) == 12 and table_width(R, True) == 18
+    rows = torch.tensor([[0, 0, 0.5, .9, .8, .7, .8, .7, .6, 1, 1, 0, 2.0, 3.0, 9.0, 1.0, 1.5, 9.0],
+                         [1, 1, 0.7, .5, .4, .3, .4, .3, .2, 1, 0, 1, 4.0, 9.0, 6.0, 2.0, 9.0, 2.5]], dtype=torch.float64)
+    m = metrics_from_table(rows, regions, ["a", "b"], True, surface=True)
+    assert m["et_hd95"] == 3.0 and m["tc_hd95"] == 3.0 and m["wt_hd95"] == 6.0      # invalid entries (9.0) skipped
+    assert m["avg_hd95"] == 4.0 and m["et_asd"] == 1.5 and m["avg_asd"] == (1.5 + 1.5 + 2.5) / 3
+    assert m["dom/a/et_hd95"] == 2.0 and m["dom/b/wt_asd"] == 2.5 and m["dom/a/wt_hd95"] == 0.0
+    keys = list(m)
+    assert keys.index("loss") < keys.index("et_hd95") < keys.index("avg_hd95") < keys.index("et_asd") < keys.index("avg_asd")
+    acc = RegionAccumulator(regions, surface=False)
+    acc.add_row([.9, .8, .7], [.8, .7, .6], [True, True, False], "a")
+    assert not any("hd95" in k or "asd" in k for k in acc.metrics(False))

@@ -159,3 +159,41 @@ def test_unet_structure_details():
         oracle.UNet(dict(cfg, in_channels="auto"))
     assert oracle.UNet(dict(cfg, in_channels="auto"), in_channels=2).in_channels == 2
     assert sum(p.numel() for p in torch.nn.InstanceNorm3d(8).parameters()) == 0
+
+
+def test_surface_oracle_known_answers():
+    """Hand-computable cases for oracle/surface.py (MONAI semantics restated; reference seg_eval.py:312-360)."""
+    import math
+    import numpy as np
+    import oracle
+    a = np.zeros((8, 9, 10), bool)
+    b = np.zeros((8, 9, 10), bool)
+    a[1, 2, 3] = True
+    b[4, 6, 3] = True
+    hd, asd = oracle.hd_asd(a, b)                                  # single voxels: 3-4-5 triangle
+    assert hd == 5.0 and asd == 5.0
+    hd, asd = oracle.hd_asd(a, b, spacing=(2.0, 1.0, 1.0))
+    assert hd == float(np.float32(math.sqrt(36 + 16)))
+    cube = np.zeros((12, 12, 12), bool)
+    cube[3:9, 3:9, 3:9] = True
+    e = oracle.mask_edges(cube)
+    assert e.sum() == 6 ** 3 - 4 ** 3 and not e[5, 5, 5] and e[3, 5, 5]      # the shell of the cube
+    shifted = np.roll(cube, 2, axis=2)
+    hd, asd = oracle.hd_asd(cube, shifted, percentile=100.0)
+    assert hd == 2.0 and 0.0 < asd < 2.0
+    border = np.zeros((6, 6, 6), bool)
+    border[0:3] = True                                              # touches the volume border: still an edge there
+    assert oracle.mask_edges(border)[0].all() and oracle.mask_edges(border)[2].all() and oracle.mask_edges(border)[1, 0, 0]
+    assert not oracle.mask_edges(border)[1, 2, 2]
+    empty = np.zeros_like(cube)
+    assert math.isnan(oracle.hd_asd(empty, empty)[0]) and math.isnan(oracle.hd_asd(empty, empty)[1])
+    hd, asd = oracle.hd_asd(cube, empty)
+    assert math.isnan(hd) and math.isinf(asd)
+    # evaluator fix-ups: empty prediction with GT -> diagonal; empty GT -> left alone (not accumulated by the caller)
+    pred = torch.zeros(1, 2, 12, 12, 12, dtype=torch.uint8)
+    gt = torch.zeros(1, 2, 12, 12, 12, dtype=torch.uint8)
+    gt[0, 0] = torch.from_numpy(cube)
+    pred[0, 1] = torch.from_numpy(cube)
+    hd, asd = oracle.evaluator_surface(pred, gt, (1.0, 1.0, 1.0))
+    assert abs(float(hd[0, 0]) - math.sqrt(3 * 121)) < 1e-5 and abs(float(asd[0, 0]) - math.sqrt(3 * 121)) < 1e-5
+    assert not math.isfinite(float(hd[0, 1]))
