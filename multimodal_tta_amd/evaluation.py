@@ -195,11 +195,14 @@ class SegmentationEvaluationStrategy:
         self.enable_surface = bool(get_config(surf, "enable", False))
         self.asd_symmetric = bool(get_config(surf, "asd_symmetric", False))
         self.loss_fn = DiceCEReport(get_config(self.config, "training.criterion", {}) or {})
-        # optional input pre-pass on the GPU (raw volumes in, the reference's `_normalize_img` applied here instead of
-        # in the dataset worker; reference src/datasets/transforms.py:129-223).  Off by default: the synthetic source
-        # and the reference's own datasets hand over normalised images.
+        # input pre-pass on the GPU (raw volumes in, the reference's `_normalize_img` applied here instead of in the
+        # dataset worker; reference src/datasets/transforms.py:129-223).  The NIfTI datasets of this package hand over
+        # raw intensities, so the pre-pass defaults to on for them and to off for the synthetic source (already
+        # normalised); `training.data.transforms.normalize_on_device` overrides either way.
         tcfg = get_config(self.config, "training.data.transforms", {}) or {}
-        self.normalize_on_device = bool(get_config(tcfg, "normalize_on_device", False))
+        synthetic = bool(get_config(self.config, "dataset.synthetic.enabled", True))
+        nod = get_config(tcfg, "normalize_on_device", None)
+        self.normalize_on_device = (not synthetic) if nod is None else bool(nod)
         self._tcfg = tcfg
 
     def prepare_image(self, x: torch.Tensor) -> torch.Tensor:
