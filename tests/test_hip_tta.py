@@ -10,6 +10,7 @@ max|logits|), masks may differ in at most 1e-4 of the
 voxels, Dice within 1e-3.
 """
 import copy
+import os
 
 import pytest
 import torch
@@ -316,3 +317,59 @@ def test_adaptation_variants_match_the_oracle(variant):
     for t, (a, b) in enumerate(zip(res["losses"].cpu().tolist(), out_ref["losses"])):
         assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, f"{variant} step {t}: loss {a} vs oracle {b}"
     logits_close(plug.logits(res).cpu(), out_ref, ref0, x, cfg["training"], steps=3, params=params, softmax=softmax)
+
+
+def test_nifti_cases_evaluate_end_to_end(tmp_path):
+    """SURVEY.md section 8f rows 4 + 2 joined to the hot path: NIfTI files -> BraTS builder -> GPU normalisation
+    pre-pass -> forward -> Dice, against the oracle fed by the same files (oracle normalisation + oracle masks)."""
+    import numpy as np
+    import oracle
+    from multimodal_tta_amd import nifti
+    from multimodal_tta_amd.registry import get_dataset_builder, get_evaluation_strategy
+    import pandas as pd
+    root = str(tmp_path)
+    rows = []
+    for i in range(2):
+        x, y = volume(10 + i)
+        lab = (y[0, 2] + y[0, 1] + y[0, 0]).numpy()                  # nested regions -> ids: WT only 1, TC 2, ET 3
+        ids = np.where(lab == 3, 3, np.where(lab == 2, 1, np.where(lab == 1, 2, 0))).astype(np.int16)
+        lp = os.path.join(root, f"c{i}_seg.nii.gz")
+        nifti.write_nifti(lp, ids.transpose(2, 1, 0))                # on disk (X, Y, Z)
+        for m, mod in enumerate(("t1n", "t1c", "t2w", "t2f")):
+            ip = os.path.join(root, f"c{i}_{mod}.nii.gz")
+            nifti.write_nifti(ip, (x[0, m] * 37.0 + 100.0 * (x[0, m] != 0)).numpy().transpose(2, 1, 0).astype(np.float32))
+            rows.append({"subject_id": f"c{i}", "modality": mod, "img_path": ip, "label_path": lp, "split": "test"})
+    csv = os.path.join(root, "processed.csv")
+    pd.DataFrame(rows).to_csv(csv, index=False)
+    cfg = root_cfg(SMALL)
+    cfg["dataset"]["synthetic"]["enabled"] = False
+    cfg["dataset"]["expected_shape"] = [32, 32, 32]
+    cfg["dataset"]["sources"] = [{"name": "site_a", "profile": "gli", "csv_path": csv}]
+    cfg["training"]["num_workers"] = 0
+    cfg["training"]["eval_batch_size"] = 1
+    t = cfg["training"]["data"]["transforms"]
+    t["image_size"] = [32, 32, 32]
+    t["normalize"] = True
+    t["mean"], t["std"] = [50.0, 60.0, 70.0, 80.0], [30.0, 31.0, 32.0, 33.0]
+    ref, hip = build_pair(SMALL)
+    loader = get_dataset_builder("brats")(cfg).get_loader("test")
+    strat = get_evaluation_strategy("seg_eval")(cfg)
+    assert strat.normalize_on_device
+    got = strat.evaluate_epoch(hip, loader, torch.device("cuda"))
+    acc = oracle.RegionAccumulator(["ET", "TC", "WT"])
+    ref.eval()
+    n_diff = 0
+    with torch.no_grad():
+        for batch in loader:
+            xn = oracle.normalize_image(batch["image"][0], mean=t["mean"], std=t["std"])[None]
+            z = ref(xn)
+            pred, gt = oracle.masks_from_logits(z, batch["label"], 0.5)
+            zh = hip(strat.prepare_image(batch["image"].cuda())).cpu()
+            n_diff += int(((zh >= 0) != (z >= 0)).sum())
+            d, i_, v = oracle.binary_dice_iou(pred, gt)
+            acc.add(d, i_, v, list(batch["domain"]))
+    want = acc.metrics(report_loss=False)
+    assert "dom/site_a/avg_dc" in got
+    for k in ("et_dc", "tc_dc", "wt_dc", "avg_dc", "miou", "dom/site_a/avg_dc"):
+        # fp32 model on both sides: only voxels whose logit sits within rounding of 0 may flip
+        assert abs(got[k] - want[k]) <= 2e-3 * max(abs(want[k]), 1e-3) + 1e-6 * n_diff + 1e-6, (k, got[k], want[k], n_diff)
