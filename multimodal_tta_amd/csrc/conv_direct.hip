@@ -16,6 +16,9 @@
 
 namespace mmtta {
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
 struct DArgs {
   TV in; NL tin;
   TV out;
@@ -875,6 +878,167 @@ static void launch_row_n(const DArgs& a, int n, hipStream_t stream) {
   }
 }
 
+// ------------------------------------------------------------------ the same up-convolution on the matrix cores
+// `bf16` precision mode.  Per tap the work is [R x K] x [K x 64 voxels]: far too thin for a tiled GEMM, but the fp32
+// VALU form above is bound by the latency of its LDS + scalar operand fetches (both count on lgkmcnt, so every weight
+// use waits for all LDS reads in flight).  Here the weights are the A operand (rows = output channel, 32 rows of which
+// R <= 4 are non-zero) and the staged activations the B operand (columns = 32 voxels of the row) of
+// v_mfma_f32_32x32x16_bf16: lanes 0-31 end with accumulator rows 0..3 = the R outputs of "their" voxel, exactly what the
+// shared epilogue wants, and one ds_read_b128 per lane feeds 32 x 32 x 16 MACs.  Staging, parity classes and epilogue
+// are those of direct_upconv_kernel; the weights are rounded to bf16 into a compact LDS image [tap][K/16][half][4 rows].
+typedef __bf16 ubf16x8 __attribute__((ext_vector_type(8)));
+typedef float ufloat16 __attribute__((ext_vector_type(16)));
+
+template <int K, int NO, bool HAS_T>
+__global__ __launch_bounds__(256) void upconv_mfma_kernel(DArgs a) {
+  extern __shared__ float lds[];
+  constexpr int VS = K / 2 + 4;                // LDS voxel stride (dwords): conflict-free ds_read_b128 across voxels
+  constexpr int XV = 65;
+  constexpr int KS = K / 16;                   // MFMA k-steps per tap
+  uint4* wimg = reinterpret_cast<uint4*>(lds + 4 * XV * VS);          // [27][KS][2][4] x 8 bf16
+  float* red = lds + 4 * XV * VS + 27 * KS * 2 * 4 * 4;
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunks = (a.in.w + 63) / 64;
+  int b = blockIdx.x;
+  const int chunk = b % chunks; b /= chunks;
+  const int iy0 = b % a.in.h;
+  const int iz0 = b / a.in.h;
+  const int ix0 = chunk * 64;
+  {  // ---- stage the four input rows (normalised, rounded to bf16)
+    constexpr int CG = K / 4;
+    constexpr int NIT = (4 * XV * CG + 255) / 256;
+    const int cg = tid % CG;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_T) nl_coeff_vec<4>(a.tin, n, K, cg * 4, sc, sh);
+    const float* inb = a.in.p + (long long)n * a.in.sn + cg * 4;
+    float4 raw[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int vs = min(tid / CG + q * (256 / CG), 4 * XV - 1);
+      const int row = vs / XV, xl = vs % XV;
+      const int iz = min(iz0 + (row >> 1), a.in.d - 1), iy = min(iy0 + (row & 1), a.in.h - 1), ix = min(ix0 + xl, a.in.w - 1);
+      raw[q] = *reinterpret_cast<const float4*>(inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw);
+    }
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int vs = tid / CG + q * (256 / CG);
+      if (vs < 4 * XV) {
+        const int row = vs / XV, xl = vs % XV;
+        const bool ok = iz0 + (row >> 1) < a.in.d && iy0 + (row & 1) < a.in.h && ix0 + xl < a.in.w;
+        float4 v;
+        v.x = ok ? (HAS_T ? nl_apply(raw[q].x, sc[0], sh[0], a.tin.relu) : raw[q].x) : 0.f;
+        v.y = ok ? (HAS_T ? nl_apply(raw[q].y, sc[1], sh[1], a.tin.relu) : raw[q].y) : 0.f;
+        v.z = ok ? (HAS_T ? nl_apply(raw[q].z, sc[2], sh[2], a.tin.relu) : raw[q].z) : 0.f;
+        v.w = ok ? (HAS_T ? nl_apply(raw[q].w, sc[3], sh[3], a.tin.relu) : raw[q].w) : 0.f;
+        uint2 pk;
+        pk.x = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){v.x, v.y}, bf16x2_t));
+        pk.y = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){v.z, v.w}, bf16x2_t));
+        *reinterpret_cast<uint2*>(lds + vs * VS + cg * 2) = pk;
+      }
+    }
+  // ---- weight image: entry ((tap * KS + s) * 2 + half) * 4 + row holds w[tap][s*16 + half*8 + 0..7][row] as bf16.
+  // One thread per (tap, s, half): eight contiguous 16-byte loads (8 channels x 4 rows), four entries out.
+  if (tid < 27 * KS * 2) {
+    const float4* wp = reinterpret_cast<const float4*>(a.w) + tid * 8;      // (tap*K + s*16 + half*8) = tid * 8
+    float4 wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = wp[j];
+    auto comp = [](const float4& v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      uint4 pk = make_uint4(0u, 0u, 0u, 0u);
+      if (row < NO) {
+        pk.x = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){comp(wv[0], row), comp(wv[1], row)}, bf16x2_t));
+        pk.y = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){comp(wv[2], row), comp(wv[3], row)}, bf16x2_t));
+        pk.z = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){comp(wv[4], row), comp(wv[5], row)}, bf16x2_t));
+        pk.w = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){comp(wv[6], row), comp(wv[7], row)}, bf16x2_t));
+      }
+      wimg[tid * 4 + row] = pk;
+    }
+  }
+  }
+  __syncthreads();
+  const int h = lane >> 5, r = lane & 31;
+  const bool wrow = r < 4;                     // lanes that hold a (possibly zero) weight row
+  float ssum[NO], ssq[NO];
+#pragma unroll
+  for (int c = 0; c < NO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+  // (Dealing the 16 (class, half-row) jobs evenly over the waves was measured slower, 84 vs 70 us at 64^3 -> 128^3:
+  // the kernel is bound by staging and the scattered epilogue, not by the MFMA pipe.)
+  const int pz = wave >> 1, py = wave & 1;     // a wave owns one (z, y) parity; both x parities -> adjacent stores
+  float vals[2][NO];
+#pragma unroll
+  for (int px = 0; px < 2; ++px) {
+    ufloat16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+    for (int tz = 0; tz <= pz; ++tz) {
+      const int kz = pz == 0 ? 1 : (tz == 0 ? 2 : 0);
+      for (int ty = 0; ty <= py; ++ty) {
+        const int ky = py == 0 ? 1 : (ty == 0 ? 2 : 0);
+        for (int tx = 0; tx <= px; ++tx) {
+          const int kx = px == 0 ? 1 : (tx == 0 ? 2 : 0);
+          const int tap = (kz * 3 + ky) * 3 + kx;
+          const float* xrow = lds + ((tz * 2 + ty) * XV + tx + r) * VS + h * 4;
+          const uint4* wt = wimg + (tap * KS * 2 + h) * 4 + (wrow ? r : 0);
+          uint4 wq[KS], x0[KS], x1[KS];
+#pragma unroll
+          for (int s2 = 0; s2 < KS; ++s2) {
+            wq[s2] = wt[s2 * 8];
+            x0[s2] = *reinterpret_cast<const uint4*>(xrow + s2 * 8);
+            x1[s2] = *reinterpret_cast<const uint4*>(xrow + 32 * VS + s2 * 8);
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < KS; ++s2) {
+            if (!wrow) wq[s2] = make_uint4(0u, 0u, 0u, 0u);
+            const ubf16x8 af = __builtin_bit_cast(ubf16x8, wq[s2]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(ubf16x8, x0[s2]), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(ubf16x8, x1[s2]), acc[1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // lanes 0..31 hold accumulator rows 0..3 = the outputs of voxels r (acc[0]) and 32 + r (acc[1]); the second set
+    // moves to lanes 32..63 so that one full-width epilogue serves the 64 voxels of the row
+#pragma unroll
+    for (int c = 0; c < NO; ++c) {
+      const float upper = __shfl(acc[1][c], r);
+      vals[px][c] = h ? upper : acc[0][c];
+    }
+  }
+  {
+    const int oz = 2 * iz0 + pz, oy = 2 * iy0 + py;
+    const int ixl = ix0 + lane;
+    if (ixl < a.in.w && oz < a.out.d && oy < a.out.h) {
+      if (2 * ixl < a.out.w) direct_epilogue<NO>(a, n, oz, oy, 2 * ixl, vals[0], ssum, ssq);
+      if (2 * ixl + 1 < a.out.w) direct_epilogue<NO>(a, n, oz, oy, 2 * ixl + 1, vals[1], ssum, ssq);
+    }
+  }
+  direct_stats<NO>(a, n, ssum, ssq, red);
+}
+
+template <int K, bool HAS_T>
+static void launch_upconv_mfma(const DArgs& a, int n, hipStream_t stream) {
+  const dim3 grid(a.blocks_per_n, n), block(256);
+  const size_t lds = ((size_t)4 * 65 * (K / 2 + 4) + 27 * (K / 16) * 2 * 4 * 4 + 32) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<K, 1, HAS_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<K, 2, HAS_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<K, 3, HAS_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<K, 4, HAS_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  switch (a.N) {
+    case 1: hipLaunchKernelGGL((upconv_mfma_kernel<K, 1, HAS_T>), grid, block, lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((upconv_mfma_kernel<K, 2, HAS_T>), grid, block, lds, stream, a); break;
+    case 3: hipLaunchKernelGGL((upconv_mfma_kernel<K, 3, HAS_T>), grid, block, lds, stream, a); break;
+    default: hipLaunchKernelGGL((upconv_mfma_kernel<K, 4, HAS_T>), grid, block, lds, stream, a); break;
+  }
+}
+
 template <int K, bool HAS_T>
 static void launch_upconv(const DArgs& a, int n, hipStream_t stream) {
   const dim3 grid(a.blocks_per_n, n), block(256);
@@ -893,6 +1057,11 @@ static void launch_upconv(const DArgs& a, int n, hipStream_t stream) {
     case 3: hipLaunchKernelGGL((direct_upconv_kernel<K, 3, HAS_T>), grid, block, lds, stream, a); break;
     default: hipLaunchKernelGGL((direct_upconv_kernel<K, 4, HAS_T>), grid, block, lds, stream, a); break;
   }
+}
+
+template <int K, bool HAS_T>
+static void launch_upconv_p(const DArgs& a, int n, bool bf, hipStream_t stream) {
+  if (bf) launch_upconv_mfma<K, HAS_T>(a, n, stream); else launch_upconv<K, HAS_T>(a, n, stream);
 }
 
 template <bool HAS_T>
@@ -948,8 +1117,9 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
     return launch_status("direct conv (row)");
   }
   if (variant == 3) {
-    if (a.K == 64) { if (has_t) launch_upconv<64, true>(a, y->n, stream); else launch_upconv<64, false>(a, y->n, stream); }
-    else { if (has_t) launch_upconv<32, true>(a, y->n, stream); else launch_upconv<32, false>(a, y->n, stream); }
+    const bool bf = d->dtype == MMTTA_BF16;
+    if (a.K == 64) { if (has_t) launch_upconv_p<64, true>(a, y->n, bf, stream); else launch_upconv_p<64, false>(a, y->n, bf, stream); }
+    else { if (has_t) launch_upconv_p<32, true>(a, y->n, bf, stream); else launch_upconv_p<32, false>(a, y->n, bf, stream); }
     return launch_status("direct up-convolution");
   }
   if (has_t) hipLaunchKernelGGL(direct_conv_kernel<true>, dim3(a.blocks_per_n, y->n), dim3(256), lds, stream, a);
