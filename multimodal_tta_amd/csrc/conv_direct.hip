@@ -18,6 +18,8 @@ namespace mmtta {
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 ubf16x8 __attribute__((ext_vector_type(8)));
+typedef float ufloat16 __attribute__((ext_vector_type(16)));
 
 struct DArgs {
   TV in; NL tin;
@@ -695,12 +697,169 @@ __global__ __launch_bounds__(256) void direct_chan_kernel(CArgs a) {
   }
 }
 
+// The same layers on the matrix cores (`bf16` precision mode): the 27 taps x 4 (padded) channels are the reduction axis
+// of v_mfma_f32_32x32x16_bf16, 7 k-steps of 16 = four taps each (tap 27 is a zero pad).  A = 32 voxels of the tile (one
+// z-slice per wave) gathered from the bf16 halo box, two 8-byte LDS reads (two taps) per lane and k-step; B = the lane's
+// output channel, 7 x NB fragments kept in registers for the whole tile; the accumulator layout (column = channel = lane
+// & 31) is already "lanes along N", so stores stay 128-byte rows and the statistics per-lane sums.
+template <int S, int KI, int NB, bool HAS_T>
+__global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
+  constexpr int TZ = 4, TY = 4, TX = 8;
+  constexpr int BZ = (TZ - 1) * S + 3, BY = (TY - 1) * S + 3, BX = (TX - 1) * S + 3, BOX = BZ * BY * BX;
+  __shared__ uint2 box[BOX];                       // 4 bf16 channels per voxel
+  __shared__ float red[2][4][32 * NB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  int t = blockIdx.x;
+  const int tile_in_n = t % a.tiles_per_n;
+  const int txi = t % a.tx; t /= a.tx;
+  const int tyi = t % a.ty; t /= a.ty;
+  const int tzi = t % a.tz;
+  const int n = t / a.tz;
+  const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
+  const int iz0 = oz0 * S - 1, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  const int N = a.out.c;
+  {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill / round to bf16
+    constexpr int NQ = (BOX + 255) / 256;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_T) nl_coeff_vec<4>(a.tin, n, KI, 0, sc, sh);
+    const float* inb = a.in.p + (long long)n * a.in.sn;
+    float4 raw[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int bv = min(tid + 256 * q, BOX - 1);
+      const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+      const int iz = min(max(iz0 + bz, 0), a.in.d - 1), iy = min(max(iy0 + by, 0), a.in.h - 1), ix = min(max(ix0 + bx, 0), a.in.w - 1);
+      raw[q] = *reinterpret_cast<const float4*>(inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int bv = tid + 256 * q;
+      if (bv < BOX) {
+        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+        const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
+        const float r4[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[k] = (ok && k < KI) ? (HAS_T ? nl_apply(r4[k], sc[k], sh[k], a.tin.relu) : r4[k]) : 0.f;
+        uint2 pk;
+        pk.x = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){v[0], v[1]}, bf16x2_t));
+        pk.y = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){v[2], v[3]}, bf16x2_t));
+        box[bv] = pk;
+      }
+    }
+  }
+  // ---- B fragments: k = s*16 + h*8 + e  <->  tap = s*4 + h*2 + (e >> 2), channel = e & 3; column = nb*32 + r
+  uint4 wfrag[7][NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = nb * 32 + r;
+    const float* wp = a.w + min(col, a.Np - 1);
+#pragma unroll
+    for (int s2 = 0; s2 < 7; ++s2) {
+      float wv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int tap = s2 * 4 + h * 2 + (e >> 2), c = e & 3;
+        const int tapc = tap < 27 ? tap : 26;
+        const float raw = c < KI ? wp[((long long)tapc * a.Kp + c) * a.Np] : 0.f;
+        wv[e] = (tap < 27 && c < KI && col < N) ? raw : 0.f;
+      }
+      uint4 pk;
+      pk.x = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[0], wv[1]}, bf16x2_t));
+      pk.y = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[2], wv[3]}, bf16x2_t));
+      pk.z = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[4], wv[5]}, bf16x2_t));
+      pk.w = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[6], wv[7]}, bf16x2_t));
+      wfrag[s2][nb] = pk;
+    }
+  }
+  float bias[NB], asc[NB], ash[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = min(nb * 32 + r, N - 1);
+    bias[nb] = a.bias ? a.bias[col] : 0.f;
+    asc[nb] = 1.f; ash[nb] = 0.f;
+    if (a.add) nl_coeff(a.tadd, n, N, col, asc[nb], ash[nb]);
+  }
+  __syncthreads();
+  // ---- A fragments: MFMA row m = r  <->  voxel (zl = wave, yl = m / 8, xl = m % 8)
+  ufloat16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+  {
+    const int xl = r % TX, yl = r / TX;
+    const uint2* bp = box + ((wave * S) * BY + yl * S) * BX + xl * S;
+    uint2 av[7][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 7; ++s2)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int tap = min(s2 * 4 + h * 2 + j, 26);           // tap 27: any valid address, its weights are zero
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        av[s2][j] = bp[(dz * BY + dy) * BX + dx];
+      }
+#pragma unroll
+    for (int s2 = 0; s2 < 7; ++s2) {
+      const uint4 a4 = make_uint4(av[s2][0].x, av[s2][0].y, av[s2][1].x, av[s2][1].y);
+      const ubf16x8 af = __builtin_bit_cast(ubf16x8, a4);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(ubf16x8, wfrag[s2][nb]), acc[nb], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: accumulator i of lane (h, r) = voxel m = (i & 3) + 8 * (i >> 2) + 4 * h, channel nb*32 + r
+  float ssum[NB], ssq[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) { ssum[nb] = 0.f; ssq[nb] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
+    const int oz = oz0 + wave, oy = oy0 + m / TX, ox = ox0 + m % TX;
+    const bool vok = oz < a.out.d && oy < a.out.h && ox < a.out.w;
+    const long long ooff = (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh + (long long)ox * a.out.sw;
+    const long long aoff = (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash + (long long)ox * a.asw;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = nb * 32 + r;
+      if (vok && col < N) {
+        float val = acc[nb][i] + bias[nb];
+        if (a.add) val += nl_apply(a.add[aoff + col], asc[nb], ash[nb], a.tadd.relu);
+        float* op = a.out.p + ooff + col;
+        if (a.accumulate) val += *op;
+        *op = val;
+        ssum[nb] += val; ssq[nb] += val * val;
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const float s0 = ssum[nb] + __shfl_xor(ssum[nb], 32, 64), s1 = ssq[nb] + __shfl_xor(ssq[nb], 32, 64);
+      if (h == 0) { red[0][wave][nb * 32 + r] = s0; red[1][wave][nb * 32 + r] = s1; }
+    }
+    __syncthreads();
+    if (tid < 32 * NB && tid < N) {
+      const float s0 = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+      const float s1 = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+      const long long row = (long long)n * a.tiles_per_n + tile_in_n;
+      a.stats[(row * 2 + 0) * N + tid] = s0;
+      a.stats[(row * 2 + 1) * N + tid] = s1;
+    }
+  }
+}
+
 bool chan_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y) {
   if (!(d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_DGRAD) || d->ksize != 3) return false;
   const int K = x->c, N = y->c;
   // N = 64 (one voxel per pass) measured slower than the fp32 implicit GEMM (109 vs 80 us on the 64->3 up-convolution's
   // input gradient: 27 LDS reads per voxel and wave); kept for N = 32, two voxels per pass
-  return K <= 4 && N == 32 && aligned16(x) && x->sw >= 4;
+  // N = 64 only on the matrix cores (bf16 mode): the input gradient of the 64->R up-convolution
+  return K <= 4 && (N == 32 || (N == 64 && d->dtype == MMTTA_BF16)) && aligned16(x) && x->sw >= 4;
 }
 
 int chan_tiles_per_n(const mmtta_tensor* y) { return ((y->d + 3) / 4) * ((y->h + 3) / 4) * ((y->w + 7) / 8); }
@@ -718,6 +877,22 @@ static void launch_chan_k(const CArgs& a, int K, int N, int blocks, hipStream_t 
     case 2: launch_chan_n<S, 2, HAS_T>(a, N, blocks, s); break;
     case 3: launch_chan_n<S, 3, HAS_T>(a, N, blocks, s); break;
     default: launch_chan_n<S, 4, HAS_T>(a, N, blocks, s); break;
+  }
+}
+
+template <int S, int KI, bool HAS_T>
+static void launch_chan_mfma_n(const CArgs& a, int N, int blocks, hipStream_t s) {
+  if (N > 32) hipLaunchKernelGGL((chan_mfma_kernel<S, KI, 2, HAS_T>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((chan_mfma_kernel<S, KI, 1, HAS_T>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+template <int S, bool HAS_T>
+static void launch_chan_mfma(const CArgs& a, int K, int N, int blocks, hipStream_t s) {
+  switch (K) {
+    case 1: launch_chan_mfma_n<S, 1, HAS_T>(a, N, blocks, s); break;
+    case 2: launch_chan_mfma_n<S, 2, HAS_T>(a, N, blocks, s); break;
+    case 3: launch_chan_mfma_n<S, 3, HAS_T>(a, N, blocks, s); break;
+    default: launch_chan_mfma_n<S, 4, HAS_T>(a, N, blocks, s); break;
   }
 }
 
@@ -741,6 +916,11 @@ int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_n
   const int blocks = a.tiles_per_n * y->n;
   const bool has_t = a.tin.mean != nullptr || a.tin.scale != nullptr;
   const int S = d->op == MMTTA_CONV_FWD ? d->stride : 2;       // CONVT_DGRAD: stride-2 gather
+  if (d->dtype == MMTTA_BF16) {
+    if (S == 1) { if (has_t) launch_chan_mfma<1, true>(a, x->c, y->c, blocks, stream); else launch_chan_mfma<1, false>(a, x->c, y->c, blocks, stream); }
+    else { if (has_t) launch_chan_mfma<2, true>(a, x->c, y->c, blocks, stream); else launch_chan_mfma<2, false>(a, x->c, y->c, blocks, stream); }
+    return launch_status("thin-K conv (bf16 MFMA)");
+  }
   if (S == 1) { if (has_t) launch_chan_k<1, true>(a, x->c, y->c, blocks, stream); else launch_chan_k<1, false>(a, x->c, y->c, blocks, stream); }
   else { if (has_t) launch_chan_k<2, true>(a, x->c, y->c, blocks, stream); else launch_chan_k<2, false>(a, x->c, y->c, blocks, stream); }
   return launch_status("direct conv (lanes along N)");
@@ -886,8 +1066,6 @@ static void launch_row_n(const DArgs& a, int n, hipStream_t stream) {
 // v_mfma_f32_32x32x16_bf16: lanes 0-31 end with accumulator rows 0..3 = the R outputs of "their" voxel, exactly what the
 // shared epilogue wants, and one ds_read_b128 per lane feeds 32 x 32 x 16 MACs.  Staging, parity classes and epilogue
 // are those of direct_upconv_kernel; the weights are rounded to bf16 into a compact LDS image [tap][K/16][half][4 rows].
-typedef __bf16 ubf16x8 __attribute__((ext_vector_type(8)));
-typedef float ufloat16 __attribute__((ext_vector_type(16)));
 
 template <int K, int NO, bool HAS_T>
 __global__ __launch_bounds__(256) void upconv_mfma_kernel(DArgs a) {

@@ -198,7 +198,9 @@ BF16_CASES = [
     (256, 512, 1, 1, False, (1, 4, 4, 4)),
     (64, 32, 3, 2, True, (1, 4, 4, 8)),
     (768, 128, 3, 2, True, (1, 2, 2, 2)),
-    (4, 32, 3, 2, False, (1, 16, 16, 16)),       # K < 16: stays on the fp32 kernel
+    (4, 32, 3, 2, False, (1, 16, 16, 16)),       # K <= 4: taps folded into the MFMA reduction (chan_mfma_kernel)
+    (3, 32, 3, 1, False, (1, 5, 7, 11)),         # ragged tile borders, stride 1
+    (1, 32, 3, 2, False, (2, 6, 10, 12)),        # single-modality encoder stem of the deep-fusion net
     (64, 3, 3, 2, True, (1, 5, 6, 70)),          # full-resolution up-convolution: bf16-staged activations, fp32 weights
     (32, 2, 3, 2, True, (2, 4, 4, 16)),
     (64, 1, 3, 2, True, (1, 3, 4, 9)),
