@@ -916,7 +916,8 @@ int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_n
   const int blocks = a.tiles_per_n * y->n;
   const bool has_t = a.tin.mean != nullptr || a.tin.scale != nullptr;
   const int S = d->op == MMTTA_CONV_FWD ? d->stride : 2;       // CONVT_DGRAD: stride-2 gather
-  if (d->dtype == MMTTA_BF16) {
+  // one input channel (the single-modality stems of the deep-fusion net) is 27 FMAs per output: the VALU kernel wins there
+  if (d->dtype == MMTTA_BF16 && (x->c >= 2 || y->c > 32)) {
     if (S == 1) { if (has_t) launch_chan_mfma<1, true>(a, x->c, y->c, blocks, stream); else launch_chan_mfma<1, false>(a, x->c, y->c, blocks, stream); }
     else { if (has_t) launch_chan_mfma<2, true>(a, x->c, y->c, blocks, stream); else launch_chan_mfma<2, false>(a, x->c, y->c, blocks, stream); }
     return launch_status("thin-K conv (bf16 MFMA)");

@@ -254,8 +254,26 @@ class ConvOp:
             e0 = PROFILER.begin()
             for _ in range(PROFILER.reps):
                 launch()
-            PROFILER.end(IGEMM_KERNELS[p.config], PROFILER.reps,
+            PROFILER.end(self._kernel_name(p.config, desc, x, y), PROFILER.reps,
                          self.flops(x, y, desc) * PROFILER.reps, e0, self._detail(desc.op, x))
+
+    def _kernel_name(self, config: int, desc, x: torch.Tensor, y: torch.Tensor) -> str:
+        """Profiler label of the kernel a conv_run call dispatches to (mirrors csrc: the thin layers have matrix-core
+        variants in bf16 mode; 'bf16' in the label selects the bf16 MFMA peak in bench.py)."""
+        name = IGEMM_KERNELS[config]
+        if int(desc.dtype) == BF16:
+            if config == 13 and (self.cin_of(desc) >= 2 or self.cout_of(desc) > 32):
+                return "chan_mfma_kernel<bf16>"
+            if config == 6 and int(desc.op) == CONVT_FWD and self.k == 3 and self.stride == 2 and self.cin in (32, 64):
+                return "upconv_mfma_kernel<bf16>"
+        return name
+
+    def cin_of(self, desc) -> int:
+        """Channels the op READS (dgrad ops run the layer backwards)."""
+        return self.cout if int(desc.op) in (CONV_DGRAD, CONVT_DGRAD) else self.cin
+
+    def cout_of(self, desc) -> int:
+        return self.cin if int(desc.op) in (CONV_DGRAD, CONVT_DGRAD) else self.cout
 
     def _detail(self, op: int, x: torch.Tensor) -> str:
         kind = {CONV_FWD: "fwd", CONV_DGRAD: "dgrad", CONVT_FWD: "fwdT", CONVT_DGRAD: "dgradT", -1: "wgrad"}[op]
