@@ -373,3 +373,45 @@ def test_nifti_cases_evaluate_end_to_end(tmp_path):
     for k in ("et_dc", "tc_dc", "wt_dc", "avg_dc", "miou", "dom/site_a/avg_dc"):
         # fp32 model on both sides: only voxels whose logit sits within rounding of 0 may flip
         assert abs(got[k] - want[k]) <= 2e-3 * max(abs(want[k]), 1e-3) + 1e-6 * n_diff + 1e-6, (k, got[k], want[k], n_diff)
+
+
+def test_main_entry_over_a_hecktor_manifest(tmp_path, capsys):
+    """`python main.py task=hecktor21 ... dataset.synthetic.enabled=false`: manifest.csv + NIfTI files -> target-centre
+    split -> GPU intensity policy (clip + masked z-score) -> S adaptation steps per volume -> Dice, HD95, ASD, per
+    centre keys.  Values are checked for sanity only; every stage has its own parity test."""
+    import json
+    import math
+    import numpy as np
+    import pandas as pd
+    import main as entry
+    from multimodal_tta_amd import nifti
+    root = str(tmp_path)
+    rows = []
+    shape = (32, 32, 16)                                              # on disk (X, Y, Z)
+    rng = np.random.RandomState(3)
+    for i, centre in enumerate(["CHUM", "CHUM", "CHUS", "CHUS"]):
+        zz, yy, xx = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+        blob = ((zz - 14 - i) ** 2 + (yy - 16) ** 2 + 4.0 * (xx - 8) ** 2) < 49
+        ct = (rng.randn(*shape) * 200 - 300 + 400 * blob).astype(np.float32)
+        pt = np.maximum(rng.randn(*shape) * 0.5 + 1.0 + 6.0 * blob, 0).astype(np.float32)
+        for kind, arr in (("ct", ct), ("pt", pt), ("gtvt", blob.astype(np.uint8))):
+            nifti.write_nifti(os.path.join(root, f"P{i}_{kind}.nii.gz"), arr, np.diag([-1.0, -1.0, 3.0, 1.0]))
+        rows.append({"patient_id": f"P{i}", "status": "ok", "ct_proc": f"P{i}_ct.nii.gz", "pt_proc": f"P{i}_pt.nii.gz",
+                     "gtvt_proc": f"P{i}_gtvt.nii.gz", "center_code": centre, "center_id": i // 2})
+    csv = os.path.join(root, "manifest.csv")
+    pd.DataFrame(rows).to_csv(csv, index=False)
+    metrics = entry.main([
+        "task=hecktor21", "dataset=hecktor21", "model=unet", "method=tta_entmin", "dataset.synthetic.enabled=false",
+        f"dataset.manifest_csv={csv}", f"dataset.root_dir={root}", "dataset.target_center=chus",
+        "dataset.expected_shape=[32,32,16]", "dataset.val_per_center=1", "training.num_workers=0",
+        "training.data.transforms.image_size=[16,32,32]", "model.channels=[4,8,16]", "model.strides=[2,2]",
+        "model.num_res_units=1", "method.steps=2", "method.precision=bf16", "evaluation.surface.enable=true",
+        "evaluation.seg.spacing=[3.0,1.0,1.0]"])
+    out = json.loads(capsys.readouterr().out)
+    assert out["strategy"] == "seg_tta_eval" and out["metrics"] == metrics
+    assert {"gtvt_dc", "avg_dc", "miou", "loss", "gtvt_hd95", "avg_hd95", "gtvt_asd", "avg_asd", "dom/CHUS/gtvt_dc",
+            "dom/CHUS/avg_hd95"} <= set(metrics)
+    assert not any(k.startswith("dom/CHUM") for k in metrics)          # only the target centre is tested
+    diag = math.sqrt((15 * 3.0) ** 2 + 31 ** 2 + 31 ** 2)
+    assert 0.0 <= metrics["avg_dc"] <= 1.0 and 0.0 <= metrics["gtvt_asd"] <= metrics["gtvt_hd95"] <= diag + 1e-3
+    assert metrics["loss"] > 0.0
