@@ -714,13 +714,16 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
       }
     }
     __syncthreads();
-#pragma unroll 4
+    // voxel v = 2*kk + h: the pair shares (zl, yl) and differs by one x step, so the box offset is a wave-uniform
+    // (scalar) term per kk plus a lane term that does not change inside the tile loop
+    const float* qlane = ql + toffl + h * a.si * 4;
+    const float* plane = pl + h * 32 + r;
+#pragma unroll 8
     for (int kk = 0; kk < MT / 2; ++kk) {
-      const int v = 2 * kk + h;
-      const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
-      const int gaddr = (((zl * a.si) * BY + yl * a.si) * BX + xl * a.si) * 4;
-      const float av = ql[gaddr + toffl];
-      const float b = pl[v * 32 + r];
+      const int xl0 = (2 * kk) % TX, yl = ((2 * kk) / TX) % TY, zl = (2 * kk) / (TX * TY);
+      const int gaddr = (((zl * a.si) * BY + yl * a.si) * BX + xl0 * a.si) * 4;
+      const float av = qlane[gaddr];
+      const float b = plane[kk * 64];
       dbacc += b;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc, 0, 0, 0);
     }

@@ -81,7 +81,7 @@ class EntropyMinimizationTTA:
         self.moddrop_p = float(get_config(md, "p", 0.0)) if bool(get_config(md, "enabled", False)) else 0.0
         self.moddrop_seed = int(get_config(md, "seed", 0))
         self.use_graph = bool(get_config(m, "use_graph", True))
-        self.side_streams = int(get_config(m, "side_streams", 2))   # 0: weight gradients stay on the main stream
+        self.side_streams = int(get_config(m, "side_streams", 0))   # 0: weight gradients stay on the main stream
         tr = get_config(cfg, "training", {}) or {}
         opt_name = str(get_config(tr, "optimizer", "adam")).lower()
         if opt_name != "adam":
