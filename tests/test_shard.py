@@ -15,14 +15,16 @@ R = 3
 REGIONS = ["ET", "TC", "WT"]
 
 
-def fake_rows(n):
+def fake_rows(n, surface=False):
     g = torch.Generator().manual_seed(5)
     rows = []
     for i in range(n):
         dice, iou = torch.rand(R, generator=g, dtype=torch.float64), torch.rand(R, generator=g, dtype=torch.float64)
         valid = (torch.rand(R, generator=g) > 0.3).double()
-        rows.append(torch.cat([torch.tensor([i, i % 2, 0.1 * i], dtype=torch.float64), dice.float().double(),
-                               iou.float().double(), valid]))
+        parts = [torch.tensor([i, i % 2, 0.1 * i], dtype=torch.float64), dice.float().double(), iou.float().double(), valid]
+        if surface:      # hd95[R], asd[R] (evaluation.surface.enable)
+            parts += [(40.0 * torch.rand(R, generator=g)).double(), (9.0 * torch.rand(R, generator=g)).double()]
+        rows.append(torch.cat(parts))
     return torch.stack(rows)
 
 
@@ -57,26 +59,31 @@ def test_metrics_from_table_equals_accumulator():
     assert acc.metrics(True) == metrics_from_table(rows, REGIONS, ["a", "b"], True)
 
 
-def _worker(rank, world, port, n, out_dir):
+def _worker(rank, world, port, n, out_dir, surface=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rows = fake_rows(n)
+    rows = fake_rows(n, surface)
     mine = rows[shard_indices(n, rank, world)]
     table = gather_table(mine, n, world)
     torch.save(table, os.path.join(out_dir, f"t{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_gather_table_two_processes_gloo(tmp_path):
+@pytest.mark.parametrize("surface", [False, True])
+def test_gather_table_two_processes_gloo(tmp_path, surface):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     n, world = 5, 2
-    mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
-    want = fake_rows(n)
+    mp.spawn(_worker, args=(world, port, n, str(tmp_path), surface), nprocs=world, join=True)
+    want = fake_rows(n, surface)
+    assert want.shape[1] == table_width(R, surface)
     for r in range(world):
         got = torch.load(os.path.join(str(tmp_path), f"t{r}.pt"), weights_only=True)
         assert torch.equal(got, want), f"rank {r}"
+    if surface:      # every rank replays the same aggregation, surface keys included
+        m = metrics_from_table(want, REGIONS, ["a", "b"], True, surface=True)
+        assert "avg_hd95" in m and "dom/a/avg_asd" in m and m["avg_hd95"] > 0.0
