@@ -581,6 +581,8 @@ static int launch_wgrad_bf16(const WArgs& a, int S, hipStream_t s) {
 // (tap, channel) pairs are flattened into the MFMA row index (27*4 = 108 <= 128 rows = 4 waves x 32), the
 // big tensor P is dense:      S[row=(tap,cs)][col=cb] = sum_o T(Q[o*si + tap - 1][cs]) * T(P[o][cb])
 // One MFMA per voxel pair and wave instead of seven, and no padded channels.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+
 struct W2Args {
   const float* q; long long qsn, qsd, qsh, qsw; int Cs, Dq, Hq, Wq; NL tq;
   const float* p; long long psn, psd, psh, psw; int Cb, Dp, Hp, Wp; NL tp;
@@ -589,6 +591,7 @@ struct W2Args {
   float* dbpart;   // [nsl][CBp] or null: per-channel sums of P (bias gradient when cb is the output channel)
   int tz, ty, tx, tiles, tiles_per_split, CBp;
   int qvec4, pvec4;
+  int bf;          // bf16 precision mode: operands rounded to bf16, 16 voxels per v_mfma_f32_32x32x16_bf16
 };
 
 __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
@@ -716,6 +719,25 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
     __syncthreads();
     // voxel v = 2*kk + h: the pair shares (zl, yl) and differs by one x step, so the box offset is a wave-uniform
     // (scalar) term per kk plus a lane term that does not change inside the tile loop
+    if (a.bf) {
+      // k = h*8 + e of MFMA step kk is voxel 16*kk + 8*h + e: with TX = 8 that is the x-row e = 0..7 at
+      // (yl, zl) = ((2*kk + h) % TY, (2*kk + h) / TY): 8 gathered values per operand, packed to bf16
+      const int xs = a.si * 4;
+#pragma unroll 2
+      for (int kk = 0; kk < MT / 16; ++kk) {
+        const int rowi = 2 * kk + h;
+        const int yl = rowi % TY, zl = rowi / TY;
+        const float* qp = ql + (((zl * a.si) * BY + yl * a.si) * BX) * 4 + toffl;
+        const float* pp = pl + (rowi * 8) * 32 + r;
+        float av[8], bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { av[e] = qp[e * xs]; bv[e] = pp[e * 32]; }
+        wbf16x8 af, bf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { af[e] = (__bf16)av[e]; bf[e] = (__bf16)bv[e]; dbacc += bv[e]; }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+      }
+    } else {
     const float* qlane = ql + toffl + h * a.si * 4;
     const float* plane = pl + h * 32 + r;
 #pragma unroll 8
@@ -726,6 +748,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
       const float b = plane[kk * 64];
       dbacc += b;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc, 0, 0, 0);
+    }
     }
     __syncthreads();
   }
@@ -1101,6 +1124,7 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
       return ((((uintptr_t)t->ptr) % 16 == 0) && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0) ? 1 : 0;
     };
     b.qvec4 = al4(w.q); b.pvec4 = al4(w.pb);
+    b.bf = (d->dtype == MMTTA_BF16 && w.ntaps == 27) ? 1 : 0;
     const int ext = w.ntaps == 1 ? 0 : 2;
     const int BZ = 3 * w.si + ext + 1, BY = 3 * w.si + ext + 1, BX = 7 * w.si + ext + 1;
     const size_t lds = ((size_t)BZ * BY * BX * 4 + 128 * 32) * sizeof(float);
