@@ -998,7 +998,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     w.tiles = w.tz * w.ty * w.tx * x->n;
     w.CGp = 128;
     w.CDp = roundup(w.pb->c, 32);
-    int S = 1024 / (w.CDp / 32);
+    int S = 512 / (w.CDp / 32);          // measured at 128^3 (256 / 512 / 768 / 1024 slabs: 56 / 46 / 57 / 57 us): one resident round of workgroups
     if (S < 1) S = 1;
     if (S > w.tiles) S = w.tiles;
     w.tps = (w.tiles + S - 1) / S;
