@@ -1024,7 +1024,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.CGp = roundup(w.g->c, 32);
   w.CDp = roundup(w.dn->c, 32);
   const int blocks_cc = (w.CGp / 32) * (w.CDp / 32);
-  int S = 512 / blocks_cc;
+  int S = 512 / blocks_cc;             // 256 measured slower overall (0.78 vs 0.76 ms of weight-gradient time per step)
   if (S < 1) S = 1;
   if (S > w.tiles) S = w.tiles;
   w.tps = (w.tiles + S - 1) / S;
