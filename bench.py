@@ -124,7 +124,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the adaptation path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK / WORLD_SIZE exported) the RCCL group is formed even for one rank, so a
+    # single-GPU box rehearses exactly the calls the N-GPU run makes (init, barrier, all_gather, all_reduce, destroy)
+    dist_on = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
@@ -167,7 +170,7 @@ def main():
     for i in range(max(args.warmup, lanes)):      # every lane captures its graph before the timed region
         one_volume(i % nvol)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -179,12 +182,12 @@ def main():
                       torch.zeros(args.steps, 2, dtype=torch.float64), dice.double(), iou.double(), valid.double()], dim=1)
     table = gather_table(rows.to(device), args.steps * world, world)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     assert table.shape == (args.steps * world, table_width(R))
@@ -269,7 +272,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, shape, args.tta_steps)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()            # rank 0 may still have been in its profile pass
         dist.destroy_process_group()
 

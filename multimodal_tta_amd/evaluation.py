@@ -302,7 +302,7 @@ def gather_table(rows: torch.Tensor, n_items: int, world: int, group=None) -> to
     per = (n_items + world - 1) // world
     pad = torch.full((per, rows.shape[1]), -1.0, dtype=torch.float64, device=rows.device)
     pad[:rows.shape[0]] = rows
-    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+    if not (dist.is_available() and dist.is_initialized()):
         allrows = pad
     else:
         bufs = [torch.empty_like(pad) for _ in range(world)]
