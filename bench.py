@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="D H W (default: 128^3 brats, 48x144x144 hecktor)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="bf16 (BASELINE configs[1]): bf16 MFMA operands, fp32 accumulate/storage; fp32: exact fp32 MFMA")
-    ap.add_argument("--lanes", type=int, default=1,
+    ap.add_argument("--lanes", type=int, default=None,
                     help="volumes adapted concurrently per GPU, each with its own weights, buffers, graph and stream "
                          "(episodic adaptation has no cross-volume state; one volume alone leaves most CUs waiting)")
     ap.add_argument("--side-streams", type=int, default=None, help="side streams for the weight gradients (default: config)")
@@ -141,7 +141,7 @@ def main():
     torch.manual_seed(42)
     model = get_model(cfg["model"]["name"])(cfg["model"])
     plug = get_plugin("entmin_tta")(cfg).setup(model, device)
-    lanes = max(1, int(args.lanes))
+    lanes = max(1, int(args.lanes if args.lanes is not None else cfg["method"].get("lanes", 1)))
     plugs, streams = [plug], [torch.cuda.Stream(device=device)]
     for lane in range(1, lanes):          # same source weights in every lane (episodic: restored per volume)
         m2 = get_model(cfg["model"]["name"])(cfg["model"])

@@ -466,7 +466,7 @@ def dice_ce_sums(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Option
     nbytes = int(lib.mmtta_dice_ce_scratch_bytes(C.byref(tz)))
     if nbytes < 0:
         check(-2, "dice_ce_scratch_bytes")
-    key = (logits.device.index, nbytes)
+    key = (logits.device.index, nbytes, int(torch.cuda.current_stream().cuda_stream))   # per stream: lanes run concurrently
     scratch = _DCE_SCRATCH.get(key)
     if scratch is None:
         scratch = _DCE_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=logits.device)
@@ -503,10 +503,11 @@ def surface_distances(pred_mask: torch.Tensor, label_ncdhw: torch.Tensor, spacin
     nbytes = int(lib.mmtta_surface_scratch_bytes(B * R, D, H, W))
     if nbytes < 0:
         raise MmttaError(f"surface_distances: extent {(D, H, W)} unsupported (at most 1024 per axis)")
-    key = (pred_mask.device.index, nbytes)
+    key = (pred_mask.device.index, nbytes, int(torch.cuda.current_stream().cuda_stream))  # per stream: lanes run concurrently
     scratch = _SURF_SCRATCH.get(key)
     if scratch is None:
-        _SURF_SCRATCH.clear()
+        for k in [k for k in _SURF_SCRATCH if k[2] == key[2]]:      # a new shape on this stream replaces its old working set
+            del _SURF_SCRATCH[k]
         scratch = _SURF_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=pred_mask.device)
     hd = torch.empty((B, R), dtype=torch.float32, device=pred_mask.device)
     asd = torch.empty((B, R), dtype=torch.float32, device=pred_mask.device)

@@ -415,3 +415,28 @@ def test_main_entry_over_a_hecktor_manifest(tmp_path, capsys):
     diag = math.sqrt((15 * 3.0) ** 2 + 31 ** 2 + 31 ** 2)
     assert 0.0 <= metrics["avg_dc"] <= 1.0 and 0.0 <= metrics["gtvt_asd"] <= metrics["gtvt_hd95"] <= diag + 1e-3
     assert metrics["loss"] > 0.0
+
+
+def test_evaluator_lanes_equal_sequential_evaluation():
+    """method.lanes = 2 (two volumes in flight on their own streams, results read back lazily) must report exactly what
+    one lane reports: same adaptation per volume (episodic), same Dice / loss / HD95 / ASD rows, same aggregation order."""
+    from multimodal_tta_amd.registry import get_dataset_builder, get_evaluation_strategy
+    results = []
+    for lanes in (1, 2, 3):
+        cfg = root_cfg(SMALL, steps=2, lr=1e-3)
+        cfg["method"]["lanes"] = lanes
+        cfg["dataset"]["synthetic"]["num_volumes"] = 5
+        cfg["dataset"]["synthetic"]["shape"] = [32, 32, 32]
+        cfg["training"]["eval_batch_size"] = 2
+        cfg["evaluation"]["surface"] = {"enable": True, "asd_symmetric": False}
+        _, hip = build_pair(SMALL)
+        loader = get_dataset_builder("brats")(cfg).get_loader("test")
+        strat = get_evaluation_strategy("seg_tta_eval")(cfg)
+        assert strat.lanes == lanes
+        results.append((strat.evaluate_epoch(hip, loader, torch.device("cuda")), strat.last_table.clone()))
+        again = strat.evaluate_epoch(hip, loader, torch.device("cuda"))           # lanes are reusable across epochs
+        assert again == results[-1][0]
+    for m, t in results[1:]:
+        assert torch.equal(t, results[0][1])
+        assert m == results[0][0]
+    assert results[0][1].shape == (5, 3 + 5 * 3) and results[0][0]["loss"] > 0.0
