@@ -129,7 +129,19 @@ def main():
     dist_on = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL prints its version banner to STDOUT when the communicator comes up; stdout carries exactly one JSON line,
+        # so file descriptor 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import multimodal_tta_amd  # noqa: F401
     from multimodal_tta_amd import ops
