@@ -1024,7 +1024,10 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.CGp = roundup(w.g->c, 32);
   w.CDp = roundup(w.dn->c, 32);
   const int blocks_cc = (w.CGp / 32) * (w.CDp / 32);
-  int S = 512 / blocks_cc;             // 256 measured slower overall (0.78 vs 0.76 ms of weight-gradient time per step)
+  // workgroups (= slabs x channel blocks) per launch.  One volume in flight: 512 beats 256 by 3 % of the weight-gradient
+  // time; two in flight (method.lanes: 2, the default) the other lane fills the CUs and halving the slab traffic wins:
+  // 512 / 256 / 128 -> 40.1 / 41.5 / 40.6 volumes/s
+  int S = 256 / blocks_cc;
   if (S < 1) S = 1;
   if (S > w.tiles) S = w.tiles;
   w.tps = (w.tiles + S - 1) / S;
