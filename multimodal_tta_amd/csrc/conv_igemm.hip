@@ -897,12 +897,12 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   const int wgs = g.tiles * ncolgroups;
   g.ksplit = 1;
   g.sps = g.nstages;
-  // measured on the U-Net (round 1 sweep of threshold / target): splitting below 384 workgroups up to ~512 is the optimum
-  // for one volume in flight; 1024 costs +6 %, 256 +2 %, no split-K +80 % of the step's conv time.  With two volumes in
-  // flight (method.lanes: 2) the other lane fills idle CUs and the optimum flattens: 384/512, 192/256, 96/128, 48/64 ->
-  // 40.1, 40.3, 40.6, 39.0 volumes/s; the single-volume optimum is kept (within 1 % of the best for two lanes).
-  if (wgs < 384 && g.nstages > 1) {
-    int want = (512 + wgs - 1) / wgs;
+  // Split the reduction when a launch has fewer than 192 workgroups, up to ~256.  Measured on the U-Net: with ONE volume
+  // in flight 384/512 is the optimum (1024: +6 %, 256: +2 %, no split-K: +80 % of a step's conv time); with TWO in flight
+  // (method.lanes: 2, the default) the other lane fills idle CUs and less splitting wins: 384/512, 192/256, 96/128 ->
+  // 41.5, 42.9, 42.2 volumes/s (one lane at 192/256: 28.9 vs 29.6).
+  if (wgs < 192 && g.nstages > 1) {
+    int want = (256 + wgs - 1) / wgs;
     if (want > g.nstages) want = g.nstages;
     g.sps = (g.nstages + want - 1) / want;
     g.ksplit = (g.nstages + g.sps - 1) / g.sps;
