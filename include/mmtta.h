@@ -81,6 +81,18 @@ int mmtta_abi_version(void);
  * launch ONLY their main kernel, so that two events around the call time exactly the kernel rocprofv3 names.
  * Results of such calls are not valid outputs.  Returns the previous value. */
 #define MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY 1
+/* Launch-geometry knobs, read when a convolution is PLANNED (mmtta_conv_plan / the first run of a layer); they change
+ * how work is split, never the result beyond fp32 summation order.  Defaults are the measured optimum for two volumes in
+ * flight per GPU; `scripts/sweep_tuning.py` sweeps them inside one process.
+ *   SPLITK_BELOW / SPLITK_TARGET  implicit GEMM: split the reduction when a launch has fewer workgroups than BELOW, up
+ *                                 to about TARGET workgroups                                   (defaults 192 / 256)
+ *   WGRAD_WORKGROUPS              workgroups (slabs x channel blocks) of a weight-gradient launch      (default 256)
+ *   WGRAD_THIN_SLABS              slabs of the thin-layer weight gradient (<= 4 channels on one side)   (default 256)
+ * Returns the previous value, MMTTA_ERR_INVALID for an unknown key or a value < 1. */
+#define MMTTA_OPT_SPLITK_BELOW 2
+#define MMTTA_OPT_SPLITK_TARGET 3
+#define MMTTA_OPT_WGRAD_WORKGROUPS 4
+#define MMTTA_OPT_WGRAD_THIN_SLABS 5
 int mmtta_set_option(int key, int value);
 
 /* ------------------------------------------------------------------ layout (boundary) ---- */

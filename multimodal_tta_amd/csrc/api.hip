@@ -11,13 +11,22 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 int g_profile_main_only = 0;
+int g_tune[4] = {192, 256, 256, 256};      // split-K below / target, weight-gradient workgroups, thin-layer slabs
 }  // namespace mmtta
 
 extern "C" int mmtta_set_option(int key, int value) {
-  if (key != MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY) return MMTTA_ERR_INVALID;
-  const int prev = mmtta::g_profile_main_only;
-  mmtta::g_profile_main_only = value;
-  return prev;
+  if (key == MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY) {
+    const int prev = mmtta::g_profile_main_only;
+    mmtta::g_profile_main_only = value;
+    return prev;
+  }
+  if (key >= MMTTA_OPT_SPLITK_BELOW && key <= MMTTA_OPT_WGRAD_THIN_SLABS) {
+    if (value < 1) return MMTTA_ERR_INVALID;
+    const int prev = mmtta::g_tune[key - MMTTA_OPT_SPLITK_BELOW];
+    mmtta::g_tune[key - MMTTA_OPT_SPLITK_BELOW] = value;
+    return prev;
+  }
+  return MMTTA_ERR_INVALID;
 }
 
 extern "C" const char* mmtta_last_error(void) { return mmtta::g_err; }

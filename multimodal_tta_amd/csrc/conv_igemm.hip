@@ -901,8 +901,8 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   // in flight 384/512 is the optimum (1024: +6 %, 256: +2 %, no split-K: +80 % of a step's conv time); with TWO in flight
   // (method.lanes: 2, the default) the other lane fills idle CUs and less splitting wins: 384/512, 192/256, 96/128 ->
   // 41.5, 42.9, 42.2 volumes/s (one lane at 192/256: 28.9 vs 29.6).
-  if (wgs < 192 && g.nstages > 1) {
-    int want = (256 + wgs - 1) / wgs;
+  if (wgs < g_tune[0] && g.nstages > 1) {
+    int want = (g_tune[1] + wgs - 1) / wgs;
     if (want > g.nstages) want = g.nstages;
     g.sps = (g.nstages + want - 1) / want;
     g.ksplit = (g.nstages + g.sps - 1) / g.sps;

@@ -1000,7 +1000,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     w.CDp = roundup(w.pb->c, 32);
     // slabs: one volume in flight 256 / 512 / 768 / 1024 -> 56 / 46 / 57 / 57 us per launch at 128^3; two in flight
     // (method.lanes: 2, the default) 256 edges out 512 for the whole step (41.9 vs 41.5 volumes/s): less slab traffic
-    int S = 256 / (w.CDp / 32);
+    int S = g_tune[3] / (w.CDp / 32);
     if (S < 1) S = 1;
     if (S > w.tiles) S = w.tiles;
     w.tps = (w.tiles + S - 1) / S;
@@ -1029,7 +1029,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   // workgroups (= slabs x channel blocks) per launch.  One volume in flight: 512 beats 256 by 3 % of the weight-gradient
   // time; two in flight (method.lanes: 2, the default) the other lane fills the CUs and halving the slab traffic wins:
   // 512 / 256 / 128 -> 40.1 / 41.5 / 40.6 volumes/s
-  int S = 256 / blocks_cc;
+  int S = g_tune[2] / blocks_cc;
   if (S < 1) S = 1;
   if (S > w.tiles) S = w.tiles;
   w.tps = (w.tiles + S - 1) / S;

@@ -1,0 +1,90 @@
+"""Sweep the launch-geometry knobs of libmmtta.so (mmtta_set_option) inside ONE process on one GPU, so that settings are
+compared on the same box: adapted volumes/s of the bench workload (unet 4x128^3, S = 10, bf16) per setting.
+
+usage: python scripts/sweep_tuning.py [--lanes 2] [--volumes 8] [--repeat 2]
+"""
+import argparse
+import gc
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multimodal_tta_amd import _lib  # noqa: E402
+
+KEYS = {"splitk_below": 2, "splitk_target": 3, "wgrad_workgroups": 4, "wgrad_thin_slabs": 5}
+SETTINGS = [
+    dict(splitk_below=192, splitk_target=256, wgrad_workgroups=256, wgrad_thin_slabs=256),     # defaults
+    dict(splitk_below=384, splitk_target=512, wgrad_workgroups=512, wgrad_thin_slabs=512),     # single-volume optimum
+    dict(splitk_below=384, splitk_target=512, wgrad_workgroups=256, wgrad_thin_slabs=256),
+    dict(splitk_below=192, splitk_target=256, wgrad_workgroups=512, wgrad_thin_slabs=512),
+    dict(splitk_below=96, splitk_target=128, wgrad_workgroups=256, wgrad_thin_slabs=256),
+    dict(splitk_below=192, splitk_target=256, wgrad_workgroups=128, wgrad_thin_slabs=256),
+    dict(splitk_below=192, splitk_target=256, wgrad_workgroups=256, wgrad_thin_slabs=512),
+]
+
+
+def run(setting, lanes, volumes):
+    import multimodal_tta_amd  # noqa: F401
+    from multimodal_tta_amd import ops
+    from multimodal_tta_amd.config import compose
+    from multimodal_tta_amd.registry import get_model, get_plugin
+    from multimodal_tta_amd.synth import synth_volume
+    lib = _lib.load()
+    for k, v in setting.items():
+        assert lib.mmtta_set_option(KEYS[k], int(v)) > 0
+    device = torch.device("cuda", 0)
+    cfg = compose(overrides=["task=brats", "dataset=brats", "model=unet", "method=tta_entmin", "method.steps=10",
+                             "method.precision=bf16"])
+    torch.manual_seed(42)
+    model = get_model("unet")(cfg["model"])
+    plugs, streams = [], []
+    for lane in range(lanes):
+        m = model if lane == 0 else get_model("unet")(cfg["model"])
+        if lane:
+            m.load_state_dict(model.state_dict())
+        p = get_plugin("entmin_tta")(cfg)
+        p.lane = lane
+        plugs.append(p.setup(m, device))
+        streams.append(torch.cuda.Stream(device=device))
+    vols = []
+    for i in range(volumes + lanes):
+        v = synth_volume(i, 4, (128, 128, 128), 3)
+        vols.append((v["image"].unsqueeze(0).to(device), v["label"].unsqueeze(0).to(device)))
+    counts = torch.zeros((len(vols), 3, 3), dtype=torch.int64, device=device)
+
+    def one(i):
+        lane = i % lanes
+        with torch.cuda.stream(streams[lane]):
+            res = plugs[lane].adapt_volume(vols[i][0])
+            ops.mask_dice_counts(res["logits_cl"], vols[i][1], 0.5, counts[i:i + 1], None)
+
+    for i in range(lanes):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(lanes, lanes + volumes):
+        one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del plugs, streams, vols, model
+    gc.collect()
+    torch.cuda.empty_cache()
+    return volumes / dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--volumes", type=int, default=8)
+    ap.add_argument("--repeat", type=int, default=2)
+    a = ap.parse_args()
+    for rep in range(a.repeat):
+        for s in SETTINGS:
+            print(f"pass {rep} lanes {a.lanes} {s}: {run(s, a.lanes, a.volumes):.2f} volumes/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
