@@ -180,6 +180,12 @@ class DiceCEReport:
         ce = float((s[:, R * 3].sum() / (B * nvox * (R if R == 1 else 1))).item())
         return self.lambda_dice * dice + self.lambda_ce * ce
 
+    def values_per_volume(self, pending) -> List[float]:
+        """The same loss for every volume of the batch on its own (reduction 'mean' makes the batch value their mean):
+        what a rank contributes per row to the gathered table."""
+        out, B, R, nvox = pending
+        return [self.value((out.view(B, R * 3 + 1)[b:b + 1].reshape(-1), 1, R, nvox)) for b in range(B)]
+
     def __call__(self, logits: torch.Tensor, label: torch.Tensor, channels_last: bool = False) -> float:
         return self.value(self.launch(logits, label, channels_last))
 
@@ -281,9 +287,19 @@ class SegmentationEvaluationStrategy:
 
     @torch.no_grad()
     def evaluate_epoch(self, model: torch.nn.Module, data_loader: Iterable, device) -> Dict[str, float]:
+        """Single process: the reference's loop and aggregation (seg_eval.py:276-460).  Under an initialised
+        ``torch.distributed`` group with more than one rank ``data_loader`` is this rank's shard: every volume becomes a
+        row of the per-volume table, the tables are merged (``merge_rank_tables``) and every rank reports the metrics of
+        the WHOLE split - a rank never prints the metrics of its shard as if they were the test set."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         model.eval()
         model.to(device)
         acc = RegionAccumulator(self.region_order, self.enable_surface)
+        rows: List[torch.Tensor] = []
+        domain_names: List[str] = []
+        n_local = 0
         for batch in data_loader:
             x, y = self.check_batch(batch, device)
             logits = model(x)
@@ -291,12 +307,33 @@ class SegmentationEvaluationStrategy:
             dice, iou, valid = dice_iou_from_counts(counts)
             hd, asd = self.surface(y, counts) if self.enable_surface else (None, None)
             domains = as_list_str(batch.get("domain", None), batch_size=x.size(0))
+            if world == 1:
+                for i in range(x.size(0)):
+                    acc.add_row(dice[i].tolist(), iou[i].tolist(), valid[i].tolist(), domains[i],
+                                hd[i].tolist() if hd is not None else None, asd[i].tolist() if asd is not None else None)
+                if self.report_loss:
+                    acc.add_loss(self.loss_fn(logits.float(), y), x.size(0))
+                continue
+            losses = (self.loss_fn.values_per_volume(self.loss_fn.launch(logits.float(), y)) if self.report_loss
+                      else [0.0] * x.size(0))
+            idx = batch.get("index", None)
             for i in range(x.size(0)):
-                acc.add_row(dice[i].tolist(), iou[i].tolist(), valid[i].tolist(), domains[i],
-                            hd[i].tolist() if hd is not None else None, asd[i].tolist() if asd is not None else None)
-            if self.report_loss:
-                acc.add_loss(self.loss_fn(logits.float(), y), x.size(0))
-        return acc.metrics(self.report_loss)
+                if domains[i] not in domain_names:
+                    domain_names.append(domains[i])
+                parts = [torch.tensor([int(idx[i]) if idx is not None else n_local, domain_names.index(domains[i]),
+                                       losses[i]], dtype=torch.float64),
+                         dice[i].double(), iou[i].double(), valid[i].double()]
+                if self.enable_surface:
+                    parts += [hd[i].double(), asd[i].double()]
+                rows.append(torch.cat(parts))
+                n_local += 1
+        if world == 1:
+            return acc.metrics(self.report_loss)
+        R = len(self.region_order)
+        table = torch.stack(rows) if rows else torch.empty((0, table_width(R, self.enable_surface)), dtype=torch.float64)
+        table, domain_names = merge_rank_tables(table, domain_names, device)
+        self.last_table = table
+        return metrics_from_table(table, self.region_order, domain_names, self.report_loss, self.enable_surface)
 
 
 # ----------------------------------------------------------------------------- sharding
@@ -346,6 +383,36 @@ def metrics_from_table(table: torch.Tensor, region_order: Sequence[str], domain_
         if report_loss:
             acc.add_loss(float(row[2].item()), 1)
     return acc.metrics(report_loss)
+
+
+def merge_rank_tables(table: torch.Tensor, domain_names: List[str], device) -> Tuple[torch.Tensor, List[str]]:
+    """Merge the ranks' per-volume tables into the table of the whole split, identical on every rank.
+
+    THREE collectives, all outside the data path and all tiny: ``all_gather_object`` of the domain-name lists (domain
+    ids must mean the same on every rank), ``all_reduce`` of the row counts (ranks may hold unequal shares), then the
+    ``all_gather`` of the fixed-shape table (``gather_table``) - RCCL over xGMI with the ``nccl`` backend, gloo in the
+    CPU tests.  Rows come back sorted by volume index, so the aggregation that follows is order-identical to a
+    single-process run."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    names: List[Optional[List[str]]] = [None] * world
+    dist.all_gather_object(names, list(domain_names))
+    merged = sorted({n for lst in names for n in (lst or [])})
+    remap = {i: merged.index(n) for i, n in enumerate(domain_names)}
+    table = table.clone()
+    for r in range(table.shape[0]):
+        table[r, 1] = remap[int(table[r, 1].item())]
+    dev = device if dist.get_backend() == "nccl" else "cpu"
+    counts_t = torch.tensor([table.shape[0]], dtype=torch.int64, device=dev)
+    per_max = counts_t.clone()
+    dist.all_reduce(counts_t)
+    dist.all_reduce(per_max, op=dist.ReduceOp.MAX)
+    # gather_table pads every rank to ceil(N/W) rows; with an arbitrary (not round-robin) shard the largest share can
+    # exceed that, so size the pad by the largest share
+    n_items = max(int(counts_t.item()), int(per_max.item()) * world, 1)
+    table = gather_table(table.to(dev), n_items, world)
+    return table, merged
 
 
 @register_evaluation_strategy("seg_tta_eval")
@@ -455,20 +522,6 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
         rows = [row for _, row in sorted(done, key=lambda t: t[0])]
         table = torch.stack(rows) if rows else torch.empty((0, table_width(R, self.enable_surface)), dtype=torch.float64)
         if world > 1:
-            # domain ids must mean the same on every rank: exchange the name lists
-            names: List[Optional[List[str]]] = [None] * world
-            dist.all_gather_object(names, domain_names)
-            merged = sorted({n for lst in names for n in (lst or [])})
-            remap = {i: merged.index(n) for i, n in enumerate(domain_names)}
-            for r in range(table.shape[0]):
-                table[r, 1] = remap[int(table[r, 1].item())]
-            domain_names = merged
-            counts_t = torch.tensor([table.shape[0]], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(counts_t)
-            n_items = int(counts_t.item())
-            dev = device if dist.get_backend() == "nccl" else "cpu"
-            table = gather_table(table.to(dev), max(n_items, 1), world)
-            # ranks may hold unequal shares; gather_table pads to ceil(N/W) which bounds every share of a
-            # round-robin shard
+            table, domain_names = merge_rank_tables(table, domain_names, device)
         self.last_table = table
         return metrics_from_table(table, self.region_order, domain_names, self.report_loss, self.enable_surface)

@@ -30,9 +30,15 @@ def _require_cuda() -> None:
 # ----------------------------------------------------------------------------- workspace
 class Workspace:
     """One grow-only scratch buffer per device, shared by split-K convs and weight gradients
-    (stream ordered).  It must reach its final size before a graph capture starts."""
+    (stream ordered).  It must reach its final size before a graph capture starts.
+
+    A buffer that has to grow is REPLACED, never freed: hipGraphs captured for an earlier (smaller) input shape have
+    the old address baked into their kernel nodes and stay replayable (the adaptation plugin keeps one graph per input
+    shape); handing the old block back to the caching allocator would let those replays scribble over whatever tensor
+    received it next."""
 
     _buffers: Dict[Tuple[int, int, int], torch.Tensor] = {}
+    _retired: list = []     # superseded buffers, kept alive for the graphs that reference them
     frozen = False
     slot = 0        # 0: main launch sequence; 1..: the side streams of the weight gradients (engine.ConvLayer.wgrad)
     lane = 0        # runtimes that run concurrently on different streams (bench.py --lanes) keep separate scratch
@@ -48,10 +54,25 @@ class Workspace:
             if cls.frozen:
                 raise MmttaError("workspace would have to grow during graph capture; run one eager warm-up step first")
             if buf is not None:
-                torch.cuda.synchronize(device)     # kernels of any stream may still be reading the old buffer
+                cls._retired.append(buf)
             buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
             cls._buffers[key] = buf
         return buf
+
+
+# ----------------------------------------------------------------------------- library options
+_OPTION_EPOCH = 0
+
+
+def set_option(key: int, value: int) -> int:
+    """``mmtta_set_option`` + invalidation of every cached launch plan: the launch-geometry knobs (split-K thresholds,
+    weight-gradient slab counts) change workspace sizes and the number of statistics rows a convolution writes, so a
+    plan made under the old value must not size buffers for a launch made under the new one.  Set options BEFORE the
+    first adaptation step of a plugin: graphs already captured keep the geometry they were captured with."""
+    global _OPTION_EPOCH
+    prev = int(_lib.load().mmtta_set_option(int(key), int(value)))
+    _OPTION_EPOCH += 1
+    return prev
 
 
 # ----------------------------------------------------------------------------- norm on load
@@ -220,7 +241,7 @@ class ConvOp:
         return (n, (d + 1) // 2, (h + 1) // 2, (w + 1) // 2, self.cout)
 
     def plan(self, desc: ConvDesc, x: torch.Tensor, y: torch.Tensor) -> ConvPlan:
-        key = (desc.op, tuple(x.shape), tuple(y.shape))
+        key = (desc.op, tuple(x.shape), tuple(y.shape), _OPTION_EPOCH)
         p = self._plans.get(key)
         if p is None:
             p = ConvPlan()

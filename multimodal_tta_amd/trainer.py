@@ -4,8 +4,10 @@ PLUGINS table.
 
 The loss and its gradient come from two HIP kernels (``mmtta_dice_ce_sums`` + ``mmtta_dice_ce_grad``), the
 backward and the optimizer are the ones the adaptation loop uses; no autograd graph is built.  The criterion keys
-are the reference's (``training.criterion.{lambda_dice,lambda_ce,include_background,squared_pred,jaccard,weight}``,
-reference seg_trainer.py:59-79); ``sigmoid: true`` heads only (every shipped config).
+are the reference TRAINER's (``training.criterion.{lambda_dice,lambda_ce,include_background,squared_pred,jaccard,
+ce_weight}`` with ``include_background`` defaulting to False, reference seg_trainer.py:33-48,59-79; the evaluator
+reads ``weight`` and defaults ``include_background`` to True instead, reference seg_eval.py:80,201 - that asymmetry
+is the reference's and is mirrored); ``sigmoid: true`` heads only (every shipped config).
 """
 from __future__ import annotations
 
@@ -31,12 +33,12 @@ class SupervisedSegStep(EntropyMinimizationTTA):
         crit = get_config(as_cfg(config), "training.criterion", {}) or {}
         if not bool(get_config(crit, "sigmoid", True)) or bool(get_config(crit, "softmax", False)):
             raise NotImplementedError("seg_supervised_step implements the sigmoid (multilabel) DiceCE of the shipped configs")
-        self.include_background = bool(get_config(crit, "include_background", True))
+        self.include_background = bool(get_config(crit, "include_background", False))       # seg_trainer.py:33
         self.squared_pred = bool(get_config(crit, "squared_pred", False))
         self.jaccard = bool(get_config(crit, "jaccard", False))
         self.lambda_dice = float(get_config(crit, "lambda_dice", 1.0))
         self.lambda_ce = float(get_config(crit, "lambda_ce", 1.0))
-        w = get_config(crit, "weight", None)
+        w = get_config(crit, "ce_weight", None)                                              # seg_trainer.py:48
         self.ce_weight = [float(v) for v in list(w)] if w is not None and len(list(w)) > 0 else None
         self._w_dev: Optional[torch.Tensor] = None
 
@@ -78,7 +80,7 @@ class SupervisedSegStep(EntropyMinimizationTTA):
             raise ValueError(f"[SegTrainer] model logits must be [B,{y.shape[1]},D,H,W], got {(n, r, d, h, w)}")
         if self.ce_weight is not None and self._w_dev is None:
             if len(self.ce_weight) != r:
-                raise ValueError(f"criterion.weight has {len(self.ce_weight)} entries for {r} channels")
+                raise ValueError(f"criterion.ce_weight has {len(self.ce_weight)} entries for {r} channels")
             self._w_dev = torch.tensor(self.ce_weight, dtype=torch.float32, device=dev)
         sums = rt.pool.flat("dce_sums", n * (r * 3 + 1), dtype=torch.float64)
         ops.dice_ce_sums(logits, y, self._w_dev, self.squared_pred, sums, logits_channels_last=True)

@@ -34,7 +34,7 @@ def run(setting, lanes, volumes):
     from multimodal_tta_amd.synth import synth_volume
     lib = _lib.load()
     for k, v in setting.items():
-        assert lib.mmtta_set_option(KEYS[k], int(v)) > 0
+        assert ops.set_option(KEYS[k], int(v)) > 0      # also drops cached launch plans
     device = torch.device("cuda", 0)
     cfg = compose(overrides=["task=brats", "dataset=brats", "model=unet", "method=tta_entmin", "method.steps=10",
                              "method.precision=bf16"])

@@ -1,0 +1,78 @@
+"""Every dispatchable kernel instantiation of the convolution family is selected by at least one shape of the GPU
+parity cases (tests/test_hip_conv.py::CASES / BF16_CASES) - asserted through the planner the launches themselves use
+(``mmtta_conv_plan`` / ``mmtta_conv_wgrad_kernel`` are host-only, so this runs without a GPU too).
+
+config ids: csrc/conv_igemm.hip::config_id (0-5 fp32 igemm, 6 direct, 7-12 bf16 igemm, 13 channel kernel);
+weight-gradient ids: mmtta_conv_wgrad_kernel (0 f32 s1, 1 f32 s2, 2 1x1, 3 small-channel, 4 bf16 s1, 5 bf16 s2, 6 tiny).
+VERDICT r1 P1: ids 2 and 9 (igemm <4,4,4,4,8,32>) used to be reachable only by the full-size bench."""
+import ctypes as C
+
+import torch
+
+from test_hip_conv import BF16_CASES, CASES
+
+# (case, (fwd, dgrad) config in fp32 mode, the same in bf16 mode, weight-gradient kernel (fp32 mode, bf16 mode))
+DISPATCH = [
+    ((32, 32, 3, 1, False, (1, 16, 16, 16)), (0, 0), (7, 7), (0, 4)),
+    ((64, 64, 3, 1, False, (1, 8, 8, 8)), (1, 1), (8, 8), (0, 4)),
+    ((128, 128, 3, 1, False, (1, 32, 32, 32)), (2, 2), (9, 9), (0, 4)),
+    ((16, 32, 3, 2, False, (1, 8, 8, 8)), (3, 0), (10, 7), (1, 5)),
+    ((32, 64, 3, 2, False, (1, 8, 8, 16)), (4, 0), (11, 7), (1, 5)),
+    ((64, 128, 3, 2, False, (1, 5, 6, 7)), (5, 1), (12, 8), (1, 5)),
+    ((128, 136, 3, 1, False, (2, 4, 6, 8)), (5, 5), (12, 12), (0, 4)),
+    ((768, 128, 3, 2, True, (1, 8, 8, 8)), (2, 5), (9, 12), (1, 5)),
+    ((256, 512, 1, 1, False, (1, 4, 4, 4)), (5, 5), (12, 12), (2, 2)),
+    ((64, 3, 3, 2, True, (1, 3, 5, 70)), (6, 4), (6, 13), (3, 3)),
+    ((4, 32, 3, 2, False, (1, 16, 16, 16)), (13, 6), (13, 6), (3, 3)),
+    ((3, 3, 3, 1, False, (1, 8, 8, 8)), (6, 6), (6, 6), (6, 6)),
+]
+
+
+def _desc(t):
+    from multimodal_tta_amd._lib import F32, Tensor
+    n, d, h, w, c = t.shape
+    sn, sd, sh, sw, _ = t.stride()
+    return Tensor(t.data_ptr(), n, c, d, h, w, sn, 1, sd, sh, sw, F32, 0)
+
+
+def _cl(n, d, h, w, c):
+    return torch.empty((n, d, h, w, (c + 3) // 4 * 4))[..., :c]
+
+
+def test_every_kernel_instantiation_is_reached_by_a_parity_case():
+    from multimodal_tta_amd import _lib
+    from multimodal_tta_amd._lib import BF16, CONV_DGRAD, CONV_FWD, CONVT_DGRAD, CONVT_FWD, F32, ConvDesc, ConvPlan
+
+    lib = _lib.load()
+    seen_cfg, seen_wg, splitk_wide = set(), set(), set()
+    for case, want_f32, want_bf16, want_wg in DISPATCH:
+        cin, cout, k, stride, transposed, (n, d, h, w) = case
+        assert case in CASES, case
+        x = _cl(n, d, h, w, cin)
+        if transposed:
+            y = _cl(n, 2 * d, 2 * h, 2 * w, cout)
+        elif stride == 1:
+            y = _cl(n, d, h, w, cout)
+        else:
+            y = _cl(n, (d + 1) // 2, (h + 1) // 2, (w + 1) // 2, cout)
+        tx, ty = _desc(x), _desc(y)
+        fo, do = (CONVT_FWD, CONVT_DGRAD) if transposed else (CONV_FWD, CONV_DGRAD)
+        for dtype, want, wg in ((F32, want_f32, want_wg[0]), (BF16, want_bf16, want_wg[1])):
+            if dtype == BF16 and (want != want_f32 or wg != want_wg[0]):
+                assert case in BF16_CASES, f"{case}: bf16 instantiation without a bf16 parity case"
+            got = []
+            for op, a, b in ((fo, tx, ty), (do, ty, tx)):
+                dsc, plan = ConvDesc(op, k, stride, cin, cout, dtype), ConvPlan()
+                assert lib.mmtta_conv_plan(C.byref(dsc), C.byref(a), C.byref(b), C.byref(plan)) == 0
+                got.append(int(plan.config))
+                if plan.ksplit > 1:
+                    splitk_wide.add(int(plan.config))
+            assert tuple(got) == want, f"{case} dtype {dtype}: plan configs {got}, expected {want}"
+            dsc = ConvDesc(fo, k, stride, cin, cout, dtype)
+            kid = int(lib.mmtta_conv_wgrad_kernel(C.byref(dsc), C.byref(tx), C.byref(ty)))
+            assert kid == wg, f"{case} dtype {dtype}: weight-gradient kernel {kid}, expected {wg}"
+            seen_cfg.update(got)
+            seen_wg.add(kid)
+    assert seen_cfg == set(range(14)), f"conv configs without a parity case: {sorted(set(range(14)) - seen_cfg)}"
+    assert seen_wg == set(range(7)), f"weight-gradient kernels without a parity case: {sorted(set(range(7)) - seen_wg)}"
+    assert {2, 9} <= splitk_wide, "the 32-channel-stage igemm also needs a split-K parity case"

@@ -66,6 +66,12 @@ CASES = [
     # <= 4 channels on both sides (VALU weight gradient, row kernel forward / input gradient), rows > 64 voxels
     (4, 2, 3, 1, False, (2, 5, 6, 70)),
     (1, 1, 3, 1, False, (1, 6, 5, 9)),
+    # the instantiations only the full-size network dispatches: igemm <4,4,4,4,8,32> (config 2 / 9),
+    # weight-gradient launches with more than 32 slabs (slab_prereduce_kernel), stride-2 thin stage <1,1,4,4,8,*>
+    (128, 128, 3, 1, False, (1, 32, 32, 32)),
+    (768, 128, 3, 2, True, (1, 8, 8, 8)),
+    (32, 32, 3, 1, False, (1, 32, 32, 32)),
+    (16, 32, 3, 2, False, (1, 8, 8, 8)),
 ]
 
 
@@ -204,6 +210,13 @@ BF16_CASES = [
     (64, 3, 3, 2, True, (1, 5, 6, 70)),          # full-resolution up-convolution: bf16-staged activations, fp32 weights
     (32, 2, 3, 2, True, (2, 4, 4, 16)),
     (64, 1, 3, 2, True, (1, 3, 4, 9)),
+    # full-size-only instantiations (see CASES)
+    (128, 128, 3, 1, False, (1, 32, 32, 32)),
+    (768, 128, 3, 2, True, (1, 8, 8, 8)),
+    (32, 32, 3, 1, False, (1, 32, 32, 32)),
+    (16, 32, 3, 2, False, (1, 8, 8, 8)),
+    (256, 256, 3, 1, False, (1, 16, 16, 16)),
+    (64, 3, 3, 2, True, (1, 3, 5, 70)),
 ]
 
 
@@ -279,3 +292,4 @@ def test_batched_pack_matches_per_layer_pack():
         for (op, w, pf, pd), (cin, cout, k, s, tr) in zip(convs, layers):
             assert torch.equal(op.packed_fwd, pf), f"fwd image differs: {(cin, cout, k, s, tr)} dtype {dtype}"
             assert torch.equal(op.packed_dgrad, pd), f"dgrad image differs: {(cin, cout, k, s, tr)} dtype {dtype}"
+

@@ -249,25 +249,41 @@ def test_concurrent_lanes_equal_sequential_runs():
         assert torch.equal(pa.logits(ra), za) and torch.equal(pb.logits(rb), zb)
 
 
-@pytest.mark.parametrize("crit", [
-    dict(lambda_dice=1.0, lambda_ce=1.0, include_background=True, squared_pred=False, jaccard=False),
-    dict(lambda_dice=5.0, lambda_ce=1.0, include_background=False, squared_pred=True, jaccard=True, weight=[1.0, 2.0, 0.5]),
+@pytest.mark.parametrize("crit,model_over,shape", [
+    (dict(lambda_dice=1.0, lambda_ce=1.0, include_background=True, squared_pred=False, jaccard=False), {}, (32, 32, 32)),
+    (dict(lambda_dice=5.0, lambda_ce=1.0, include_background=False, squared_pred=True, jaccard=True,
+          ce_weight=[1.0, 2.0, 0.5]), {}, (32, 32, 32)),
+    # the HECKTOR criterion block (reference configs/_global_patches/hecktor21.yaml:59-69): one region, so MONAI's CE
+    # term is BCE-with-logits with pos_weight = ce_weight and include_background=False is ignored
+    (dict(lambda_dice=5.0, lambda_ce=1.0, include_background=False, squared_pred=False, jaccard=False,
+          ce_weight=[50.0]), dict(in_channels=2, num_classes=1), (16, 48, 48)),
+    # trainer defaults (reference seg_trainer.py:33-48): include_background False, no weight
+    (dict(), {}, (32, 32, 32)),
 ])
-def test_supervised_dicece_step_matches_autograd(crit):
+def test_supervised_dicece_step_matches_autograd(crit, model_over, shape):
     """The reference's supervised step (reference src/core/trainers/seg_trainer.py:97-145) with the loss gradient
     from mmtta_dice_ce_grad: loss value and the logits after two Adam steps against torch autograd on the oracle
-    (oracle.DiceCELoss + oracle.build_adam)."""
+    (oracle.DiceCELoss + oracle.build_adam).  The plugin reads the TRAINER's keys (``ce_weight``, include_background
+    default False: seg_trainer.py:33,48), the oracle loss is constructed the way seg_trainer.py:59-79 does."""
     import oracle
+    from multimodal_tta_amd.models import UNet
     from multimodal_tta_amd.registry import get_plugin
 
-    cfg = root_cfg(SMALL, steps=1, lr=1e-3)
+    mcfg = dict(SMALL, **model_over)
+    cfg = root_cfg(mcfg, steps=1, lr=1e-3)
+    for k in ("weight", "ce_weight", "include_background", "lambda_dice", "lambda_ce", "squared_pred", "jaccard"):
+        cfg["training"]["criterion"].pop(k, None)
     cfg["training"]["criterion"].update(crit)
     cfg["training"]["criterion"]["sigmoid"] = True
-    ref, hip = build_pair(SMALL)
-    x, y = volume(3)
-    w = torch.tensor(crit["weight"]) if "weight" in crit else None
-    loss_fn = oracle.DiceCELoss(include_background=crit["include_background"], sigmoid=True, squared_pred=crit["squared_pred"],
-                                jaccard=crit["jaccard"], weight=w, lambda_dice=crit["lambda_dice"], lambda_ce=crit["lambda_ce"])
+    torch.manual_seed(42)
+    ref = oracle.UNet(mcfg)
+    hip = UNet(mcfg)
+    hip.load_state_dict(ref.state_dict())
+    x, y = volume(3, shape=shape, C=mcfg["in_channels"], R=mcfg["num_classes"])
+    w = torch.tensor(crit["ce_weight"]) if "ce_weight" in crit else None
+    loss_fn = oracle.DiceCELoss(include_background=crit.get("include_background", False), sigmoid=True,
+                                squared_pred=crit.get("squared_pred", False), jaccard=crit.get("jaccard", False), weight=w,
+                                lambda_dice=crit.get("lambda_dice", 1.0), lambda_ce=crit.get("lambda_ce", 1.0))
     opt = oracle.build_adam(list(ref.named_parameters()), cfg["training"])
     ref.train()
     ref_losses = []
@@ -286,6 +302,39 @@ def test_supervised_dicece_step_matches_autograd(crit):
         z_ref, z_hip = ref(x), hip(x.cuda()).cpu()
     err = (z_hip - z_ref).abs().max().item() / z_ref.abs().max().item()
     assert err < 5e-3, f"logits after two supervised steps: rel err {err:.3e}"
+
+
+def test_dicece_sums_and_gradient_single_region_bce_pos_weight():
+    """R == 1 branch of DiceCE at the kernel level: mmtta_dice_ce_sums + mmtta_dice_ce_grad with
+    pos_weight [50], lambda_dice 5 (the HECKTOR criterion, reference hecktor21.yaml:59-69 / seg_trainer.py:68-79)
+    against oracle.DiceCELoss value and its autograd gradient; channels-last and NCDHW logits."""
+    import oracle
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(3)
+    B, R, D, H, W = 2, 1, 6, 10, 12
+    z = torch.randn(B, R, D, H, W) * 2.0
+    y = (torch.rand(B, R, D, H, W) < 0.1).float()
+    w = torch.tensor([50.0])
+    zz = z.clone().requires_grad_(True)
+    loss_fn = oracle.DiceCELoss(include_background=False, sigmoid=True, weight=w, lambda_dice=5.0, lambda_ce=1.0)
+    loss = loss_fn(zz, y)
+    loss.backward()
+    for channels_last in (True, False):
+        zg = ops.to_cl(z.cuda()) if channels_last else z.cuda().contiguous()
+        sums = torch.zeros(B * (R * 3 + 1), dtype=torch.float64, device="cuda")
+        ops.dice_ce_sums(zg, y.cuda(), w.cuda(), False, sums, logits_channels_last=channels_last)
+        dz = torch.zeros_like(zg)
+        ops.dice_ce_grad(zg, y.cuda(), w.cuda(), False, False, False, 5.0, 1.0, sums, dz, logits_channels_last=channels_last)
+        torch.cuda.synchronize()
+        s = sums.cpu().view(B, R * 3 + 1)
+        inter, ps, gs = s[:, 0], s[:, 1], s[:, 2]
+        f = 1.0 - (2.0 * inter + 1e-5) / (gs + ps + 1e-5)
+        val = 5.0 * f.mean().item() + s[:, 3].sum().item() / (B * D * H * W)
+        assert abs(val - loss.item()) <= 1e-5 * abs(loss.item()), (val, loss.item())
+        got = (dz.permute(0, 4, 1, 2, 3) if channels_last else dz).cpu()
+        gerr = (got - zz.grad).abs().max().item() / zz.grad.abs().max().item()
+        assert gerr <= 2e-5, f"channels_last={channels_last}: gradient rel err {gerr:.3e}"
 
 
 @pytest.mark.parametrize("variant", ["hecktor_r1", "softmax_r3", "batchnorm_affine_only"])
@@ -440,3 +489,37 @@ def test_evaluator_lanes_equal_sequential_evaluation():
         assert torch.equal(t, results[0][1])
         assert m == results[0][0]
     assert results[0][1].shape == (5, 3 + 5 * 3) and results[0][0]["loss"] > 0.0
+
+
+def test_graphs_of_a_smaller_shape_survive_workspace_growth():
+    """ADVICE r1 (ops.py:47): graphs captured for shape A have the scratch address baked in; a larger shape B makes the
+    workspace grow.  Replaying A's graph afterwards must still give A's result (the superseded buffer stays alive
+    instead of returning to the allocator), compared with eager launches from a fresh plugin."""
+    from multimodal_tta_amd import ops
+    from multimodal_tta_amd.registry import get_plugin
+
+    xa = volume(5, shape=(16, 16, 16))[0].cuda()
+    xb = volume(6, shape=(32, 48, 32))[0].cuda()
+    want = {}
+    for name, x in (("a", xa), ("b", xb)):
+        _, hip = build_pair(SMALL)
+        eager = get_plugin("entmin_tta")(root_cfg(SMALL, steps=3, lr=1e-3, use_graph=False)).setup(hip, "cuda")
+        eager.lane = 7                    # its own scratch: the graph plugin below starts from an empty workspace
+        want[name] = eager.logits(eager.adapt_volume(x)).clone()
+    _, hip = build_pair(SMALL)
+    plug = get_plugin("entmin_tta")(root_cfg(SMALL, steps=3, lr=1e-3, use_graph=True)).setup(hip, "cuda")
+    plug.lane = 8
+    za1 = plug.logits(plug.adapt_volume(xa)).clone()
+    key = (xa.device.index, 0, 8)
+    small = ops.Workspace._buffers[key]
+    zb = plug.logits(plug.adapt_volume(xb)).clone()
+    assert ops.Workspace._buffers[key] is not small, "shape B was expected to outgrow shape A's workspace"
+    junk = [torch.full((small.numel() // 4,), float("nan"), device="cuda") for _ in range(4)]   # would land in a freed block
+    za2 = plug.logits(plug.adapt_volume(xa)).clone()
+    zb2 = plug.logits(plug.adapt_volume(xb)).clone()
+    torch.cuda.synchronize()
+    assert plug.use_graph and len(plug._graphs) == 2
+    assert torch.equal(za1, want["a"]) and torch.equal(zb, want["b"])
+    assert torch.equal(za2, want["a"]), "replaying the smaller shape's graph after the workspace grew changed its result"
+    assert torch.equal(zb2, want["b"])
+    del junk

@@ -87,3 +87,87 @@ def test_gather_table_two_processes_gloo(tmp_path, surface):
     if surface:      # every rank replays the same aggregation, surface keys included
         m = metrics_from_table(want, REGIONS, ["a", "b"], True, surface=True)
         assert "avg_hd95" in m and "dom/a/avg_asd" in m and m["avg_hd95"] > 0.0
+
+
+# ----------------------------------------------------------------------------- seg_eval / merge under a real group
+class _CpuScoredEval:
+    """Mixin for the CPU tests: the strategy's host logic is the product code, only the voxel kernel behind
+    ``score`` (mmtta_mask_dice_counts, GPU-only) is replaced by the oracle's restatement of the same counts."""
+
+    def score(self, logits, y, channels_last=False):
+        import oracle
+        pred, gt = oracle.masks_from_logits(logits, y, self.threshold)
+        inter = (pred & gt).flatten(2).sum(-1)
+        return torch.stack([inter, pred.flatten(2).sum(-1), gt.flatten(2).sum(-1)], dim=-1).to(torch.int64)
+
+
+def _eval_volumes(n):
+    g = torch.Generator().manual_seed(11)
+    vols = []
+    for i in range(n):
+        x = torch.randn(1, 2, 4, 6, 6, generator=g)
+        y = (torch.rand(1, R, 4, 6, 6, generator=g) > 0.6).float()
+        if i == 2:
+            y[:, 1] = 0.0          # an empty ground-truth region: valid = False on that row
+        vols.append((x, y, ["siteA", "siteB", "siteC"][i % 3]))
+    return vols
+
+
+def _eval_setup():
+    from multimodal_tta_amd.evaluation import SegmentationEvaluationStrategy
+
+    class Strat(_CpuScoredEval, SegmentationEvaluationStrategy):
+        pass
+
+    cfg = {"evaluation": {"seg": {"threshold": 0.5, "region_order": REGIONS}, "loss": {"report_loss": False}},
+           "dataset": {"synthetic": {"enabled": True}}}
+    torch.manual_seed(3)
+    model = torch.nn.Conv3d(2, R, 1)
+    return Strat(cfg), model
+
+
+def _batches(vols, indices, bs):
+    out = []
+    for j in range(0, len(indices), bs):
+        ids = indices[j:j + bs]
+        out.append({"image": torch.cat([vols[i][0] for i in ids]), "label": torch.cat([vols[i][1] for i in ids]),
+                    "domain": [vols[i][2] for i in ids], "index": torch.tensor(ids)})
+    return out
+
+
+def _seg_eval_worker(rank, world, port, n, out_dir, shards):
+    import json
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    strat, model = _eval_setup()
+    metrics = strat.evaluate_epoch(model, _batches(_eval_volumes(n), shards[rank], 2), "cpu")
+    with open(os.path.join(out_dir, f"m{rank}.json"), "w") as fh:
+        json.dump(metrics, fh)
+    torch.save(strat.last_table, os.path.join(out_dir, f"tab{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shards", [[[0, 2, 4], [1, 3]], [[0, 1, 2, 3], [4]], [[0, 1, 2, 3, 4], []]])
+def test_seg_eval_under_two_gloo_ranks_reports_the_whole_split(tmp_path, shards):
+    """ADVICE r1 (main.py:57): a plain ``seg_eval`` run under torch.distributed must merge the shards - every rank
+    returns the metrics of all volumes, identical to one process; unequal (and empty) shards included."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n, world = 5, 2
+    strat, model = _eval_setup()
+    want = strat.evaluate_epoch(model, _batches(_eval_volumes(n), list(range(n)), 2), "cpu")
+    assert "dom/siteA/avg_dc" in want and want["avg_dc"] > 0.0
+    mp.spawn(_seg_eval_worker, args=(world, port, n, str(tmp_path), shards), nprocs=world, join=True)
+    tabs = []
+    for r in range(world):
+        with open(os.path.join(str(tmp_path), f"m{r}.json")) as fh:
+            got = json.load(fh)
+        assert got == want, f"rank {r}: {got} vs {want}"
+        tabs.append(torch.load(os.path.join(str(tmp_path), f"tab{r}.pt"), weights_only=True))
+    assert torch.equal(tabs[0], tabs[1]) and tabs[0].shape == (n, table_width(R))
+    assert tabs[0][:, 0].tolist() == [float(i) for i in range(n)]
