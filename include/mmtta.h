@@ -307,6 +307,25 @@ int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const mmtta_tens
 int mmtta_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int32_t* step, void* stream);
 
+/* The three optimizers the reference's factory can build (reference src/core/experiment_manager.py:199-210:
+ * torch.optim.SGD / Adam / AdamW, chosen by `training.optimizer`, hyper-parameters from
+ * `training.optimizers.<name>`, configs/training/default.yaml:11-45) over the same arena layout:
+ *   ADAM   as mmtta_adam_step;
+ *   ADAMW  p *= 1 - lr*weight_decay (decay segment), then the Adam update without the L2 term;
+ *   SGD    g += weight_decay*p (decay segment); buf = g on the first step, momentum*buf + (1-dampening)*g after;
+ *          g = nesterov ? g + momentum*buf : buf (momentum 0: plain);  p -= lr*g.   `m` is the momentum buffer,
+ *          `v` is unused (may be NULL).
+ * All buffers 16-byte aligned, n_decay a multiple of 4 (the arena guarantees both). */
+enum { MMTTA_OPTIM_ADAM = 0, MMTTA_OPTIM_ADAMW = 1, MMTTA_OPTIM_SGD = 2 };
+typedef struct mmtta_optim_desc {
+  int32_t kind;
+  float lr, beta1, beta2, eps, weight_decay;
+  float momentum, dampening;
+  int32_t nesterov;
+} mmtta_optim_desc;
+int mmtta_optim_step(const mmtta_optim_desc* desc, float* p, const float* g, float* m, float* v, int64_t n,
+                     int64_t n_decay, int32_t* step, void* stream);
+
 /* ------------------------------------------------------------------ evaluation tail ------ */
 /* sigmoid -> (>= threshold) -> uint8 mask; GT (> 0.5); per (n,r) integer counts
  * inter = sum p&g, psum = sum p, gsum = sum g.  Replaces reference

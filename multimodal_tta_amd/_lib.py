@@ -56,6 +56,14 @@ class ConvPlan(C.Structure):
     ]
 
 
+class OptimDesc(C.Structure):          # mmtta_optim_desc
+    _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("momentum", C.c_float), ("dampening", C.c_float), ("nesterov", C.c_int32)]
+
+
+OPTIM_ADAM, OPTIM_ADAMW, OPTIM_SGD = 0, 1, 2
+
+
 class ConvEpilogue(C.Structure):
     _fields_ = [("add", C.POINTER(Tensor)), ("add_norm", NormOnLoad)]
 
@@ -106,6 +114,8 @@ _SIGNATURES = {
     "mmtta_entropy_loss": (C.c_int, [_P(Tensor), C.c_int, _P(Tensor), C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmtta_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "mmtta_optim_step": (C.c_int, [_P(OptimDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                   C.c_void_p, C.c_void_p]),
     "mmtta_mask_dice_counts": (C.c_int, [_P(Tensor), _P(Tensor), C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmtta_dice_ce_scratch_bytes": (C.c_int64, [_P(Tensor)]),
     "mmtta_dice_ce_sums": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -134,33 +134,82 @@ static int entropy_blocks(const mmtta_tensor* z) {
   return (int)b;
 }
 
-// ------------------------------------------------------------------ Adam
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long long n,
-                                                   long long n_decay, float lr, float beta1, float beta2, float eps,
-                                                   float wd, const int* __restrict__ step) {
+// ------------------------------------------------------------------ fused optimizers over the flat arena
+// KIND 0: torch.optim.Adam (coupled L2), 1: torch.optim.AdamW (decoupled decay), 2: torch.optim.SGD (momentum, dampening,
+// nesterov).  One thread owns 4 consecutive parameters (16-byte accesses; the arena keeps every parameter and both
+// segment boundaries 16-byte aligned), the decay / no-decay split is the segment boundary n_decay
+// (reference src/core/experiment_manager.py:199-237).
+struct OptimArgs {
+  float lr, beta1, beta2, eps, wd, momentum, dampening;
+  int nesterov;
+};
+
+template <int KIND>
+__device__ __forceinline__ void optim_update(float& pi, float gi, float& mi, float& vi, bool decay, const OptimArgs& a,
+                                             float step_size, float bc2_sqrt, bool first) {
+  if (KIND == 0) {
+    if (decay) gi = gi + a.wd * pi;
+    mi = mi + (1.f - a.beta1) * (gi - mi);
+    vi = vi * a.beta2 + ((1.f - a.beta2) * gi) * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+    pi = pi - step_size * (mi / denom);
+  } else if (KIND == 1) {
+    if (decay) pi = pi * (1.f - a.lr * a.wd);
+    mi = mi + (1.f - a.beta1) * (gi - mi);
+    vi = vi * a.beta2 + ((1.f - a.beta2) * gi) * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+    pi = pi - step_size * (mi / denom);
+  } else {
+    if (decay) gi = gi + a.wd * pi;
+    if (a.momentum != 0.f) {
+      mi = first ? gi : a.momentum * mi + (1.f - a.dampening) * gi;
+      gi = a.nesterov ? gi + a.momentum * mi : mi;
+    }
+    pi = pi - a.lr * gi;
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void optim_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long long n,
+                                                    long long n_decay, OptimArgs a, const int* __restrict__ step) {
   __shared__ float s_step_size, s_bc2_sqrt;
+  const int t0 = *step;
   if (threadIdx.x == 0) {
-    const double t = (double)(*step + 1);
-    const double bc1 = 1.0 - pow((double)beta1, t);
-    const double bc2 = 1.0 - pow((double)beta2, t);
-    s_step_size = (float)((double)lr / bc1);
-    s_bc2_sqrt = (float)sqrt(bc2);
+    const double t = (double)(t0 + 1);
+    const double bc1 = 1.0 - pow((double)a.beta1, t);
+    const double bc2 = 1.0 - pow((double)a.beta2, t);
+    s_step_size = KIND == 2 ? a.lr : (float)((double)a.lr / bc1);
+    s_bc2_sqrt = KIND == 2 ? 1.f : (float)sqrt(bc2);
   }
   __syncthreads();
   const float step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
-  const float w1 = 1.f - beta1, w2 = 1.f - beta2;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float pi = p[i];
-    float gi = g[i];
-    if (i < n_decay && wd != 0.f) gi = gi + wd * pi;
-    float mi = m[i], vi = v[i];
-    mi = mi + w1 * (gi - mi);
-    vi = vi * beta2 + (w2 * gi) * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - step_size * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
+  const bool first = t0 == 0;
+  const bool wd_on = a.wd != 0.f;
+  const long long n4 = n >> 2;
+  for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+    const long long i = q << 2;
+    float4 pq = *reinterpret_cast<const float4*>(p + i);
+    const float4 gq = *reinterpret_cast<const float4*>(g + i);
+    float4 mq = make_float4(0.f, 0.f, 0.f, 0.f), vq = mq;
+    if (KIND != 2 || a.momentum != 0.f) mq = *reinterpret_cast<const float4*>(m + i);
+    if (KIND != 2) vq = *reinterpret_cast<const float4*>(v + i);
+    const bool decay = wd_on && i < n_decay;          // n_decay is a multiple of 4
+    optim_update<KIND>(pq.x, gq.x, mq.x, vq.x, decay, a, step_size, bc2_sqrt, first);
+    optim_update<KIND>(pq.y, gq.y, mq.y, vq.y, decay, a, step_size, bc2_sqrt, first);
+    optim_update<KIND>(pq.z, gq.z, mq.z, vq.z, decay, a, step_size, bc2_sqrt, first);
+    optim_update<KIND>(pq.w, gq.w, mq.w, vq.w, decay, a, step_size, bc2_sqrt, first);
+    *reinterpret_cast<float4*>(p + i) = pq;
+    if (KIND != 2 || a.momentum != 0.f) *reinterpret_cast<float4*>(m + i) = mq;
+    if (KIND != 2) *reinterpret_cast<float4*>(v + i) = vq;
+  }
+  // ragged tail (n not a multiple of 4: never the case for the arena, kept for arbitrary callers)
+  const long long i = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) {
+    float pi = p[i], mi = m[i], vi = KIND != 2 ? v[i] : 0.f;
+    optim_update<KIND>(pi, g[i], mi, vi, wd_on && i < n_decay, a, step_size, bc2_sqrt, first);
+    p[i] = pi; m[i] = mi;
+    if (KIND != 2) v[i] = vi;
   }
 }
 
@@ -389,19 +438,43 @@ extern "C" int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const
   return launch_status("entropy finish");
 }
 
-extern "C" int mmtta_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr,
-                               float beta1, float beta2, float eps, float weight_decay, int32_t* step, void* stream) {
-  MMTTA_CHECK(p && g && m && v && step && n >= 0 && n_decay >= 0 && n_decay <= n, MMTTA_ERR_INVALID, "adam: bad argument");
+static int optim_launch(int kind, float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, const OptimArgs& a,
+                        int32_t* step, hipStream_t s) {
+  MMTTA_CHECK(p && g && m && step && n >= 0 && n_decay >= 0 && n_decay <= n, MMTTA_ERR_INVALID, "optimizer: bad argument");
+  MMTTA_CHECK(kind == MMTTA_OPTIM_SGD || v != nullptr, MMTTA_ERR_INVALID, "optimizer: Adam/AdamW need the second-moment buffer");
+  MMTTA_CHECK(kind >= MMTTA_OPTIM_ADAM && kind <= MMTTA_OPTIM_SGD, MMTTA_ERR_INVALID, "optimizer: kind %d", kind);
   if (n == 0) return MMTTA_OK;
-  hipStream_t s = (hipStream_t)stream;
-  long long blocks = (n + 255) / 256;
+  const bool al = ((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0 && n_decay % 4 == 0;
+  MMTTA_CHECK(al, MMTTA_ERR_UNSUPPORTED, "optimizer: buffers must be 16-byte aligned and n_decay a multiple of 4");
+  long long blocks = ((n + 3) / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, (long long)n, (long long)n_decay, lr, beta1,
-                     beta2, eps, weight_decay, step);
-  int st = launch_status("adam");
+  const dim3 grid((unsigned)blocks), blk(256);
+  if (kind == MMTTA_OPTIM_ADAM)
+    hipLaunchKernelGGL(optim_kernel<0>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step);
+  else if (kind == MMTTA_OPTIM_ADAMW)
+    hipLaunchKernelGGL(optim_kernel<1>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step);
+  else
+    hipLaunchKernelGGL(optim_kernel<2>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step);
+  int st = launch_status("optimizer");
   if (st) return st;
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
-  return launch_status("adam step counter");
+  return launch_status("optimizer step counter");
+}
+
+extern "C" int mmtta_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int32_t* step, void* stream) {
+  OptimArgs a{lr, beta1, beta2, eps, weight_decay, 0.f, 0.f, 0};
+  return optim_launch(MMTTA_OPTIM_ADAM, p, g, m, v, n, n_decay, a, step, (hipStream_t)stream);
+}
+
+extern "C" int mmtta_optim_step(const mmtta_optim_desc* d, float* p, const float* g, float* m, float* v, int64_t n,
+                                int64_t n_decay, int32_t* step, void* stream) {
+  MMTTA_CHECK(d != nullptr, MMTTA_ERR_INVALID, "optimizer: null desc");
+  OptimArgs a{d->lr, d->beta1, d->beta2, d->eps, d->weight_decay, d->momentum, d->dampening, d->nesterov};
+  if (d->kind == MMTTA_OPTIM_SGD)
+    MMTTA_CHECK(!(d->nesterov && (d->momentum <= 0.f || d->dampening != 0.f)), MMTTA_ERR_INVALID,
+                "optimizer: nesterov needs momentum > 0 and zero dampening (torch.optim.SGD raises the same)");
+  return optim_launch(d->kind, p, g, m, v, n, n_decay, a, step, (hipStream_t)stream);
 }
 
 extern "C" int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label, float threshold, int64_t* counts,

@@ -464,6 +464,43 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
                                       weight_decay, ptr(step), stream_ptr()), "adam_step")
 
 
+OPTIMIZERS = {"adam": _lib.OPTIM_ADAM, "adamw": _lib.OPTIM_ADAMW, "sgd": _lib.OPTIM_SGD}
+
+
+@dataclass
+class OptimSpec:
+    """Hyper-parameters of the fused arena optimizer, read the way the reference's factory reads them (reference
+    src/core/experiment_manager.py:199-237: `training.optimizer` names the class, `training.optimizers.<name>` holds
+    its keyword arguments, `training.learning_rate / weight_decay / momentum` are the fall-backs)."""
+    name: str = "adam"
+    lr: float = 1e-3
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    weight_decay: float = 0.0
+    momentum: float = 0.0
+    dampening: float = 0.0
+    nesterov: bool = False
+
+    def struct(self) -> _lib.OptimDesc:
+        return _lib.OptimDesc(OPTIMIZERS[self.name], self.lr, self.beta1, self.beta2, self.eps, self.weight_decay,
+                              self.momentum, self.dampening, 1 if self.nesterov else 0)
+
+
+def optim_step(spec: OptimSpec, p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: Optional[torch.Tensor],
+               n_decay: int, step: torch.Tensor) -> None:
+    """One step of torch.optim.{Adam, AdamW, SGD} over the flat arena ([0, n_decay) decays)."""
+    n = p.numel()
+    for t in (p, g, m) + ((v,) if v is not None else ()):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise MmttaError("optimizer: p, g, m, v must be contiguous fp32 of equal length")
+    if step.dtype != torch.int32:
+        raise MmttaError("optimizer: step must be a device int32 scalar")
+    d = spec.struct()
+    check(_lib.load().mmtta_optim_step(C.byref(d), ptr(p), ptr(g), ptr(m), ptr(v), n, int(n_decay), ptr(step),
+                                       stream_ptr()), "optim_step")
+
+
 def _desc_any(t: torch.Tensor, channels_last: bool):
     return desc_cl(t) if channels_last else desc_ncdhw(t)
 

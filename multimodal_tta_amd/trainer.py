@@ -89,7 +89,5 @@ class SupervisedSegStep(EntropyMinimizationTTA):
                          self.lambda_dice, self.lambda_ce, sums, dlogits, logits_channels_last=True)
         if ar.n_train > 0:
             rt.run_backward(dlogits)
-            ops.adam_step(ar.params[:ar.n_train], ar.grads[:ar.n_train], ar.exp_avg[:ar.n_train],
-                          ar.exp_avg_sq[:ar.n_train], ar.n_decay, self.lr, self.beta1, self.beta2, self.eps,
-                          self.weight_decay, ar.step)
+            self.optimizer_step()
         return {"loss": self.loss_value(sums, n, r, d * h * w)}

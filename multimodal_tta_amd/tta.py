@@ -83,20 +83,30 @@ class EntropyMinimizationTTA:
         self.use_graph = bool(get_config(m, "use_graph", True))
         self.side_streams = int(get_config(m, "side_streams", 0))   # 0: weight gradients stay on the main stream
         tr = get_config(cfg, "training", {}) or {}
-        opt_name = str(get_config(tr, "optimizer", "adam")).lower()
-        if opt_name != "adam":
-            raise NotImplementedError(
-                f"training.optimizer={opt_name}: the fused arena optimizer implements torch.optim.Adam "
-                "(the reference default, configs/training/default.yaml:11); use the nn.Module facade with a torch "
-                "optimizer for others")
-        oc = get_config(tr, "optimizers.adam", {}) or {}
-        self.lr = float(get_config(oc, "lr", get_config(tr, "learning_rate", 1e-3)))
-        betas = get_config(oc, "betas", [0.9, 0.999])
-        self.beta1, self.beta2 = float(betas[0]), float(betas[1])
-        self.eps = float(get_config(oc, "eps", 1e-8))
-        self.weight_decay = float(get_config(oc, "weight_decay", get_config(tr, "weight_decay", 0.0)))
+        # the reference's factory (src/core/experiment_manager.py:199-237): `training.optimizer` names the class
+        # (default "sgd" there, "adam" in the shipped configs/training/default.yaml:11), `training.optimizers.<name>` holds
+        # its arguments, `training.{learning_rate,weight_decay,momentum}` are the fall-backs
+        opt_name = str(get_config(tr, "optimizer", "sgd")).lower()
+        if opt_name not in ops.OPTIMIZERS:
+            raise ValueError(f"Unsupported optimizer: {opt_name}")
+        oc = get_config(tr, f"optimizers.{opt_name}", {}) or {}
         if bool(get_config(oc, "amsgrad", False)):
             raise NotImplementedError("amsgrad")
+        if bool(get_config(oc, "maximize", False)):
+            raise NotImplementedError("maximize")
+        betas = get_config(oc, "betas", [0.9, 0.999])
+        self.optim = ops.OptimSpec(
+            name=opt_name,
+            lr=float(get_config(oc, "lr", get_config(tr, "learning_rate", 1e-3))),
+            beta1=float(betas[0]), beta2=float(betas[1]),
+            eps=float(get_config(oc, "eps", 1e-8)),
+            # torch defaults when the block names none: Adam / SGD 0, AdamW 1e-2
+            weight_decay=float(get_config(oc, "weight_decay", get_config(tr, "weight_decay", 0.0))),
+            momentum=float(get_config(oc, "momentum", get_config(tr, "momentum", 0.0))) if opt_name == "sgd" else 0.0,
+            dampening=float(get_config(oc, "dampening", 0.0)) if opt_name == "sgd" else 0.0,
+            nesterov=bool(get_config(oc, "nesterov", False)) if opt_name == "sgd" else False)
+        if self.optim.nesterov and (self.optim.momentum <= 0.0 or self.optim.dampening != 0.0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")      # torch.optim.SGD's message
         rules = get_config(tr, "param_groups", {}) or {}
         self.no_decay_keys = list(get_config(rules, "no_decay_keys", []))
         self.treat_1d = bool(get_config(rules, "treat_1d_as_no_decay", True))
@@ -143,9 +153,20 @@ class EntropyMinimizationTTA:
         ops.entropy_loss(logits, dlogits, partial, loss, softmax=self.softmax)
         if ar.n_train > 0:
             rt.run_backward(dlogits)
-            ops.adam_step(ar.params[:ar.n_train], ar.grads[:ar.n_train], ar.exp_avg[:ar.n_train],
-                          ar.exp_avg_sq[:ar.n_train], ar.n_decay, self.lr, self.beta1, self.beta2, self.eps,
-                          self.weight_decay, ar.step)
+            self.optimizer_step()
+
+    def optimizer_step(self) -> None:
+        """The fused arena optimizer: ONE launch over [decay | no-decay] (+ the device step counter)."""
+        ar = self.rt.arena
+        ops.optim_step(self.optim, ar.params[:ar.n_train], ar.grads[:ar.n_train], ar.exp_avg[:ar.n_train],
+                       ar.exp_avg_sq[:ar.n_train], ar.n_decay, ar.step)
+
+    # hyper-parameters under their old attribute names (tests, scripts)
+    lr = property(lambda self: self.optim.lr)
+    beta1 = property(lambda self: self.optim.beta1)
+    beta2 = property(lambda self: self.optim.beta2)
+    eps = property(lambda self: self.optim.eps)
+    weight_decay = property(lambda self: self.optim.weight_decay)
 
     def _step(self, x_cl: torch.Tensor, present: Optional[Sequence[bool]]) -> None:
         if not self.use_graph:

@@ -30,7 +30,7 @@ from .losses import (  # noqa: F401
     DiceCELoss,
 )
 from .dice import binary_dice_iou, masks_from_logits, RegionAccumulator  # noqa: F401
-from .adam import split_param_groups, build_adam, adam_reference_step  # noqa: F401
+from .adam import split_param_groups, build_adam, build_optimizer, adam_reference_step  # noqa: F401
 from .tta import adapt_volume, select_params  # noqa: F401
 
 MODELS = {

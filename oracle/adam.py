@@ -56,6 +56,41 @@ def build_adam(named_params, train_cfg: Dict[str, Any]) -> torch.optim.Adam:
     )
 
 
+def build_optimizer(named_params, train_cfg: Dict[str, Any]) -> torch.optim.Optimizer:
+    """The reference's optimizer factory (reference src/core/experiment_manager.py:199-237): ``training.optimizer`` in
+    {sgd, adam, adamw} (default "sgd"), keyword arguments from ``training.optimizers.<name>`` restricted to the
+    class's allowed set, ``lr`` / ``momentum`` / ``weight_decay`` fall back to ``training.*``; the decay / no-decay
+    groups as in ``build_adam``."""
+    named_params = list(named_params)
+    name = str(cfg_get(train_cfg, "optimizer", "sgd")).lower()
+    space = {
+        "sgd": (torch.optim.SGD, {"lr", "momentum", "weight_decay", "dampening", "nesterov"}),
+        "adam": (torch.optim.Adam, {"lr", "betas", "eps", "weight_decay", "amsgrad"}),
+        "adamw": (torch.optim.AdamW, {"lr", "betas", "eps", "weight_decay", "amsgrad"}),
+    }
+    if name not in space:
+        raise ValueError(f"Unsupported optimizer: {name}")
+    cls, allowed = space[name]
+    opt_cfg = cfg_get(train_cfg, f"optimizers.{name}", {}) or {}
+    rules = cfg_get(train_cfg, "param_groups", {}) or {}
+    wd = float(cfg_get(opt_cfg, "weight_decay", cfg_get(train_cfg, "weight_decay", 0.0)))
+    groups = split_param_groups(named_params, wd, no_decay_keys=list(cfg_get(rules, "no_decay_keys", [])),
+                                treat_1d=bool(cfg_get(rules, "treat_1d_as_no_decay", True)))
+    groups = [g for g in groups if len(g["params"]) > 0]
+    kwargs = {k: opt_cfg[k] for k in allowed if k in opt_cfg}
+    kwargs.pop("weight_decay", None)          # the groups carry it (reference: group values override the default)
+    if "betas" in kwargs:
+        kwargs["betas"] = (float(kwargs["betas"][0]), float(kwargs["betas"][1]))
+    for k in ("lr", "eps", "momentum", "dampening"):
+        if k in kwargs:
+            kwargs[k] = float(kwargs[k])
+    if "lr" not in kwargs:
+        kwargs["lr"] = float(cfg_get(opt_cfg, "lr", cfg_get(train_cfg, "learning_rate", 1e-3)))
+    if name == "sgd" and "momentum" not in kwargs:
+        kwargs["momentum"] = float(cfg_get(opt_cfg, "momentum", cfg_get(train_cfg, "momentum", 0.0)))
+    return cls(groups, **kwargs)
+
+
 def adam_reference_step(p, g, m, v, step: int, lr: float, beta1: float, beta2: float, eps: float, wd: float):
     """One torch.optim.Adam (amsgrad=False, coupled L2) update on fp32 tensors; returns (p, m, v)."""
     g = g + wd * p if wd != 0.0 else g

@@ -238,6 +238,46 @@ def test_adam_matches_torch_over_steps():
     close("adam params", p, ref, rel=1e-6, abs_=2e-7)
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("adam", dict(lr=1e-3, betas=(0.9, 0.9999), eps=1e-8, weight_decay=5e-4)),
+    ("adamw", dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)),
+    ("sgd", dict(lr=1e-2, momentum=0.9, weight_decay=1e-4, dampening=0.0, nesterov=False)),
+    ("sgd", dict(lr=1e-2, momentum=0.9, weight_decay=1e-4, dampening=0.0, nesterov=True)),
+    ("sgd", dict(lr=1e-2, momentum=0.8, weight_decay=0.0, dampening=0.3, nesterov=False)),
+    ("sgd", dict(lr=1e-2, momentum=0.0, weight_decay=1e-3, dampening=0.0, nesterov=False)),
+])
+def test_fused_optimizers_match_torch_over_steps(name, kw):
+    """mmtta_optim_step == torch.optim.{Adam, AdamW, SGD} with the reference's decay / no-decay groups over 5 steps
+    (the three classes of the reference factory, src/core/experiment_manager.py:199-210; hyper-parameters of
+    configs/training/default.yaml:13-45)."""
+    from multimodal_tta_amd import ops
+    torch.manual_seed(8)
+    n_decay, n_nodecay = 1000, 36        # arena segments are multiples of 4
+    n = n_decay + n_nodecay
+    p0 = torch.randn(n)
+    pd = torch.nn.Parameter(p0[:n_decay].clone())
+    pn = torch.nn.Parameter(p0[n_decay:].clone())
+    cls = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "sgd": torch.optim.SGD}[name]
+    tkw = dict(kw)
+    wd = tkw.pop("weight_decay")
+    opt = cls([{"params": [pd], "weight_decay": wd}, {"params": [pn], "weight_decay": 0.0}], **tkw)
+    b = kw.get("betas", (0.9, 0.999))
+    spec = ops.OptimSpec(name=name, lr=kw["lr"], beta1=b[0], beta2=b[1], eps=kw.get("eps", 1e-8), weight_decay=wd,
+                         momentum=kw.get("momentum", 0.0), dampening=kw.get("dampening", 0.0),
+                         nesterov=kw.get("nesterov", False))
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for t in range(5):
+        g = torch.randn(n) * (10.0 ** (-t))
+        pd.grad, pn.grad = g[:n_decay].clone(), g[n_decay:].clone()
+        opt.step()
+        ops.optim_step(spec, p, g.cuda(), m, v, n_decay, step)
+    torch.cuda.synchronize()
+    assert int(step.item()) == 5
+    close(f"{name} params", p, torch.cat([pd.detach(), pn.detach()]), rel=1e-6, abs_=2e-7)
+
+
 @pytest.mark.parametrize("R,thr,shape", [(3, 0.5, (2, 8, 8, 8)), (1, 0.3, (1, 6, 10, 12)), (3, 0.5, (1, 32, 32, 32))])
 def test_mask_dice_counts_exact(R, thr, shape):
     """Integer counts are bit exact against the reference formulas (src/evaluation/seg_eval.py:41-68,304-306)."""

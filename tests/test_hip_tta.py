@@ -523,3 +523,30 @@ def test_graphs_of_a_smaller_shape_survive_workspace_growth():
     assert torch.equal(za2, want["a"]), "replaying the smaller shape's graph after the workspace grew changed its result"
     assert torch.equal(zb2, want["b"])
     del junk
+
+
+@pytest.mark.parametrize("opt,over", [
+    ("adamw", {}),                                            # configs/training/default.yaml:40-45
+    ("sgd", {"lr": 1e-2}),                                    # momentum 0.9, weight decay 1e-4 (default.yaml:13-18)
+    ("sgd", {"lr": 1e-2, "nesterov": True}),
+])
+def test_adaptation_with_the_other_factory_optimizers(opt, over):
+    """`training.optimizer` = adamw / sgd (reference src/core/experiment_manager.py:199-237) through the fused arena
+    optimizer, against the oracle loop driven by torch.optim.AdamW / SGD built by the restated factory."""
+    import oracle
+    from multimodal_tta_amd.registry import get_plugin
+
+    cfg = root_cfg(SMALL, steps=3, lr=1e-3)
+    cfg["training"]["optimizer"] = opt
+    cfg["training"]["optimizers"][opt].update(over)
+    ref, hip = build_pair(SMALL)
+    ref0 = copy.deepcopy(ref)
+    x, _ = volume(7)
+    out_ref = oracle.adapt_volume(ref, x, cfg["training"], steps=3)
+    plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    assert plug.optim.name == opt
+    res = plug.adapt_volume(x.cuda())
+    for t, (a, b) in enumerate(zip(res["losses"].cpu().tolist(), out_ref["losses"])):
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, f"{opt} step {t}: loss {a} vs oracle {b}"
+    assert out_ref["losses"][-1] != out_ref["losses"][0]
+    logits_close(plug.logits(res).cpu(), out_ref, ref0, x, cfg["training"], steps=3)

@@ -197,3 +197,24 @@ def test_surface_oracle_known_answers():
     hd, asd = oracle.evaluator_surface(pred, gt, (1.0, 1.0, 1.0))
     assert abs(float(hd[0, 0]) - math.sqrt(3 * 121)) < 1e-5 and abs(float(asd[0, 0]) - math.sqrt(3 * 121)) < 1e-5
     assert not math.isfinite(float(hd[0, 1]))
+
+
+def test_optimizer_factory_follows_the_reference_rules():
+    """reference src/core/experiment_manager.py:199-237: class by `training.optimizer`, kwargs from
+    `training.optimizers.<name>`, decay / no-decay groups, lr / momentum fall-backs, unknown name -> ValueError."""
+    import pytest
+    m = torch.nn.Sequential(torch.nn.Conv3d(2, 3, 1), torch.nn.BatchNorm3d(3))
+    tr = {"optimizer": "sgd", "learning_rate": 0.5, "momentum": 0.7,
+          "optimizers": {"sgd": {"weight_decay": 1e-4, "nesterov": False},
+                         "adamw": {"lr": 5e-4, "weight_decay": 0.05, "betas": [0.9, 0.95], "eps": 1e-6}},
+          "param_groups": {"no_decay_keys": ["bias", "bn", "norm", "LayerNorm"], "treat_1d_as_no_decay": True}}
+    opt = oracle.build_optimizer(m.named_parameters(), tr)
+    assert isinstance(opt, torch.optim.SGD)
+    g_decay, g_nodecay = opt.param_groups
+    assert g_decay["lr"] == 0.5 and g_decay["momentum"] == 0.7 and g_decay["weight_decay"] == 1e-4
+    assert g_nodecay["weight_decay"] == 0.0 and len(g_decay["params"]) == 1 and len(g_nodecay["params"]) == 3
+    opt = oracle.build_optimizer(m.named_parameters(), dict(tr, optimizer="adamw"))
+    assert isinstance(opt, torch.optim.AdamW) and opt.param_groups[0]["betas"] == (0.9, 0.95)
+    assert opt.param_groups[0]["weight_decay"] == 0.05 and opt.param_groups[0]["eps"] == 1e-6
+    with pytest.raises(ValueError, match="Unsupported optimizer"):
+        oracle.build_optimizer(m.named_parameters(), dict(tr, optimizer="lion"))
