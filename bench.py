@@ -12,11 +12,18 @@ the mask/Dice tail.  Inputs are resident in HBM before the timed region.  Ranks 
 volumes (weak scaling); the only collective is the all_gather of the per-volume Dice table.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline     - the dominant kernel (by measured time), algorithmic FLOPs per launch over its
-                 measured launch duration (events on the launch stream), against the dense MFMA peak of
-                 the operand type that kernel uses (bf16 2.5 PF, fp32 157.3 TF)
+  roofline     - the dominant conv kernel (by measured time; events on the launch stream).  bf16 mode is HBM-bound
+                 (model AI ~ 109 flop/B < ridge ~ 310): `achieved` = that kernel's ALGORITHMIC
+                 bytes per launch (input + weight image + output, each once) / its measured launch duration against
+                 8 TB/s, `traffic` = its HBM bytes per launch from the committed rocprofv3 PMC pass of this build;
+                 `mfma` carries the same kernel's FLOP/s against the dense MFMA peak of its operand type and
+                 `whole_volume` the algorithmic bytes and FLOPs of a whole adapted volume over its wall time.
+                 fp32 mode (--precision fp32) is MFMA-bound: the two blocks swap places.
   cpu_baseline - the oracle (torch CPU restatement of the reference path) timed on this host on a
                  bounded sample of the same workload.
+  parity_full_size - the GPU path against that same CPU step on volume 0 (loss, logits, masks, Dice).
+  variants     - (1 GPU) the same workload with one volume in flight, and in fp32 mode (the reference's arithmetic).
+  ranks        - per-rank volumes/s (min / max over ranks) and the time of the gather.
 """
 from __future__ import annotations
 
@@ -58,6 +65,7 @@ def parse():
     ap.add_argument("--side-streams", type=int, default=None, help="side streams for the weight gradients (default: config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the one-lane and fp32-mode runs of the same workload")
     ap.add_argument("--no-graph", action="store_true")
     return ap.parse_args()
 
@@ -80,17 +88,20 @@ def build_cfg(args):
 
 def cpu_baseline(cfg, shape, tta_steps):
     """Oracle on the host cores: 1 adaptation step + 1 final forward of one full-size volume, extrapolated to
-    S steps (a bounded sample: a whole 10-step volume is ~1 min of CPU work)."""
+    S steps (a bounded sample: a whole 10-step volume is ~1 min of CPU work).  Also returns what the step produced
+    (loss before the update, logits after it) so that the GPU path can be checked against it at full size."""
     import oracle
     from multimodal_tta_amd.synth import synth_volume
 
     torch.manual_seed(42)
     model = oracle.MODELS[cfg["model"]["name"]](cfg["model"])
+    state = {k: v.clone() for k, v in model.state_dict().items()}
     C = int(cfg["model"].get("in_channels", cfg["model"].get("num_modalities", 4)))
     R = int(cfg["model"]["num_classes"])
+    thr = float(cfg["evaluation"]["seg"]["threshold"])
     v = synth_volume(0, C, shape, R)
     x = v["image"].unsqueeze(0)
-    opt = oracle.build_adam(list(model.named_parameters()), cfg["training"])
+    opt = oracle.build_optimizer(list(model.named_parameters()), cfg["training"])
     model.train()
     t0 = time.perf_counter()
     opt.zero_grad()
@@ -102,15 +113,65 @@ def cpu_baseline(cfg, shape, tta_steps):
     t0 = time.perf_counter()
     with torch.no_grad():
         z = model(x)
-        pred, gt = oracle.masks_from_logits(z, v["label"].unsqueeze(0), 0.5)
-        oracle.binary_dice_iou(pred, gt)
+        pred, gt = oracle.masks_from_logits(z, v["label"].unsqueeze(0), thr)
+        dice, _, valid = oracle.binary_dice_iou(pred, gt)
     t_fwd = time.perf_counter() - t0
     per_volume = tta_steps * t_step + t_fwd
-    return {
+    base = {
         "value": 1.0 / per_volume, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"1 adaptation step ({t_step:.2f} s) + 1 final forward+Dice ({t_fwd:.2f} s) of one "
-                  f"{C}x{shape[0]}x{shape[1]}x{shape[2]} volume, extrapolated to S={tta_steps} steps",
+        "sample": f"1 adaptation step ({t_step:.2f} s, first call of the process: no warm-up) + 1 final forward+Dice "
+                  f"({t_fwd:.2f} s) of one {C}x{shape[0]}x{shape[1]}x{shape[2]} volume, extrapolated to S={tta_steps} steps",
     }
+    return base, {"state": state, "x": x, "label": v["label"].unsqueeze(0), "loss0": float(loss.item()), "logits": z,
+                  "pred": pred, "dice": dice, "thr": thr}
+
+
+def parity_full_size(cfg, ref, device, precision):
+    """The GPU path on the volume, weights and single step the CPU baseline just ran: |loss| relative error, logits
+    error relative to max|logits|, fraction of mask voxels that differ, largest per-region Dice difference."""
+    import oracle
+    from multimodal_tta_amd.registry import get_model, get_plugin
+    model = get_model(cfg["model"]["name"])(cfg["model"])
+    model.load_state_dict(ref["state"])
+    plug = get_plugin("entmin_tta")(cfg)
+    plug.lane = 5
+    plug.setup(model, device)
+    res = plug.adapt_volume(ref["x"].to(device), steps=1)
+    z = plug.logits(res).cpu()
+    loss0 = float(res["losses"].cpu()[0])
+    scale = ref["logits"].abs().max().item()
+    pred = (torch.sigmoid(z) >= ref["thr"]).to(torch.uint8)
+    dice, _, _ = oracle.binary_dice_iou(pred, (ref["label"] > 0.5).to(torch.uint8))
+    tol = {"bf16": dict(loss=1e-2, logits=3e-2, dice=2e-2), "fp32": dict(loss=1e-4, logits=2e-3, dice=1e-3)}[precision]
+    out = {
+        "against": "cpu_baseline step (oracle, fp32, same weights / volume 0 / 1 step + final forward)",
+        "loss_rel_err": abs(loss0 - ref["loss0"]) / abs(ref["loss0"]),
+        "logits_err_over_max": (z - ref["logits"]).abs().max().item() / scale,
+        "mask_mismatch_fraction": (pred != ref["pred"]).float().mean().item(),
+        "dice_max_abs_diff": (dice - ref["dice"]).abs().max().item(),
+        "dice_gpu": [float(v) for v in dice.view(-1)], "dice_cpu": [float(v) for v in ref["dice"].view(-1)],
+        "tolerance": tol,
+    }
+    out["within_tolerance"] = bool(out["loss_rel_err"] <= tol["loss"] and out["logits_err_over_max"] <= tol["logits"]
+                                   and out["dice_max_abs_diff"] <= tol["dice"])
+    del plug, model
+    return out
+
+
+def bench_rows(counts_cpu: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """This rank's rows of the per-volume table: global volume index i*world + rank (round-robin shard), domain 0,
+    loss 0, then dice / iou / valid from the exact counts.  counts_cpu: int64 [n_local, R, 3]."""
+    from multimodal_tta_amd.evaluation import dice_iou_from_counts
+    n = counts_cpu.shape[0]
+    dice, iou, valid = dice_iou_from_counts(counts_cpu)
+    return torch.cat([torch.arange(n, dtype=torch.float64).view(-1, 1) * world + rank,
+                      torch.zeros(n, 2, dtype=torch.float64), dice.double(), iou.double(), valid.double()], dim=1)
+
+
+def post_dice_from_table(table: torch.Tensor, R: int) -> float:
+    vmask = table[:, 3 + 2 * R:3 + 3 * R] > 0.5
+    dvals = table[:, 3:3 + R]
+    return float((dvals * vmask).sum().item() / max(1.0, float(vmask.sum().item())))
 
 
 def main():
@@ -150,18 +211,6 @@ def main():
     from multimodal_tta_amd.synth import synth_volume
 
     cfg, shape = build_cfg(args)
-    torch.manual_seed(42)
-    model = get_model(cfg["model"]["name"])(cfg["model"])
-    plug = get_plugin("entmin_tta")(cfg).setup(model, device)
-    lanes = max(1, int(args.lanes if args.lanes is not None else cfg["method"].get("lanes", 1)))
-    plugs, streams = [plug], [torch.cuda.Stream(device=device)]
-    for lane in range(1, lanes):          # same source weights in every lane (episodic: restored per volume)
-        m2 = get_model(cfg["model"]["name"])(cfg["model"])
-        m2.load_state_dict(model.state_dict())
-        p2 = get_plugin("entmin_tta")(cfg)
-        p2.lane = lane
-        plugs.append(p2.setup(m2, device))
-        streams.append(torch.cuda.Stream(device=device))
     C = int(cfg["model"].get("in_channels", cfg["model"].get("num_modalities", 4)))
     R = int(cfg["model"]["num_classes"])
     thr = float(cfg["evaluation"]["seg"]["threshold"])
@@ -170,42 +219,59 @@ def main():
     for i in range(nvol):
         v = synth_volume(rank * nvol + i, C, shape, R)
         vols.append((v["image"].unsqueeze(0).to(device), v["label"].unsqueeze(0).to(device)))
+
+    def make_lanes(cfg_, lanes_, lane0=0):
+        """`lanes_` plugins with the same seeded source weights (episodic: restored per volume), a stream each."""
+        torch.manual_seed(42)
+        model = get_model(cfg_["model"]["name"])(cfg_["model"])
+        plugs_, streams_ = [], []
+        for lane in range(lanes_):
+            m = model if lane == 0 else get_model(cfg_["model"]["name"])(cfg_["model"])
+            if lane:
+                m.load_state_dict(model.state_dict())
+            p_ = get_plugin("entmin_tta")(cfg_)
+            p_.lane = lane0 + lane
+            plugs_.append(p_.setup(m, device))
+            streams_.append(torch.cuda.Stream(device=device))
+        return plugs_, streams_
+
+    def run_volumes(plugs_, streams_, first, last, counts_):
+        for i in range(first, last):
+            lane = i % len(plugs_)
+            x, y = vols[i % nvol]
+            with torch.cuda.stream(streams_[lane]):
+                res = plugs_[lane].adapt_volume(x)
+                ops.mask_dice_counts(res["logits_cl"], y, thr, counts_[i % nvol:i % nvol + 1], None)
+
+    lanes = max(1, int(args.lanes if args.lanes is not None else cfg["method"].get("lanes", 1)))
+    plugs, streams = make_lanes(cfg, lanes)
+    plug = plugs[0]
     counts = torch.zeros((nvol, R, 3), dtype=torch.int64, device=device)
 
-    def one_volume(i):
-        lane = i % lanes
-        x, y = vols[i]
-        with torch.cuda.stream(streams[lane]):
-            res = plugs[lane].adapt_volume(x)
-            ops.mask_dice_counts(res["logits_cl"], y, thr, counts[i:i + 1], None)
-
-    for i in range(max(args.warmup, lanes)):      # every lane captures its graph before the timed region
-        one_volume(i % nvol)
+    run_volumes(plugs, streams, 0, max(args.warmup, lanes), counts)      # every lane captures its graph before the timed region
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, nvol):
-        one_volume(i)
+    run_volumes(plugs, streams, args.warmup, nvol, counts)
     torch.cuda.synchronize()
-    dice, iou, valid = dice_iou_from_counts(counts[args.warmup:].cpu())
-    rows = torch.cat([torch.arange(args.steps, dtype=torch.float64).view(-1, 1) * world + rank,
-                      torch.zeros(args.steps, 2, dtype=torch.float64), dice.double(), iou.double(), valid.double()], dim=1)
+    t_local = time.perf_counter() - t0
+    rows = bench_rows(counts[args.warmup:].cpu(), rank, world)
+    tg0 = time.perf_counter()
     table = gather_table(rows.to(device), args.steps * world, world)
     torch.cuda.synchronize()
+    t_gather = time.perf_counter() - tg0
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, t_local, -t_local, t_gather], dtype=torch.float64, device=device)
     if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, t_local_max, t_local_min, t_gather = float(t[0]), float(t[1]), -float(t[2]), float(t[3])
     assert table.shape == (args.steps * world, table_width(R))
-    vmask = table[:, 3 + 2 * R:3 + 3 * R] > 0.5
-    dvals = table[:, 3:3 + R]
-    post_dice = float((dvals * vmask).sum().item() / max(1.0, float(vmask.sum().item())))
+    post_dice = post_dice_from_table(table, R)
 
     out = {
         "metric": "adapted volumes/sec", "value": args.steps * world / elapsed, "unit": "volumes/s",
@@ -217,76 +283,126 @@ def main():
             "workload": f"{cfg['model']['name']} {C}x{shape[0]}x{shape[1]}x{shape[2]} {args.task}-shaped volume: "
                         f"S={args.tta_steps} entropy-min steps (fwd+bwd+Adam, all parameters) + final forward + Dice",
             "tta_steps": args.tta_steps, "volume": [C, *shape], "adapted_params": str(cfg["method"]["params"]),
-            "precision": ("bf16 MFMA operands (v_mfma_f32_32x32x16_bf16) for forward/input-gradient convs, fp32 accumulate; "
-                          "fp32 storage, norms, loss, weight gradients, Adam") if args.precision == "bf16"
+            "precision": ("bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulate, for forward, input-gradient "
+                          "and 27-tap weight-gradient convs; fp32 storage, norms, loss, 1x1/thin weight gradients, "
+                          "Adam and master weights") if args.precision == "bf16"
             else "fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32)", "weights": "seeded default init (no checkpoint offline)",
-            "parallelism": f"{world} rank(s), one per GPU, volumes sharded round-robin, one all_gather of the Dice table; "
-                           f"{lanes} volume(s) in flight per GPU on separate streams",
+            "parallelism": f"{world} rank(s), one per GPU, volumes sharded round-robin, no data-path collective; the "
+                           f"per-volume Dice table is merged by one all_gather; {lanes} volume(s) in flight per GPU on "
+                           "separate streams",
             "graph": bool(plug.use_graph), "lanes": lanes,
         },
+        "ranks": {"volumes_per_s_min": args.steps / t_local_max, "volumes_per_s_max": args.steps / t_local_min,
+                  "gather_ms": 1000.0 * t_gather},
     }
 
     if rank == 0 and not args.no_profile_pass:
-        # instrumented eager pass: events around every conv launch, on the launch stream
-        # (multi-kernel entry points launch only their main kernel here, so a call's duration IS the duration of the
-        # kernel rocprofv3 lists under that name; the outputs of this pass are thrown away)
-        from multimodal_tta_amd import _lib
-        prof = ops.KernelProfiler(reps=4)
-        ops.PROFILER = prof
-        saved = plug.use_graph
-        plug.use_graph = False
-        _lib.load().mmtta_set_option(1, 1)
-        try:
-            plug.adapt_volume(vols[0][0], steps=2)
+        out["roofline"] = roofline_block(args, cfg, plug, vols[0][0], elapsed / args.steps)
+        out["config"]["algorithmic_conv_tflop_per_volume"] = out["roofline"]["whole_volume"]["algorithmic_tflop"]
+    if rank == 0 and world == 1 and not args.no_variants:
+        # the same workload (a) with one volume in flight, (b) in fp32 mode: the reference's own arithmetic
+        variants = {}
+        for name, prec, nl in (("one_lane", args.precision, 1), ("fp32", "fp32", lanes)):
+            if (prec, nl) == (args.precision, lanes):
+                continue
+            a2 = argparse.Namespace(**vars(args))
+            a2.precision = prec
+            cfg2, _ = build_cfg(a2)
+            pl2, st2 = make_lanes(cfg2, nl, lane0=8 if name == "fp32" else 6)
+            c2 = torch.zeros_like(counts)
+            nv = min(args.steps, 4)
+            run_volumes(pl2, st2, 0, nl, c2)
             torch.cuda.synchronize()
-        finally:
-            _lib.load().mmtta_set_option(1, 0)
-        plug.use_graph = saved
-        ops.PROFILER = None
-        summ = prof.summary()
-        total_ms = sum(d["ms"] for d in summ.values())
-        # algorithmic conv FLOPs of one adapted volume from the same pass (2 steps + 1 final forward were recorded)
-        per_kind = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
-        for rname, _launches, rflops, _e0, _e1, detail in prof.records:
-            kind = detail.split(" ")[0]
-            kind = "fwd" if kind.startswith("fwd") else ("dgrad" if kind.startswith("dgrad") else "wgrad")
-            per_kind[kind] += rflops / prof.reps
-        f_fwd = per_kind["fwd"] / 3.0
-        f_vol = args.tta_steps * (f_fwd + per_kind["dgrad"] / 2.0 + per_kind["wgrad"] / 2.0) + f_fwd
-        eff = f_vol / (elapsed / (args.steps * world) * world) / 1e12     # per GPU: one volume's FLOPs / its wall time
-        out["config"]["algorithmic_conv_tflop_per_volume"] = f_vol / 1e12
-        whole = {"effective_tflops_per_gpu": eff,
-                 "frac_of_mfma_peak": eff / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS)}
-        name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        peak = mfma_peak(name)
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this build
-        # (scripts/pmc_layers.sh -> scripts/pmc_summary.py --json; FETCH_SIZE x2 on gfx950 + WRITE_SIZE), else null
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            t = json.load(open(tpath)).get(name)
-            if t:
-                traffic = t["fetch_bytes"] + t["write_bytes"]
-        out["roofline"] = {
-            "bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": traffic,
-            "avg_launch_us": 1000.0 * d["ms"] / d["launches"], "launches": d["launches"],
-            "flops_per_launch": d["flops"] / d["launches"],
-            "share_of_conv_time": d["ms"] / total_ms,
-            "all_conv_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
-                                     "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / mfma_peak(k), "ms": v["ms"],
-                                     "launches": v["launches"]} for k, v in sorted(summ.items())},
-            "conv_tflops_overall": sum(v["flops"] for v in summ.values()) / (total_ms * 1e-3) / 1e12,
-            "whole_volume": whole,
-        }
+            tv = time.perf_counter()
+            run_volumes(pl2, st2, args.warmup, args.warmup + nv, c2)
+            torch.cuda.synchronize()
+            tv = time.perf_counter() - tv
+            variants[name] = {"value": nv / tv, "unit": "volumes/s", "precision": prec, "lanes": nl, "volumes": nv}
+            del pl2, st2
+        out["variants"] = variants
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, shape, args.tta_steps)
+        out["cpu_baseline"], ref = cpu_baseline(cfg, shape, args.tta_steps)
+        out["parity_full_size"] = parity_full_size(cfg, ref, device, args.precision)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()            # rank 0 may still have been in its profile pass
         dist.destroy_process_group()
+
+
+def roofline_block(args, cfg, plug, x0, s_per_volume):
+    """Instrumented eager pass: events around every conv launch, on the launch stream (multi-kernel entry points launch
+    only their main kernel here, so a call's duration IS the duration of the kernel rocprofv3 lists under that name; the
+    outputs of this pass are thrown away)."""
+    from multimodal_tta_amd import _lib, ops
+    prof = ops.KernelProfiler(reps=4)
+    ops.PROFILER = prof
+    saved = plug.use_graph
+    plug.use_graph = False
+    _lib.load().mmtta_set_option(1, 1)
+    try:
+        plug.adapt_volume(x0, steps=2)
+        torch.cuda.synchronize()
+    finally:
+        _lib.load().mmtta_set_option(1, 0)
+        plug.use_graph = saved
+        ops.PROFILER = None
+    summ = prof.summary()
+    total_ms = sum(d["ms"] for d in summ.values())
+    # algorithmic conv FLOPs and bytes of one adapted volume from the same pass (2 steps + 1 final forward recorded)
+    per_kind = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
+    for rname, _launches, rflops, _e0, _e1, detail, rbytes in prof.records:
+        kind = detail.split(" ")[0]
+        kind = "fwd" if kind.startswith("fwd") else ("dgrad" if kind.startswith("dgrad") else "wgrad")
+        per_kind[kind][0] += rflops / prof.reps
+        per_kind[kind][1] += rbytes / prof.reps
+    S = args.tta_steps
+    f_fwd, b_fwd = per_kind["fwd"][0] / 3.0, per_kind["fwd"][1] / 3.0
+    f_vol = S * (f_fwd + per_kind["dgrad"][0] / 2.0 + per_kind["wgrad"][0] / 2.0) + f_fwd
+    n_params = plug.rt.arena.n_train
+    R = int(cfg["model"]["num_classes"])
+    nvox = int(x0.shape[2] * x0.shape[3] * x0.shape[4])
+    # SURVEY.md section 8(d): B = B_fwd * (3S + 1) + 28 B * P * S (optimizer) + 2 * R * DHW (mask + Dice), fp32 tensors
+    b_vol_survey = b_fwd * (3 * S + 1) + 28.0 * n_params * S + 2.0 * R * nvox
+    b_vol_layers = S * (b_fwd + per_kind["dgrad"][1] / 2.0 + per_kind["wgrad"][1] / 2.0) + b_fwd + 28.0 * n_params * S \
+        + 2.0 * R * nvox
+    bf = args.precision == "bf16"
+    whole = {"algorithmic_tflop": f_vol / 1e12, "effective_tflops_per_gpu": f_vol / s_per_volume / 1e12,
+             "frac_of_mfma_peak": f_vol / s_per_volume / 1e12 / (PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS),
+             "algorithmic_gb": b_vol_survey / 1e9, "algorithmic_gb_per_layer_io": b_vol_layers / 1e9,
+             "achieved_gbps": b_vol_survey / s_per_volume / 1e9, "frac_of_hbm_peak": b_vol_survey / s_per_volume / 1e9 / PEAK_HBM_GBPS,
+             "b_fwd_gb": b_fwd / 1e9}
+    name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    sec = d["ms"] * 1e-3
+    tflops = d["flops"] / sec / 1e12
+    gbps = d["bytes"] / sec / 1e9
+    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this build
+    # (scripts/pmc_layers.sh -> scripts/pmc_summary.py --json; FETCH_SIZE x2 on gfx950 + WRITE_SIZE), else null
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath)).get(name)
+        if t:
+            traffic = t["fetch_bytes"] + t["write_bytes"]
+    hbm = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+           "bytes_per_launch": d["bytes"] / d["launches"]}
+    mfma = {"bound": "mfma", "achieved": tflops, "peak": mfma_peak(name), "unit": "TFLOP/s", "frac": tflops / mfma_peak(name),
+            "flops_per_launch": d["flops"] / d["launches"]}
+    first, second = (hbm, mfma) if bf else (mfma, hbm)
+    block = dict(first)
+    block.update({
+        "kernel": name, "traffic": traffic, "avg_launch_us": 1000.0 * d["ms"] / d["launches"], "launches": d["launches"],
+        "share_of_conv_time": d["ms"] / total_ms,
+        ("mfma" if bf else "hbm"): {k: v for k, v in second.items() if k != "bound"},
+        "all_conv_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                 "mfma_frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / mfma_peak(k),
+                                 "gbps": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
+                                 "hbm_frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, "ms": v["ms"],
+                                 "launches": v["launches"]} for k, v in sorted(summ.items())},
+        "conv_tflops_overall": sum(v["flops"] for v in summ.values()) / (total_ms * 1e-3) / 1e12,
+        "whole_volume": whole,
+    })
+    return block
 
 
 if __name__ == "__main__":

@@ -39,6 +39,7 @@ class Workspace:
 
     _buffers: Dict[Tuple[int, int, int], torch.Tensor] = {}
     _retired: list = []     # superseded buffers, kept alive for the graphs that reference them
+    min_bytes = 1 << 20     # first allocation of a slot (tests lower it to provoke growth with small shapes)
     frozen = False
     slot = 0        # 0: main launch sequence; 1..: the side streams of the weight gradients (engine.ConvLayer.wgrad)
     lane = 0        # runtimes that run concurrently on different streams (bench.py --lanes) keep separate scratch
@@ -55,7 +56,7 @@ class Workspace:
                 raise MmttaError("workspace would have to grow during graph capture; run one eager warm-up step first")
             if buf is not None:
                 cls._retired.append(buf)
-            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            buf = torch.empty(max(nbytes, cls.min_bytes), dtype=torch.uint8, device=device)
             cls._buffers[key] = buf
         return buf
 
@@ -163,29 +164,31 @@ class KernelProfiler:
         e.record()
         return e
 
-    def end(self, name: str, launches: int, flops: float, e0, detail: str = "") -> None:
+    def end(self, name: str, launches: int, flops: float, e0, detail: str = "", nbytes: float = 0.0) -> None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((name, launches, flops, e0, e1, detail))
+        self.records.append((name, launches, flops, e0, e1, detail, nbytes))
 
     def by_layer(self):
         """Per (kernel, layer shape) totals: scripts/layer_times.py prints them."""
         torch.cuda.synchronize()
         out = {}
-        for name, launches, flops, e0, e1, detail in self.records:
-            d = out.setdefault((name, detail), {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for name, launches, flops, e0, e1, detail, nbytes in self.records:
+            d = out.setdefault((name, detail), {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
             d["launches"] += launches
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
         return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, launches, flops, e0, e1, _detail in self.records:
-            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "calls": 0})
+        for name, launches, flops, e0, e1, _detail, nbytes in self.records:
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "calls": 0, "bytes": 0.0})
             d["launches"] += launches
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
             d["calls"] += 1
         return out
@@ -276,7 +279,8 @@ class ConvOp:
             for _ in range(PROFILER.reps):
                 launch()
             PROFILER.end(self._kernel_name(p.config, desc, x, y), PROFILER.reps,
-                         self.flops(x, y, desc) * PROFILER.reps, e0, self._detail(desc.op, x))
+                         self.flops(x, y, desc) * PROFILER.reps, e0, self._detail(desc.op, x),
+                         self.io_bytes(x, y, packed) * PROFILER.reps)
 
     def _kernel_name(self, config: int, desc, x: torch.Tensor, y: torch.Tensor) -> str:
         """Profiler label of the kernel a conv_run call dispatches to (mirrors csrc: the thin layers have matrix-core
@@ -307,6 +311,12 @@ class ConvOp:
         coarse = min(x.shape[1] * x.shape[2] * x.shape[3], y.shape[1] * y.shape[2] * y.shape[3]) * x.shape[0]
         return 2.0 * coarse * self.cin * self.cout * self.k ** 3
 
+    @staticmethod
+    def io_bytes(a: torch.Tensor, b: torch.Tensor, w: torch.Tensor) -> float:
+        """Algorithmic bytes of one call (SURVEY.md section 8d convention): each activation tensor of the call once
+        (logical channels, storage element size) plus the weight image / weight gradient once."""
+        return float(a.numel() * a.element_size() + b.numel() * b.element_size() + w.numel() * w.element_size())
+
     def forward(self, x: torch.Tensor, x_nl: Optional[NL], bias: Optional[torch.Tensor], y: torch.Tensor,
                 stats: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
                 add_nl: Optional[NL] = None, accumulate: bool = False) -> None:
@@ -335,7 +345,7 @@ class ConvOp:
                 launch()
             kid = lib.mmtta_conv_wgrad_kernel(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy))
             PROFILER.end(WGRAD_KERNELS[kid], PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0,
-                         self._detail(-1, x))
+                         self._detail(-1, x), self.io_bytes(x, dy, dw) * PROFILER.reps)
 
 
 class BatchedPacker:

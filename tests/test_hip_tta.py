@@ -509,10 +509,15 @@ def test_graphs_of_a_smaller_shape_survive_workspace_growth():
     _, hip = build_pair(SMALL)
     plug = get_plugin("entmin_tta")(root_cfg(SMALL, steps=3, lr=1e-3, use_graph=True)).setup(hip, "cuda")
     plug.lane = 8
-    za1 = plug.logits(plug.adapt_volume(xa)).clone()
     key = (xa.device.index, 0, 8)
-    small = ops.Workspace._buffers[key]
-    zb = plug.logits(plug.adapt_volume(xb)).clone()
+    ops.Workspace._buffers.pop(key, None)
+    saved_min, ops.Workspace.min_bytes = ops.Workspace.min_bytes, 256     # shape A gets exactly what it needs
+    try:
+        za1 = plug.logits(plug.adapt_volume(xa)).clone()
+        small = ops.Workspace._buffers[key]
+        zb = plug.logits(plug.adapt_volume(xb)).clone()
+    finally:
+        ops.Workspace.min_bytes = saved_min
     assert ops.Workspace._buffers[key] is not small, "shape B was expected to outgrow shape A's workspace"
     junk = [torch.full((small.numel() // 4,), float("nan"), device="cuda") for _ in range(4)]   # would land in a freed block
     za2 = plug.logits(plug.adapt_volume(xa)).clone()

@@ -171,3 +171,48 @@ def test_seg_eval_under_two_gloo_ranks_reports_the_whole_split(tmp_path, shards)
         tabs.append(torch.load(os.path.join(str(tmp_path), f"tab{r}.pt"), weights_only=True))
     assert torch.equal(tabs[0], tabs[1]) and tabs[0].shape == (n, table_width(R))
     assert tabs[0][:, 0].tolist() == [float(i) for i in range(n)]
+
+
+# ----------------------------------------------------------------------------- bench.py's table assembly
+def _bench_counts(rank, n):
+    g = torch.Generator().manual_seed(100 + rank)
+    gt = torch.randint(0, 5000, (n, R), generator=g)
+    gt[0, 1] = 0                                   # an empty ground-truth region: valid = False
+    pred = torch.randint(0, 5000, (n, R), generator=g)
+    inter = torch.minimum(gt, pred) // 2
+    return torch.stack([inter, pred, gt], dim=-1).to(torch.int64)
+
+
+def _bench_worker(rank, world, port, n, out_dir):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = bench.bench_rows(_bench_counts(rank, n), rank, world)
+    table = gather_table(rows, n * world, world)
+    torch.save(table, os.path.join(out_dir, f"b{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_bench_table_assembly_two_processes_gloo(tmp_path):
+    """bench.py --gpus N: every rank contributes `steps` rows with global indices i*W + rank; the gathered table is the
+    same on every rank, sorted by volume index, and post_tta_dice is the mean over the VALID (volume, region) pairs."""
+    import bench
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n, world = 3, 2
+    mp.spawn(_bench_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    per_rank = [bench.bench_rows(_bench_counts(r, n), r, world) for r in range(world)]
+    want = torch.cat(per_rank)
+    want = want[torch.argsort(want[:, 0])]
+    assert want[:, 0].tolist() == [float(i) for i in range(n * world)]
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f"b{r}.pt"), weights_only=True)
+        assert torch.equal(got, want), f"rank {r}"
+    valid = want[:, 3 + 2 * R:3 + 3 * R] > 0.5
+    assert int((~valid).sum()) == world              # the two empty-GT regions are excluded
+    assert abs(bench.post_dice_from_table(want, R) - float(want[:, 3:3 + R][valid].mean())) < 1e-12
