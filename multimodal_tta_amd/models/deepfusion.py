@@ -152,6 +152,41 @@ class DeepFusionRuntime(Runtime):
         self.state.update(catf=catf, shared=shared, bcat=bcat, xdec=xdec, last=cur, skips=skips)
         return logits
 
+    # ---------------------------------------------------------------- auxiliary outputs
+    def _global_mean(self, key, feat: torch.Tensor) -> torch.Tensor:
+        """mean over the voxels of a channels-last feature map -> [n, C] (reference :76 ``torch.mean(x, dim=[2,3,4])``):
+        the two-stage per-(n,c) sum kernels of the norm layers, count = voxels."""
+        n, d, h, w, c = feat.shape
+        rows = ops.reduce_rows_per_n(feat)
+        part = self.pool.flat((key, "gpart"), n * rows * 2 * c)
+        mean = self.pool.flat((key, "gmean"), n * c)
+        rstd = self.pool.flat((key, "grstd"), n * c)
+        scratch = self.pool.flat((key, "gtot"), n * c * 2, dtype=torch.float64)
+        ops.channel_stats(feat, part)
+        ops.norm_stats_finalize(ops.NORM_INSTANCE, 1, part, rows, n, c, d * h * w, 1e-5, True, None, None, 0.1, mean, rstd,
+                                scratch)
+        return mean.view(n, c)
+
+    def global_features(self):
+        """(specific_globals_flat: list of M [B, C_b], shared global [B, C_b]) of the last forward."""
+        st, cb = self.state, self.channels[-1]
+        spec = [self._global_mean(("spec", m), st["catf"][m][..., cb:]).clone() for m in range(self.M)]
+        shared = self._global_mean("sharedg", st["shared"]).clone()
+        return spec, shared
+
+    def domain_logits(self, spec: List[torch.Tensor], classifier: nn.Linear) -> torch.Tensor:
+        """``domain_classifier(torch.cat(specific_globals, dim=0).view(B*C, -1))`` (reference :263-264): rows are
+        modality-major; the Linear runs as a 1x1x1 convolution over B*M one-voxel items."""
+        B, cb = spec[0].shape
+        g = torch.cat(spec, dim=0).contiguous().view(B * self.M, 1, 1, 1, cb)
+        if getattr(self, "_dom_op", None) is None:
+            self._dom_op = ops.ConvOp(cb, self.M, 1, 1, False, self.device, dtype=ops.F32)
+        w = classifier.weight.detach().to(self.device, torch.float32).contiguous().view(self.M, cb, 1, 1, 1)
+        self._dom_op.pack(w)
+        out = ops.new_cl(B * self.M, 1, 1, 1, self.M, self.device, ldc=(self.M + 3) // 4 * 4)
+        self._dom_op.forward(g, None, classifier.bias.detach().to(self.device, torch.float32).contiguous(), out)
+        return out.reshape(B * self.M, -1)[:, :self.M].clone()
+
     # ---------------------------------------------------------------- backward
     def backward_cl(self, dlogits: torch.Tensor) -> None:
         st, pool, c = self.state, self.pool, self.channels
@@ -265,18 +300,32 @@ class MultimodalUNetDeepFusion(HipSegModel):
 
     def forward(self, x: torch.Tensor, return_domain_logits: bool = False,
                 return_intermediate_features: bool = False, present: Optional[Sequence[bool]] = None):
-        if return_domain_logits or return_intermediate_features:
-            raise NotImplementedError(
-                "domain logits / intermediate features are auxiliary training outputs the reference trainer never "
-                "requests (src/core/trainers/seg_trainer.py:110); they are outside the adaptation hot path")
-        if present is not None:
+        """Reference contract (src/models/unet_multimodal_midfusion.py:204-267): logits, or - with the domain classifier
+        enabled - ``(logits, shared_globals_rep, specific_globals_flat)`` / ``(logits, domain_logits)`` (the first
+        flag wins, like the reference's two ``if``s).  The auxiliary outputs are computed from the bottleneck
+        features the forward just produced (global means: the per-(n,c) statistics kernels; classifier: a 1x1x1
+        convolution launch) and are returned DETACHED: the reference trainer never requests them
+        (seg_trainer.py:110), so no backward is wired through them."""
+        aux = (return_domain_logits or return_intermediate_features) and self.domain_enabled
+        if present is not None or aux:
             if x.device.type != "cuda":
                 raise ops.MmttaError("this model computes on an MI355X through libmmtta.so")
+        if present is not None:
             rt = self.runtime(x.device)
             rt.training = self.training
             rt.pack_all()
-            return ops.from_cl(rt.forward_cl(rt.stage_input(x.float()), present=present))
-        return super().forward(x)
+            logits = ops.from_cl(rt.forward_cl(rt.stage_input(x.float()), present=present))
+        else:
+            logits = super().forward(x)
+        if not aux:
+            return logits
+        if present is not None and not all(present):
+            raise ValueError("auxiliary outputs need every modality present (the reference has no missing-modality path)")
+        rt = self.runtime(x.device)
+        spec, shared = rt.global_features()
+        if return_intermediate_features:
+            return logits, [shared for _ in range(x.shape[1])], spec
+        return logits, rt.domain_logits(spec, self.domain_classifier)
 
     def get_domain_loss_weight(self) -> float:
         return self.domain_loss_weight if getattr(self, "domain_enabled", False) else 0.0

@@ -134,3 +134,37 @@ def test_deepfusion_missing_modality_forward_and_tta():
     # implementations differ by a few 1e-3 of their range whatever the kernels do (measured 1.9e-3 .. 2.1e-3 across
     # builds of this repository); the losses above are the tight check.
     assert e_hip <= max(4e-3, 3 * e_ref), (e_hip, e_ref)
+
+
+@pytest.mark.parametrize("over,shape", [({}, (2, 4, 16, 16, 16)), ({"num_modalities": 2, "num_classes": 1}, (1, 2, 16, 16, 32))])
+def test_auxiliary_outputs_match_the_oracle(over, shape):
+    """``forward(..., return_intermediate_features=True)`` and ``return_domain_logits=True`` (reference
+    src/models/unet_multimodal_midfusion.py:204-209,258-265): same tuple structure, shared / specific global means
+    and the domain classifier's logits against the oracle restatement; disabled classifier -> plain logits."""
+    cfg = dict(SMALL, **over)
+    ref, hip = build_pair(cfg)
+    torch.manual_seed(1)
+    x = torch.randn(shape)
+    ref.eval()
+    hip.eval()
+    with torch.no_grad():
+        z_ref, sh_ref, sp_ref = ref(x, return_intermediate_features=True)
+        z2_ref, dl_ref = ref(x, return_domain_logits=True)
+        z, sh, sp = hip(x.cuda(), return_intermediate_features=True)
+        z2, dl = hip(x.cuda(), return_domain_logits=True)
+    M = cfg["num_modalities"]
+    assert len(sh) == len(sh_ref) == M and len(sp) == len(sp_ref) == M
+    assert rel_err(z, z_ref) < 5e-4 and rel_err(z2, z2_ref) < 5e-4
+    for a, b in zip(sh + sp, sh_ref + sp_ref):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-4, (a.shape, b.shape, rel_err(a, b))
+    assert dl.shape == dl_ref.shape == (shape[0] * M, M)
+    assert rel_err(dl, dl_ref) < 2e-4, rel_err(dl, dl_ref)
+    # the first flag wins when both are set; a model without the classifier returns plain logits (reference :258-265)
+    with torch.no_grad():
+        both = hip(x.cuda(), return_domain_logits=True, return_intermediate_features=True)
+    assert len(both) == 3
+    ref2, hip2 = build_pair(dict(cfg, domain_classifier={"enabled": False}))
+    with torch.no_grad():
+        plain = hip2(x.cuda(), return_domain_logits=True)
+    assert torch.is_tensor(plain) and plain.shape == z_ref.shape
+    assert hip2.get_domain_loss_weight() == 0.0 and hip.get_domain_loss_weight() == 0.1
