@@ -22,6 +22,11 @@ def build_pair(cfg, seed=42):
     return ref, hip.cuda()
 
 
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+
+
 def feeds_norm(model, pname):
     if not pname.endswith(".conv.bias"):
         return False
@@ -141,7 +146,7 @@ def test_auxiliary_outputs_match_the_oracle(over, shape):
     """``forward(..., return_intermediate_features=True)`` and ``return_domain_logits=True`` (reference
     src/models/unet_multimodal_midfusion.py:204-209,258-265): same tuple structure, shared / specific global means
     and the domain classifier's logits against the oracle restatement; disabled classifier -> plain logits."""
-    cfg = dict(SMALL, **over)
+    cfg = dict(CFG, **over)
     ref, hip = build_pair(cfg)
     torch.manual_seed(1)
     x = torch.randn(shape)
