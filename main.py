@@ -19,6 +19,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per lane (see bench.py); read at HIP start-up
 
 
 def main(argv=None) -> dict:

@@ -8,13 +8,22 @@ Importing the package registers, under the reference's own registry names
   dataset builders       brats, hecktor21, default (synthetic volumes)
 All arithmetic runs in csrc/libmmtta.so (HIP, gfx950); there is no CPU or PyTorch fallback.
 """
-from . import registry  # noqa: F401
-from .config import Cfg, compose, get_config, require_config  # noqa: F401
-from . import models  # noqa: F401  (registers the models)
-from . import evaluation  # noqa: F401
-from . import tta  # noqa: F401
-from . import trainer  # noqa: F401  (plugin seg_supervised_step)
-from . import datasets  # noqa: F401
+import os as _os
+
+# `method.lanes` volumes are adapted concurrently per GPU, one stream each; their kernels only overlap when the streams
+# sit on different hardware queues, and the HIP runtime spreads all streams of a process over GPU_MAX_HW_QUEUES (default
+# 4) queues.  8 is the measured optimum for 3-4 lanes (42.0 -> 50.1 volumes/s; 16 is slower).  The variable is read when
+# HIP starts up, i.e. this only takes effect when the package is imported before the first CUDA call of the process
+# (bench.py and main.py set it first thing).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import registry  # noqa: F401,E402
+from .config import Cfg, compose, get_config, require_config  # noqa: F401,E402
+from . import models  # noqa: F401,E402  (registers the models)
+from . import evaluation  # noqa: F401,E402
+from . import tta  # noqa: F401,E402
+from . import trainer  # noqa: F401,E402  (plugin seg_supervised_step)
+from . import datasets  # noqa: F401,E402
 
 __all__ = ["registry", "compose", "get_config", "require_config", "Cfg", "models", "evaluation", "tta", "datasets"]
 __version__ = "0.1.0"

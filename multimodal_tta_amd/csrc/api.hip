@@ -11,7 +11,9 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 int g_profile_main_only = 0;
-int g_tune[4] = {192, 256, 256, 256};      // split-K below / target, weight-gradient workgroups, thin-layer slabs
+// split-K below / target, weight-gradient workgroups, thin-layer slabs.  Swept with the lanes bound to their own hardware
+// queues (profiles/r02_tuning_sweep.txt): four volumes in flight want half the splitting two did (96/128, 128 slabs)
+int g_tune[4] = {96, 128, 128, 256};
 }  // namespace mmtta
 
 extern "C" int mmtta_set_option(int key, int value) {

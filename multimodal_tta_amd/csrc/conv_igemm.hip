@@ -120,9 +120,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
   const int cb = wave % NB, mg = wave / NB;
   const int h = lane >> 5, r = lane & 31;
 
-  const int cidx = blockIdx.x / a.tiles_per_cls;
+  // workgroups are dealt round-robin over the 8 XCDs: give each XCD one CONTIGUOUS run of tiles (a z-slab of the
+  // volume), so that the halo rows neighbouring tiles share are served by that XCD's L2 instead of being fetched again
+  const int bx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int cidx = bx / a.tiles_per_cls;
   const ClassInfo ci = a.cls[cidx];
-  int t = blockIdx.x % a.tiles_per_cls;
+  int t = bx % a.tiles_per_cls;
   const int tile_in_n = t % (a.tz * a.ty * a.tx);
   const int txi = t % a.tx; t /= a.tx;
   const int tyi = t % a.ty; t /= a.ty;
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
   float s_sum = 0.f, s_sq = 0.f;
   if (a.ksplit > 1) {
     if (colact) {
-      float* wsb = a.ws + ((long long)blockIdx.z * gridDim.x + blockIdx.x) * MT * a.Np + col;
+      float* wsb = a.ws + ((long long)blockIdx.z * gridDim.x + bx) * MT * a.Np + col;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll

@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
   float dbacc = 0.f;
 
-  const int t0 = blockIdx.x * a.tiles_per_split;
+  // slab index = blockIdx.x; the TILE RANGE of a slab follows the XCD-contiguous order, so the workgroups of one XCD
+  // sweep one contiguous part of the volume and re-read each other's halo rows from their own L2
+  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int t0 = sx * a.tiles_per_split;
   const int t1 = min(a.tiles, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
   for (int tile = t0; tile < t1; ++tile) {
@@ -409,7 +412,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WArgs a) {   // two 
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
   float dbsum = 0.f;
 
-  const int t0 = blockIdx.x * a.tiles_per_split;
+  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);     // see wgrad_f32_kernel: one part of the volume per XCD
+  const int t0 = sx * a.tiles_per_split;
   const int t1 = min(a.tiles, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
   // Software pipeline over the tiles of this workgroup: the global loads of tile i+1 (the whole D tile and the first
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float dbacc = 0.f;
-  const int t0 = blockIdx.x * a.tiles_per_split;
+  const int t0 = (int)xcd_contiguous_id(blockIdx.x, gridDim.x) * a.tiles_per_split;   // one part of the volume per XCD
   const int t1 = min(a.tiles, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
   for (int tile = t0; tile < t1; ++tile) {

@@ -435,7 +435,8 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
         self.plugin = get_plugin(self.plugin_name)(self.config).setup(model, device)
         self.plugins, self.streams = [self.plugin], [None]
         if self.lanes > 1:
-            self.streams = [torch.cuda.Stream(device=device)]
+            pool = ops.lane_streams(self.lanes, device)          # one hardware queue per lane
+            self.streams = [pool[0]]
             mcfg = get_config(self.config, "model", None)
             for lane in range(1, self.lanes):
                 twin = get_model(str(get_config(mcfg, "name", "unet")))(mcfg)
@@ -443,7 +444,7 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
                 p = get_plugin(self.plugin_name)(self.config)
                 p.lane = lane
                 self.plugins.append(p.setup(twin, device))
-                self.streams.append(torch.cuda.Stream(device=device))
+                self.streams.append(pool[lane])
 
     def _submit(self, lane: int, x1: torch.Tensor, y1: torch.Tensor) -> Dict[str, Any]:
         """Queue adaptation + scoring of one volume on the lane's stream; nothing here waits for the GPU."""

@@ -175,17 +175,23 @@ class EntropyMinimizationTTA:
         key = (tuple(x_cl.shape), x_cl.data_ptr(), None if present is None else tuple(present))
         g = self._graphs.get(key)
         if g is None:
-            # eager warm-up (allocates every buffer, sizes the workspace), then capture
-            side = torch.cuda.Stream(device=x_cl.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            # eager warm-up (allocates every buffer, sizes the workspace), then capture.  Both run on the CALLER's stream
+            # when that is not the default stream: a lane keeps its one stream (= its hardware queue, ops.lane_streams)
+            # for everything, no helper streams are created per capture
+            cur = torch.cuda.current_stream(x_cl.device)
+            on_default = cur == torch.cuda.default_stream(x_cl.device)
+            work = ops.helper_stream(x_cl.device) if on_default else cur
+            if on_default:
+                work.wait_stream(cur)
+            with torch.cuda.stream(work):
                 self._step_launches(x_cl, present)
-            torch.cuda.current_stream().wait_stream(side)
+            if on_default:
+                cur.wait_stream(work)
             torch.cuda.synchronize()
             try:
                 ops.Workspace.frozen = True
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, stream=work):
                     self._step_launches(x_cl, present)
             except Exception as exc:  # capture is an optimisation: the eager launches are the same kernels
                 warnings.warn(f"hipGraph capture failed ({exc}); running the step eagerly")

@@ -9,21 +9,18 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per lane (see bench.py)
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_tta_amd import _lib  # noqa: E402
 
 KEYS = {"splitk_below": 2, "splitk_target": 3, "wgrad_workgroups": 4, "wgrad_thin_slabs": 5}
-SETTINGS = [
-    dict(splitk_below=192, splitk_target=256, wgrad_workgroups=256, wgrad_thin_slabs=256),     # defaults
-    dict(splitk_below=384, splitk_target=512, wgrad_workgroups=512, wgrad_thin_slabs=512),     # single-volume optimum
-    dict(splitk_below=384, splitk_target=512, wgrad_workgroups=256, wgrad_thin_slabs=256),
-    dict(splitk_below=192, splitk_target=256, wgrad_workgroups=512, wgrad_thin_slabs=512),
-    dict(splitk_below=96, splitk_target=128, wgrad_workgroups=256, wgrad_thin_slabs=256),
-    dict(splitk_below=192, splitk_target=256, wgrad_workgroups=128, wgrad_thin_slabs=256),
-    dict(splitk_below=192, splitk_target=256, wgrad_workgroups=256, wgrad_thin_slabs=512),
-]
+SETTINGS = [dict(splitk_below=b, splitk_target=t, wgrad_workgroups=w, wgrad_thin_slabs=th)
+            for (b, t) in ((192, 256), (96, 128), (48, 64)) for (w, th) in ((256, 256), (128, 128), (128, 256), (64, 128))]
+
+
+LANE_STREAMS = {}
 
 
 def run(setting, lanes, volumes):
@@ -40,7 +37,10 @@ def run(setting, lanes, volumes):
                              "method.precision=bf16"])
     torch.manual_seed(42)
     model = get_model("unet")(cfg["model"])
-    plugs, streams = [], []
+    plugs = []
+    if "pool" not in LANE_STREAMS:          # created and touched once, before any other stream: one hardware queue each
+        LANE_STREAMS["pool"] = ops.lane_streams(6, device)
+    streams = LANE_STREAMS["pool"][:lanes]
     for lane in range(lanes):
         m = model if lane == 0 else get_model("unet")(cfg["model"])
         if lane:
@@ -48,7 +48,6 @@ def run(setting, lanes, volumes):
         p = get_plugin("entmin_tta")(cfg)
         p.lane = lane
         plugs.append(p.setup(m, device))
-        streams.append(torch.cuda.Stream(device=device))
     vols = []
     for i in range(volumes + lanes):
         v = synth_volume(i, 4, (128, 128, 128), 3)
@@ -77,13 +76,14 @@ def run(setting, lanes, volumes):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--lanes", type=int, nargs="+", default=[2])
     ap.add_argument("--volumes", type=int, default=8)
     ap.add_argument("--repeat", type=int, default=2)
     a = ap.parse_args()
     for rep in range(a.repeat):
-        for s in SETTINGS:
-            print(f"pass {rep} lanes {a.lanes} {s}: {run(s, a.lanes, a.volumes):.2f} volumes/s", flush=True)
+        for lanes in a.lanes:
+            for s in SETTINGS:
+                print(f"pass {rep} lanes {lanes} {s}: {run(s, lanes, max(a.volumes, 2 * lanes)):.2f} volumes/s", flush=True)
 
 
 if __name__ == "__main__":

@@ -141,7 +141,7 @@ def test_deepfusion_missing_modality_forward_and_tta():
     assert e_hip <= max(4e-3, 3 * e_ref), (e_hip, e_ref)
 
 
-@pytest.mark.parametrize("over,shape", [({}, (2, 4, 16, 16, 16)), ({"num_modalities": 2, "num_classes": 1}, (1, 2, 16, 16, 32))])
+@pytest.mark.parametrize("over,shape", [({}, (2, 4, 32, 32, 32)), ({"num_modalities": 2, "num_classes": 1}, (1, 2, 32, 32, 64))])
 def test_auxiliary_outputs_match_the_oracle(over, shape):
     """``forward(..., return_intermediate_features=True)`` and ``return_domain_logits=True`` (reference
     src/models/unet_multimodal_midfusion.py:204-209,258-265): same tuple structure, shared / specific global means
