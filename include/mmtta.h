@@ -81,18 +81,23 @@ int mmtta_abi_version(void);
  * launch ONLY their main kernel, so that two events around the call time exactly the kernel rocprofv3 names.
  * Results of such calls are not valid outputs.  Returns the previous value. */
 #define MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY 1
-/* Launch-geometry knobs, read when a convolution is PLANNED (mmtta_conv_plan / the first run of a layer); they change
- * how work is split, never the result beyond fp32 summation order.  Defaults are the measured optimum for two volumes in
- * flight per GPU; `scripts/sweep_tuning.py` sweeps them inside one process.
+/* Launch-geometry knobs, read when a convolution is PLANNED or LAUNCHED; they change how work is split, never the
+ * result beyond fp32 summation order.  A caller that caches mmtta_conv_plan results (workspace size, statistics rows)
+ * must drop them after changing a knob and set knobs before capturing launches into a graph (the Python layer does
+ * both: ops.set_option).  Defaults are the measured optimum for four volumes in flight per GPU (DESIGN.md section
+ * 3.2); `scripts/sweep_tuning.py` sweeps them inside one process.
  *   SPLITK_BELOW / SPLITK_TARGET  implicit GEMM: split the reduction when a launch has fewer workgroups than BELOW, up
- *                                 to about TARGET workgroups                                   (defaults 192 / 256)
- *   WGRAD_WORKGROUPS              workgroups (slabs x channel blocks) of a weight-gradient launch      (default 256)
+ *                                 to about TARGET workgroups                                    (defaults 96 / 128)
+ *   WGRAD_WORKGROUPS              workgroups (slabs x channel blocks) of a weight-gradient launch      (default 128)
  *   WGRAD_THIN_SLABS              slabs of the thin-layer weight gradient (<= 4 channels on one side)   (default 256)
  * Returns the previous value, MMTTA_ERR_INVALID for an unknown key or a value < 1. */
 #define MMTTA_OPT_SPLITK_BELOW 2
 #define MMTTA_OPT_SPLITK_TARGET 3
 #define MMTTA_OPT_WGRAD_WORKGROUPS 4
 #define MMTTA_OPT_WGRAD_THIN_SLABS 5
+/* 1 (default): the implicit GEMM requests the input box of stage k+1 while the matrix cores work on stage k (bf16
+ * mode, full 3x3x3 stride-1 stages); 0: load -> barrier -> MFMA -> barrier as in round 1.  Same results bit for bit. */
+#define MMTTA_OPT_IGEMM_PIPELINE 6
 int mmtta_set_option(int key, int value);
 
 /* ------------------------------------------------------------------ layout (boundary) ---- */

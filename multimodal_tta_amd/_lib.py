@@ -146,6 +146,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.mmtta_abi_version() != 1:
         raise MmttaError("libmmtta.so ABI version mismatch")
+    if os.environ.get("MMTTA_NO_PIPE", "0") == "1":      # A/B aid: MMTTA_OPT_IGEMM_PIPELINE off (same results bit for bit)
+        lib.mmtta_set_option(6, 0)
     _lib = lib
     return lib
 

@@ -11,6 +11,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 int g_profile_main_only = 0;
+int g_igemm_pipeline = 1;
 // split-K below / target, weight-gradient workgroups, thin-layer slabs.  Swept with the lanes bound to their own hardware
 // queues (profiles/r02_tuning_sweep.txt): four volumes in flight want half the splitting two did (96/128, 128 slabs)
 int g_tune[4] = {96, 128, 128, 256};
@@ -20,6 +21,11 @@ extern "C" int mmtta_set_option(int key, int value) {
   if (key == MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY) {
     const int prev = mmtta::g_profile_main_only;
     mmtta::g_profile_main_only = value;
+    return prev;
+  }
+  if (key == MMTTA_OPT_IGEMM_PIPELINE) {
+    const int prev = mmtta::g_igemm_pipeline;
+    mmtta::g_igemm_pipeline = value ? 1 : 0;
     return prev;
   }
   if (key >= MMTTA_OPT_SPLITK_BELOW && key <= MMTTA_OPT_WGRAD_THIN_SLABS) {

@@ -164,6 +164,7 @@ int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s);  // 
 
 // direct path for layers producing <= 4 channels (conv_direct.hip)
 extern int g_profile_main_only;     // api.hip: mmtta_set_option(MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY)
+extern int g_igemm_pipeline;        // api.hip: MMTTA_OPT_IGEMM_PIPELINE
 extern int g_tune[4];               // api.hip: launch-geometry knobs (MMTTA_OPT_SPLITK_BELOW ... MMTTA_OPT_WGRAD_THIN_SLABS)
 bool direct_applicable(const mmtta_conv_desc* d);
 int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);

@@ -75,6 +75,8 @@ struct GArgs {
   float* ws; int ksplit, stages_per_split, nstages;
   int tz, ty, tx;
   int vec4;
+  int pipeline;    // box-load software pipeline on (MMTTA_OPT_IGEMM_PIPELINE; default 1)
+  int coef_off;    // word offset of the coefficient table behind the LDS box image
   int ncls, tiles_per_cls;
   ClassInfo cls[8];
   int toff[27];   // box-relative voxel offset of each tap (int32 tables: read with SCALAR loads)
@@ -122,7 +124,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
 
   // workgroups are dealt round-robin over the 8 XCDs: give each XCD one CONTIGUOUS run of tiles (a z-slab of the
   // volume), so that the halo rows neighbouring tiles share are served by that XCD's L2 instead of being fetched again
-  const int bx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  // (the whole 3-D grid is renumbered, tile index fastest: the tiles that stream the SAME weight panel - same column
+  // group, same K split - then also share an XCD, which matters for the weight-bound 8^3 / 16^3 levels)
+  const unsigned lflat = xcd_contiguous_id(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                           gridDim.x * gridDim.y * gridDim.z);
+  const int bx = (int)(lflat % gridDim.x);
+  const int lby = (int)((lflat / gridDim.x) % gridDim.y), lbz = (int)(lflat / (gridDim.x * gridDim.y));
   const int cidx = bx / a.tiles_per_cls;
   const ClassInfo ci = a.cls[cidx];
   int t = bx % a.tiles_per_cls;
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
   const int LP = (BF && a.si == 1) ? LDS_PITCH_BF16 : BX;      // LDS x-row pitch in voxels
   const int iz0 = gz0 * a.si + ci.zmin, iy0 = gy0 * a.si + ci.ymin, ix0 = gx0 * a.si + ci.xmin;
 
-  const int colbase = (blockIdx.y * NB + cb) * 32;
+  const int colbase = (lby * NB + cb) * 32;
   const bool colact = colbase < a.Np;
 
   int rowaddr[MB];   // LDS word address of (row's voxel, channel h) inside the box
@@ -156,11 +163,63 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
 
-  const int ks0 = blockIdx.z * a.stages_per_split;
+  const int ks0 = lbz * a.stages_per_split;
   const int ks1 = min(a.nstages, ks0 + a.stages_per_split);
   const float* inb = a.in + (long long)n * a.isn;
 
+  // Software pipeline of the box loads (bf16, full 3x3x3 stride-1 stages): the first NPF items of a thread for stage
+  // ks+1 are requested DURING the MFMA phase of stage ks - after its last weight-fragment request, because loads return
+  // in order and a weight fetch issued behind them would wait for them - and converted / written to LDS after the
+  // barrier that ends the phase.  The HBM / L2 round trip of the box then hides behind 2/3 of the MFMAs instead of
+  // opening every stage (measured before: 35 % of a workgroup's life was the load burst).
+  constexpr int PCV8 = BF ? KCI / 8 : 1;
+  constexpr int PSTEP = 256 / PCV8;
+  constexpr int PNI = ((TZ + 2) * (TY + 2) * (TX + 2) + PSTEP - 1) / PSTEP;    // items per thread of the stride-1 3x3x3 box
+  // register budget (two workgroups per CU: 256 per lane): the 16-channel stages have ~34 registers to spare, the
+  // 32-channel stages none (their two weight-fragment sets take 80) - those keep the unpipelined order
+  constexpr int NPF = (BF && KCI == 16) ? (PNI < 3 ? PNI : 3) : 0;           // of which prefetched (8 registers each)
+  constexpr int NPFA = NPF > 0 ? NPF : 1;
+  float4 pfa[NPFA], pfb[NPFA];
+  unsigned pok = 0u;
+  const bool pipe = NPF > 0 && a.vec4 && a.pipeline && ci.ntaps == 27 && a.si == 1 && (a.Ci % KCI) == 0 && colact;
+  // norm-on-load coefficients of every channel this workgroup will stage, once, in LDS behind the box image (a
+  // per-stage fetch from global memory would be an exposed round trip in front of every commit)
+  float* coef = lds + a.coef_off;
+  const int cbase = ks0 * KCI, nch = (ks1 - ks0) * KCI;
+  if (pipe) {
+    for (int cch = tid; cch < nch; cch += 256) {
+      float sc1, sh1;
+      nl_coeff(a.tin, n, a.Ci, min(cbase + cch, a.Ci - 1), sc1, sh1);
+      coef[cch] = sc1;
+      coef[nch + cch] = sh1;
+    }
+  }
+  auto issue = [&](int ks) {
+    const int c = ks * KCI + (tid % PCV8) * 8;
+    pok = 0u;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int bv = tid / PCV8 + i * PSTEP;
+      const int bvc = min(bv, boxvox - 1);
+      const int bz = (int)__umulhi((unsigned)bvc, ci.mBXY), brem = bvc - bz * ci.BXY;
+      const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
+      const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+      const bool ok = bv < boxvox && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+      pok |= (ok ? 1u : 0u) << i;
+      // unconditional loads from clamped (always valid) addresses, masked when they are committed
+      const float* src = inb + min(max(iz, 0), a.Di - 1) * a.isd + min(max(iy, 0), a.Hi - 1) * a.ish +
+                         min(max(ix, 0), a.Wi - 1) * a.isw + c;
+      pfa[i] = *reinterpret_cast<const float4*>(src);
+      pfb[i] = *reinterpret_cast<const float4*>(src + 4);
+    }
+  };
+  if (pipe && ks0 < ks1) {
+    issue(ks0);
+    __syncthreads();      // coefficients visible
+  }
+
   for (int ks = ks0; ks < ks1; ++ks) {
+    const int stage = ks;
     const int c0 = ks * KCI;
     // the first group of weight fragments of this stage is requested before the staging pass, so its L2 round trip
     // hides behind the box loads instead of opening the MFMA phase (full 27-tap stages of the bf16 path only)
@@ -187,14 +246,44 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
         const int cv = tid % CV8;          // 256 % CV8 == 0
         const int c = c0 + cv * 8;
         float sc[8], sh[8];
-        nl_coeff_vec<8>(a.tin, n, a.Ci, c, sc, sh);
+        constexpr int STEP = 256 / CV8;
+        int first_item = 0;
+        if (pipe) {
+          {
+            const float4* cq = reinterpret_cast<const float4*>(coef + (c - cbase));
+            const float4* hq = reinterpret_cast<const float4*>(coef + nch + (c - cbase));
+            const float4 s0 = cq[0], s1 = cq[1], h0 = hq[0], h1 = hq[1];
+            sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+            sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+          }
+#pragma unroll
+          for (int i = 0; i < NPF; ++i) {
+            const int bv = tid / CV8 + i * STEP;
+            if (bv < boxvox) {
+              uint4 pk = make_uint4(0u, 0u, 0u, 0u);
+              if ((pok >> i) & 1u) {
+                const float xs[8] = {pfa[i].x, pfa[i].y, pfa[i].z, pfa[i].w, pfb[i].x, pfb[i].y, pfb[i].z, pfb[i].w};
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = nl_apply(xs[j], sc[j], sh[j], a.tin.relu);
+                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+              }
+              const int bz = (int)__umulhi((unsigned)bv, ci.mBXY), brem = bv - bz * ci.BXY;
+              const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
+              *reinterpret_cast<uint4*>(lh + ((bz * BY + by) * LP + bx) * VS + cv * 8) = pk;
+            }
+          }
+          first_item = NPF;
+        } else {
+          nl_coeff_vec<8>(a.tin, n, a.Ci, c, sc, sh);
+        }
         // U items per trip: all their global loads are issued before the first use (one exposed latency per
         // trip instead of one per item)
-        constexpr int STEP = 256 / CV8;
         // all of a thread's items in as few trips as the register budget allows: one exposed memory latency per trip
         constexpr int U = 4;
         const bool tail = (a.Ci & 7) != 0;       // only then can lanes beyond Ci hold uninitialised padding
-        for (int bv0 = tid / CV8; bv0 < boxvox; bv0 += U * STEP) {
+        for (int bv0 = tid / CV8 + first_item * STEP; bv0 < boxvox; bv0 += U * STEP) {
           float4 x0[U], x1[U];
           bool ok[U];
 #pragma unroll
@@ -345,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
                 }
               }
             }
+            if (g == NG - 2 && pipe && stage + 1 < ks1) issue(stage + 1);     // behind the stage's last weight request
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < G; ++t) {
@@ -481,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(GArgs a) {   // two workg
   float s_sum = 0.f, s_sq = 0.f;
   if (a.ksplit > 1) {
     if (colact) {
-      float* wsb = a.ws + ((long long)blockIdx.z * gridDim.x + bx) * MT * a.Np + col;
+      float* wsb = a.ws + ((long long)lbz * gridDim.x + bx) * MT * a.Np + col;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -969,6 +1059,9 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
     if (need > lds) lds = need;
   }
   if (lds < 4 * 2 * 32 * sizeof(float)) lds = 4 * 2 * 32 * sizeof(float);
+  lds = (lds + 15) / 16 * 16;
+  a.coef_off = (int)(lds / sizeof(float));
+  if (BF && KCI == 16) lds += (size_t)2 * a.stages_per_split * KCI * sizeof(float);     // scale | shift of the staged channels
   MMTTA_CHECK(lds <= 160 * 1024, MMTTA_ERR_UNSUPPORTED, "conv: LDS box of %zu bytes exceeds 160 KiB", lds);
   auto kern = igemm_kernel<NB, MB, TZ, TY, TX, KCI, BF>;
   static bool attr_set = false;
@@ -1172,6 +1265,7 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   a.tz = g.tz; a.ty = g.ty; a.tx = g.tx;
   const bool al = (((uintptr_t)x->ptr) % 16 == 0) && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0;
   a.vec4 = al ? 1 : 0;
+  a.pipeline = g_igemm_pipeline;
   Taps ht[8];
   a.ncls = g.classes ? 8 : 1;
   a.tiles_per_cls = g.tiles_per_n * x->n;

@@ -254,7 +254,8 @@ class ConvolutionBlock(Block):
         return y, nl
 
     def bwd(self, dT: torch.Tensor, dx: Optional[torch.Tensor], accumulate: bool = False, need_dx: bool = True,
-            grad_accumulate: bool = False) -> None:
+            grad_accumulate: bool = False, add: Optional[torch.Tensor] = None) -> None:
+        """``add``: another gradient term of the block's input, summed into dx by the input-gradient epilogue."""
         x, x_nl, y, nl = self.saved
         dy = dT
         if self.norm is not None:
@@ -262,7 +263,7 @@ class ConvolutionBlock(Block):
             self.norm.backward(self.rt.pool, self.key, dT, y, nl, dy, self.rt.training, grad_accumulate)
         self.conv.wgrad(x, x_nl, dy, grad_accumulate)
         if need_dx:
-            self.conv.op.dgrad(dy, dx, accumulate)
+            self.conv.op.dgrad(dy, dx, accumulate, add=add)
 
 
 class ResidualUnitBlock(Block):
@@ -310,13 +311,13 @@ class ResidualUnitBlock(Block):
                 unit.bwd(d, dprev, accumulate=False, need_dx=True, grad_accumulate=grad_accumulate)
                 d = dprev
             else:
-                unit.bwd(d, dx, accumulate=accumulate, need_dx=need_dx, grad_accumulate=grad_accumulate)
+                # identity residual: its gradient term (dout itself) rides in the epilogue of this input gradient
+                unit.bwd(d, dx, accumulate=accumulate, need_dx=need_dx, grad_accumulate=grad_accumulate,
+                         add=dout if (self.residual is None and need_dx) else None)
         if self.residual is not None:
             self.residual.wgrad(x, x_nl, dout, grad_accumulate)
             if need_dx:
                 self.residual.op.dgrad(dout, dx, accumulate=True)
-        elif need_dx:
-            ops.lincomb([dout], [1.0], dx, accumulate=True)
 
 
 # ----------------------------------------------------------------------------- runtime base

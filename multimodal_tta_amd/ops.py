@@ -352,8 +352,10 @@ class ConvOp:
                 add_nl: Optional[NL] = None, accumulate: bool = False) -> None:
         self._run(self.d_fwd, self.packed_fwd, x, x_nl, bias, y, accumulate, stats, add, add_nl)
 
-    def dgrad(self, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool = False) -> None:
-        self._run(self.d_dgrad, self.packed_dgrad, dy, None, None, dx, accumulate, None, None, None)
+    def dgrad(self, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool = False, add: Optional[torch.Tensor] = None) -> None:
+        """dx (+)= conv^T(dy) [+ add]: ``add`` is a second gradient term of the same tensor (the identity branch of a
+        ResidualUnit) summed in the epilogue instead of by a separate pass over dx."""
+        self._run(self.d_dgrad, self.packed_dgrad, dy, None, None, dx, accumulate, None, add, None)
 
     def wgrad(self, x: torch.Tensor, x_nl: Optional[NL], dy: torch.Tensor, dw: torch.Tensor,
               db: Optional[torch.Tensor], accumulate: bool = False) -> None:
