@@ -98,6 +98,21 @@ int mmtta_abi_version(void);
 /* 1 (default): the implicit GEMM requests the input box of stage k+1 while the matrix cores work on stage k (bf16
  * mode, full 3x3x3 stride-1 stages); 0: load -> barrier -> MFMA -> barrier as in round 1.  Same results bit for bit. */
 #define MMTTA_OPT_IGEMM_PIPELINE 6
+/* Producer / consumer form of the bf16-operand implicit GEMM (512-thread workgroups: four loader waves and four MFMA
+ * waves, double-buffered LDS, persistent over a contiguous range of tiles).  0 (default): off; 1: the wide small-grid
+ * configurations only; 2: every bf16 configuration.  Same results as the default kernel up to the summation order of
+ * the statistics rows.  Measured round 2: 5-15 % faster per launch on the 8^3 / 16^3 levels
+ * when a lane runs alone, but 4 % SLOWER for four lanes (a 512-thread, 256-register workgroup owns its CU), and 2x
+ * slower on the 64^3 layers - kept as a measured, tested alternative, not the default.  It changes the number of
+ * statistics rows a convolution writes (mmtta_conv_plan reports it): set before planning.
+ * IGEMM_WS_WORKGROUPS: workgroups of such a launch (default 256 = one per CU). */
+#define MMTTA_OPT_IGEMM_PRODUCER_CONSUMER 7
+/* 1 (default): implicit-GEMM epilogues store 16 bytes per lane through an LDS transposition (same values; the
+ * statistics rows sum in a different order); 0: four-byte stores straight from the accumulators (round 1). */
+#define MMTTA_OPT_EPILOGUE_VEC16 9
+/* 1: the 32-output-channel stride-1 layers (64^3 level) use the lean 4x8x8 tile at four workgroups per CU. */
+#define MMTTA_OPT_IGEMM_LEAN 10
+#define MMTTA_OPT_IGEMM_WS_WORKGROUPS 8
 int mmtta_set_option(int key, int value);
 
 /* ------------------------------------------------------------------ layout (boundary) ---- */

@@ -148,6 +148,12 @@ def load() -> C.CDLL:
         raise MmttaError("libmmtta.so ABI version mismatch")
     if os.environ.get("MMTTA_NO_PIPE", "0") == "1":      # A/B aid: MMTTA_OPT_IGEMM_PIPELINE off (same results bit for bit)
         lib.mmtta_set_option(6, 0)
+    if os.environ.get("MMTTA_NO_EPIVEC", "0") == "1":    # A/B aid: MMTTA_OPT_EPILOGUE_VEC16 off
+        lib.mmtta_set_option(9, 0)
+    if "MMTTA_LEAN" in os.environ:                       # A/B aid: MMTTA_OPT_IGEMM_LEAN
+        lib.mmtta_set_option(10, int(os.environ["MMTTA_LEAN"]))
+    if "MMTTA_WS" in os.environ:                         # A/B aid: MMTTA_OPT_IGEMM_PRODUCER_CONSUMER = 0 / 1 / 2
+        lib.mmtta_set_option(7, int(os.environ["MMTTA_WS"]))
     _lib = lib
     return lib
 

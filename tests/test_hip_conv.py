@@ -293,3 +293,41 @@ def test_batched_pack_matches_per_layer_pack():
             assert torch.equal(op.packed_fwd, pf), f"fwd image differs: {(cin, cout, k, s, tr)} dtype {dtype}"
             assert torch.equal(op.packed_dgrad, pd), f"dgrad image differs: {(cin, cout, k, s, tr)} dtype {dtype}"
 
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("case", [(32, 32, 3, 1, False, (1, 16, 16, 16)), (128, 136, 3, 1, False, (2, 4, 6, 8)),
+                                  (512, 512, 3, 1, False, (1, 4, 4, 4)), (768, 128, 3, 2, True, (1, 8, 8, 8)),
+                                  (64, 128, 3, 2, False, (1, 5, 6, 7)), (33, 32, 3, 1, False, (1, 8, 8, 16))])
+def test_producer_consumer_igemm_matches_the_default_kernel(case, mode):
+    """MMTTA_OPT_IGEMM_PRODUCER_CONSUMER (off by default: DESIGN.md section 3.2): the loader-wave / MFMA-wave form of the
+    bf16 implicit GEMM gives the default kernel's forward and input-gradient results bit for bit (same products, same
+    k order); its per-wave statistics rows add up to the same per-(n,c) sums."""
+    from multimodal_tta_amd import ops
+
+    cin, cout, k, stride, transposed, shape = case
+    n, d, h, w = shape
+    torch.manual_seed(3)
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = torch.randn(n, cin, d, h, w)
+    outs = {}
+    for ws in (0, mode):
+        prev = ops.set_option(7, ws)
+        try:
+            op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+            op.pack(mod.weight.detach().cuda().contiguous())
+            x_cl = cl(x)
+            y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda")
+            rows = op.stats_rows(x_cl, y_cl)
+            stats = torch.zeros((rows, 2, cout), device="cuda")
+            op.forward(x_cl, None, mod.bias.detach().cuda(), y_cl, stats=stats)
+            gy_cl = cl(torch.randn(n, cout, *y_cl.shape[1:4], generator=torch.Generator().manual_seed(5)))
+            dx_cl = ops.new_cl(n, d, h, w, cin, "cuda")
+            op.dgrad(gy_cl, dx_cl)
+            torch.cuda.synchronize()
+            outs[ws] = (y_cl.clone(), dx_cl.clone(), stats.view(n, rows // n, 2, cout).double().sum(1).cpu())
+        finally:
+            ops.set_option(7, prev)
+    assert torch.equal(outs[0][0], outs[mode][0]), "forward differs"
+    assert torch.equal(outs[0][1], outs[mode][1]), "input gradient differs"
+    assert torch.allclose(outs[0][2], outs[mode][2], rtol=1e-5, atol=1e-4)
