@@ -67,6 +67,8 @@ def parse():
                     help="volumes adapted concurrently per GPU, each with its own weights, buffers, graph and stream "
                          "(episodic adaptation has no cross-volume state; one volume alone leaves most CUs waiting)")
     ap.add_argument("--side-streams", type=int, default=None, help="side streams for the weight gradients (default: config)")
+    ap.add_argument("--storage", default=None, choices=["bf16", "fp32"],
+                    help="bf16 precision: storage of the wide forward activations (default: the method config, bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the one-lane and fp32-mode runs of the same workload")
@@ -84,6 +86,8 @@ def build_cfg(args):
         ov += ["method.use_graph=false"]
     if getattr(args, "side_streams", None) is not None:
         ov += [f"method.side_streams={args.side_streams}"]
+    if getattr(args, "storage", None) or os.environ.get("MMTTA_STORAGE"):
+        ov += [f"method.storage={getattr(args, 'storage', None) or os.environ['MMTTA_STORAGE']}"]
     cfg = compose(overrides=ov)
     shape = args.shape or ([128, 128, 128] if args.task == "brats" else [48, 144, 144])
     cfg["dataset"]["synthetic"]["shape"] = list(shape)

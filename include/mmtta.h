@@ -112,6 +112,10 @@ int mmtta_abi_version(void);
 #define MMTTA_OPT_EPILOGUE_VEC16 9
 /* 1: the 32-output-channel stride-1 layers (64^3 level) use the lean 4x8x8 tile at four workgroups per CU. */
 #define MMTTA_OPT_IGEMM_LEAN 10
+/* The bf16-operand 27-tap weight gradient can stage its operands with 16-byte (bf16 storage: 8-byte) loads, four
+ * channels per thread: 1 (default) when an operand is bf16-stored, 2 always, 0 never (one channel per thread, element
+ * loads, next tile's rows prefetched - the faster loader for fp32-stored operands).  Bit-identical results. */
+#define MMTTA_OPT_WGRAD_VECTOR_STAGING 11
 #define MMTTA_OPT_IGEMM_WS_WORKGROUPS 8
 int mmtta_set_option(int key, int value);
 

@@ -150,6 +150,8 @@ def load() -> C.CDLL:
         lib.mmtta_set_option(6, 0)
     if os.environ.get("MMTTA_NO_EPIVEC", "0") == "1":    # A/B aid: MMTTA_OPT_EPILOGUE_VEC16 off
         lib.mmtta_set_option(9, 0)
+    if "MMTTA_WGVEC" in os.environ:                      # A/B aid: MMTTA_OPT_WGRAD_VECTOR_STAGING
+        lib.mmtta_set_option(11, int(os.environ["MMTTA_WGVEC"]))
     if "MMTTA_LEAN" in os.environ:                       # A/B aid: MMTTA_OPT_IGEMM_LEAN
         lib.mmtta_set_option(10, int(os.environ["MMTTA_LEAN"]))
     if "MMTTA_WS" in os.environ:                         # A/B aid: MMTTA_OPT_IGEMM_PRODUCER_CONSUMER = 0 / 1 / 2
@@ -180,15 +182,16 @@ TENSOR_OWNS_PAD = 1   # include/mmtta.h MMTTA_TENSOR_OWNS_PAD
 
 
 def desc_cl(t: torch.Tensor) -> Tensor:
-    """Descriptor of a channels-last activation view: torch shape [N, D, H, W, C], stride(C) == 1."""
-    if t.dim() != 5 or t.dtype != torch.float32 or not t.is_cuda:
-        raise MmttaError(f"expected a CUDA float32 [N,D,H,W,C] view, got {tuple(t.shape)} {t.dtype} {t.device}")
+    """Descriptor of a channels-last activation view: torch shape [N, D, H, W, C], stride(C) == 1.  fp32, or bf16 for the
+    forward activations of `bf16` precision (storage type travels in the descriptor; strides are in elements)."""
+    if t.dim() != 5 or t.dtype not in (torch.float32, torch.bfloat16) or not t.is_cuda:
+        raise MmttaError(f"expected a CUDA float32 / bfloat16 [N,D,H,W,C] view, got {tuple(t.shape)} {t.dtype} {t.device}")
     n, d, h, w, c = t.shape
     sn, sd, sh, sw, sc = t.stride()
     if sc != 1 and c != 1:
         raise MmttaError("activation views must have unit stride along C")
     flags = TENSOR_OWNS_PAD if getattr(t, "_mmtta_owns_pad", False) else 0
-    return Tensor(t.data_ptr(), n, c, d, h, w, sn, 1, sd, sh, sw, F32, flags)
+    return Tensor(t.data_ptr(), n, c, d, h, w, sn, 1, sd, sh, sw, BF16 if t.dtype == torch.bfloat16 else F32, flags)
 
 
 def desc_ncdhw(t: torch.Tensor) -> Tensor:

@@ -17,6 +17,7 @@ int g_ws_workgroups = 256;
 void* g_ws_debug = nullptr;
 int g_epilogue_vec = 1;
 int g_igemm_lean = 0;
+int g_wgrad_vec = 1;
 // split-K below / target, weight-gradient workgroups, thin-layer slabs.  Swept with the lanes bound to their own hardware
 // queues (profiles/r02_tuning_sweep.txt): four volumes in flight want half the splitting two did (96/128, 128 slabs)
 int g_tune[4] = {96, 128, 128, 256};
@@ -37,6 +38,11 @@ extern "C" int mmtta_set_option(int key, int value) {
     if (value < 1) return MMTTA_ERR_INVALID;
     const int prev = mmtta::g_ws_workgroups;
     mmtta::g_ws_workgroups = value;
+    return prev;
+  }
+  if (key == MMTTA_OPT_WGRAD_VECTOR_STAGING) {
+    const int prev = mmtta::g_wgrad_vec;
+    mmtta::g_wgrad_vec = value < 0 ? 0 : (value > 2 ? 2 : value);
     return prev;
   }
   if (key == MMTTA_OPT_IGEMM_LEAN) {

@@ -31,18 +31,97 @@ inline int launch_status(const char* what) {
 
 inline bool is_cl(const mmtta_tensor* t) { return t->sc == 1 || t->c == 1; }
 
-// Device-side copy of a tensor view (float data).
+inline bool is_f32(const mmtta_tensor* t) { return t->dtype == MMTTA_F32; }
+inline bool is_bf16(const mmtta_tensor* t) { return t->dtype == MMTTA_BF16; }
+
+// ---- storage-type helpers.  In `bf16` precision the forward activations (raw conv outputs, residual-unit outputs,
+// concat buffers) are STORED as bf16 (what torch autocast does); gradients, logits, statistics and weights stay fp32.
+// A tensor's base pointer is carried as `float*` either way; `bf` says the elements are 2 bytes wide, offsets are in
+// ELEMENTS.  4 consecutive channels = one 8-byte (bf16) or 16-byte (fp32) access.
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned int h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ unsigned int f32x2_to_bf16x2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v;
+  v[0] = (__bf16)lo;   // v_cvt_pk_bf16_f32: round to nearest even, NaN preserved
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ float4 ld4_any(const float* base, long long eoff, int bf) {
+  if (bf) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + eoff);
+    return make_float4(bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu),
+                       bf16_bits_to_f32(u.y >> 16));
+  }
+  return *reinterpret_cast<const float4*>(base + eoff);
+}
+__device__ __forceinline__ void st4_any(float* base, long long eoff, float4 v, int bf) {
+  if (bf) {
+    uint2 u;
+    u.x = f32x2_to_bf16x2(v.x, v.y);
+    u.y = f32x2_to_bf16x2(v.z, v.w);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + eoff) = u;
+  } else {
+    *reinterpret_cast<float4*>(base + eoff) = v;
+  }
+}
+__device__ __forceinline__ float ld1_any(const float* base, long long eoff, int bf) {
+  if (bf) return bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(base)[eoff]);
+  return base[eoff];
+}
+__device__ __forceinline__ void st1_any(float* base, long long eoff, float v, int bf) {
+  if (bf) reinterpret_cast<unsigned short*>(base)[eoff] = (unsigned short)(f32x2_to_bf16x2(v, 0.f) & 0xffffu);
+  else base[eoff] = v;
+}
+// 8 consecutive channels: two 16-byte loads (fp32) or one (bf16)
+__device__ __forceinline__ void ld8_any(const float* base, long long eoff, int bf, float4& lo, float4& hi) {
+  if (bf) {
+    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + eoff);
+    lo = make_float4(bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu),
+                     bf16_bits_to_f32(u.y >> 16));
+    hi = make_float4(bf16_bits_to_f32(u.z & 0xffffu), bf16_bits_to_f32(u.z >> 16), bf16_bits_to_f32(u.w & 0xffffu),
+                     bf16_bits_to_f32(u.w >> 16));
+  } else {
+    lo = *reinterpret_cast<const float4*>(base + eoff);
+    hi = *reinterpret_cast<const float4*>(base + eoff + 4);
+  }
+}
+
+// Compile-time forms.  A run-time `bf` test around a load inside an unrolled loop makes hipcc branch around every
+// load and wait for it at the end of its branch (measured: the whole adaptation 25 % slower with run-time tests, for
+// fp32 AND bf16 storage), so hot loops are instantiated per storage type and selected by ONE wave-uniform branch outside:
+//   MMTTA_BF_DISPATCH(flag, NAME, { ... uses `constexpr bool NAME` ... })
+template <bool BF> __device__ __forceinline__ float4 ld4_t(const float* base, long long eoff) { return ld4_any(base, eoff, BF ? 1 : 0); }
+template <bool BF> __device__ __forceinline__ float ld1_t(const float* base, long long eoff) { return ld1_any(base, eoff, BF ? 1 : 0); }
+template <bool BF> __device__ __forceinline__ void st4_t(float* base, long long eoff, float4 v) { st4_any(base, eoff, v, BF ? 1 : 0); }
+template <bool BF> __device__ __forceinline__ void st1_t(float* base, long long eoff, float v) { st1_any(base, eoff, v, BF ? 1 : 0); }
+template <bool BF> __device__ __forceinline__ void ld8_t(const float* base, long long eoff, float4& lo, float4& hi) {
+  ld8_any(base, eoff, BF ? 1 : 0, lo, hi);
+}
+#define MMTTA_BF_DISPATCH(flag, NAME, ...) \
+  do {                                      \
+    if (flag) {                             \
+      constexpr bool NAME = true;           \
+      __VA_ARGS__                           \
+    } else {                                \
+      constexpr bool NAME = false;          \
+      __VA_ARGS__                           \
+    }                                       \
+  } while (0)
+
+// Device-side copy of a tensor view (fp32 data, or bf16 data when `bf`: see the storage helpers above).
 struct TV {
   float* p;
   int n, c, d, h, w;
   long long sn, sc, sd, sh, sw;
   int flags;
+  int bf;
 };
 
 inline TV tv(const mmtta_tensor* t) {
   TV v;
   v.p = (float*)t->ptr;
   v.flags = t->flags;
+  v.bf = t->dtype == MMTTA_BF16 ? 1 : 0;
   v.n = t->n; v.c = t->c; v.d = t->d; v.h = t->h; v.w = t->w;
   v.sn = t->sn; v.sc = t->sc; v.sd = t->sd; v.sh = t->sh; v.sw = t->sw;
   return v;
@@ -167,6 +246,7 @@ extern int g_profile_main_only;     // api.hip: mmtta_set_option(MMTTA_OPT_PROFI
 extern int g_igemm_pipeline;        // api.hip: MMTTA_OPT_IGEMM_PIPELINE
 extern int g_igemm_ws;              // api.hip: MMTTA_OPT_IGEMM_PRODUCER_CONSUMER
 extern int g_ws_workgroups;         // api.hip: MMTTA_OPT_IGEMM_WS_WORKGROUPS
+extern int g_wgrad_vec;             // api.hip: MMTTA_OPT_WGRAD_VECTOR_STAGING
 extern int g_igemm_lean;            // api.hip: MMTTA_OPT_IGEMM_LEAN
 extern int g_epilogue_vec;          // api.hip: MMTTA_OPT_EPILOGUE_VEC16
 extern void* g_ws_debug;            // api.hip: mmtta_debug_set_buffer (phase stamps of the producer/consumer kernel)

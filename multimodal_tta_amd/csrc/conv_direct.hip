@@ -587,7 +587,7 @@ struct CArgs {
   TV out;
   const float* w; int Kp, Np;     // implicit-GEMM fp32 image [27][Kp][Np]
   const float* bias;
-  const float* add; long long asn, asd, ash, asw; NL tadd;
+  const float* add; long long asn, asd, ash, asw; NL tadd; int add_bf;
   int accumulate;
   float* stats; int tiles_per_n;
   int tz, ty, tx;
@@ -816,26 +816,37 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
   float ssum[NB], ssq[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) { ssum[nb] = 0.f; ssq[nb] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
-    const int oz = oz0 + wave, oy = oy0 + m / TX, ox = ox0 + m % TX;
-    const bool vok = oz < a.out.d && oy < a.out.h && ox < a.out.w;
-    const long long ooff = (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh + (long long)ox * a.out.sw;
-    const long long aoff = (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash + (long long)ox * a.asw;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int col = nb * 32 + r;
-      if (vok && col < N) {
+  MMTTA_BF_DISPATCH(a.out.bf, OBF, {
+_Pragma("unroll")
+    for (int i = 0; i < 16; ++i) {
+      const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
+      const int oz = oz0 + wave, oy = oy0 + m / TX, ox = ox0 + m % TX;
+      const bool vok = oz < a.out.d && oy < a.out.h && ox < a.out.w;
+      const long long ooff = (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh + (long long)ox * a.out.sw;
+      const long long aoff = (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash + (long long)ox * a.asw;
+_Pragma("unroll")
+      for (int nb = 0; nb < NB; ++nb) {
+        const int col = nb * 32 + r;
+        const bool live = vok && col < N;
         float val = acc[nb][i] + bias[nb];
-        if (a.add) val += nl_apply(a.add[aoff + col], asc[nb], ash[nb], a.tadd.relu);
-        float* op = a.out.p + ooff + col;
-        if (a.accumulate) val += *op;
-        *op = val;
-        ssum[nb] += val; ssq[nb] += val * val;
+        // fused add / accumulate operands share the output's storage type (host-checked)
+        if (a.add) val += nl_apply(live ? ld1_t<OBF>(a.add, aoff + col) : 0.f, asc[nb], ash[nb], a.tadd.relu);
+        if (a.accumulate && live) val += ld1_t<OBF>(a.out.p, ooff + col);
+        if constexpr (OBF) {
+          // bf16 rows: neighbouring channel lanes pair up, the even one stores both as one dword (a 2-byte store per
+          // lane is a partial-dword write: ~12x the time per byte of a full store)
+          const float other = __shfl_xor(val, 1, 64);
+          if (live && !(r & 1)) {
+            if (col + 1 < N) reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned short*>(a.out.p) + ooff + col)[0] = f32x2_to_bf16x2(val, other);
+            else st1_t<true>(a.out.p, ooff + col, val);
+          }
+        } else {
+          if (live) a.out.p[ooff + col] = val;
+        }
+        if (live) { ssum[nb] += val; ssq[nb] += val * val; }
       }
     }
-  }
+  });
   if (a.stats != nullptr) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -902,14 +913,21 @@ int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_n
   CArgs a;
   a.in = tv(x); a.tin = nl(x_norm); a.out = tv(y);
   a.w = (const float*)packed; a.Kp = Kp; a.Np = Np; a.bias = bias;
-  a.add = nullptr; a.asn = a.asd = a.ash = a.asw = 0; a.tadd = nl(nullptr);
+  a.add = nullptr; a.asn = a.asd = a.ash = a.asw = 0; a.tadd = nl(nullptr); a.add_bf = 0;
   if (epi && epi->add) {
     const mmtta_tensor* ad = epi->add;
     MMTTA_CHECK(ad->ptr && is_cl(ad) && ad->n == y->n && ad->c == y->c && ad->d == y->d && ad->h == y->h && ad->w == y->w,
                 MMTTA_ERR_INVALID, "conv: epilogue `add` must be channels-last with the shape of y");
     a.add = (const float*)ad->ptr; a.asn = ad->sn; a.asd = ad->sd; a.ash = ad->sh; a.asw = ad->sw;
     a.tadd = nl(&epi->add_norm);
+    a.add_bf = is_bf16(ad) ? 1 : 0;
   }
+  // the <= 4-channel gathered tensor is always fp32 (network input, gradient); the 32 / 64-channel result may be
+  // bf16-stored, on the matrix-core path only
+  MMTTA_CHECK(is_f32(x), MMTTA_ERR_UNSUPPORTED, "thin-K conv: the gathered tensor must be fp32-stored");
+  const bool mfma_path = d->dtype == MMTTA_BF16 && (x->c >= 2 || y->c > 32);
+  MMTTA_CHECK(mfma_path || (is_f32(y) && !a.add_bf), MMTTA_ERR_UNSUPPORTED, "thin-K conv (VALU path): fp32-stored tensors only");
+  MMTTA_CHECK(a.add == nullptr || (a.add_bf != 0) == is_bf16(y), MMTTA_ERR_UNSUPPORTED, "thin-K conv: the fused add must share the output's storage type");
   a.accumulate = accumulate; a.stats = stats;
   a.tz = (y->d + 3) / 4; a.ty = (y->h + 3) / 4; a.tx = (y->w + 7) / 8;
   a.tiles_per_n = a.tz * a.ty * a.tx;
@@ -1091,15 +1109,17 @@ __global__ __launch_bounds__(256) void upconv_mfma_kernel(DArgs a) {
     const int cg = tid % CG;
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (HAS_T) nl_coeff_vec<4>(a.tin, n, K, cg * 4, sc, sh);
-    const float* inb = a.in.p + (long long)n * a.in.sn + cg * 4;
+    const long long inbo = (long long)n * a.in.sn + cg * 4;      // element offset (the input may be bf16-stored)
     float4 raw[NIT];
-#pragma unroll
-    for (int q = 0; q < NIT; ++q) {
-      const int vs = min(tid / CG + q * (256 / CG), 4 * XV - 1);
-      const int row = vs / XV, xl = vs % XV;
-      const int iz = min(iz0 + (row >> 1), a.in.d - 1), iy = min(iy0 + (row & 1), a.in.h - 1), ix = min(ix0 + xl, a.in.w - 1);
-      raw[q] = *reinterpret_cast<const float4*>(inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw);
-    }
+    MMTTA_BF_DISPATCH(a.in.bf, INBF, {
+_Pragma("unroll")
+      for (int q = 0; q < NIT; ++q) {
+        const int vs = min(tid / CG + q * (256 / CG), 4 * XV - 1);
+        const int row = vs / XV, xl = vs % XV;
+        const int iz = min(iz0 + (row >> 1), a.in.d - 1), iy = min(iy0 + (row & 1), a.in.h - 1), ix = min(ix0 + xl, a.in.w - 1);
+        raw[q] = ld4_t<INBF>(a.in.p, inbo + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw);
+      }
+    });
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
       const int vs = tid / CG + q * (256 / CG);
@@ -1285,6 +1305,11 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   }
   const bool has_t = a.tin.mean != nullptr || a.tin.scale != nullptr;
   const int variant = direct_variant(d, x);
+  // bf16-stored operands: only the INPUT of the matrix-core up-convolution (the 64 / 32-channel concat buffer); the
+  // <= 4-channel results and every other direct variant work on fp32-stored tensors
+  MMTTA_CHECK(is_f32(y) && !(epi && epi->add && is_bf16(epi->add)), MMTTA_ERR_UNSUPPORTED, "direct conv: outputs are fp32-stored");
+  MMTTA_CHECK(is_f32(x) || (variant == 3 && d->dtype == MMTTA_BF16), MMTTA_ERR_UNSUPPORTED,
+              "direct conv: a bf16-stored input is supported by the matrix-core up-convolution only");
   if (variant == 1) {
     const size_t kl_lds = (size_t)T * a.K * 16 + 32 * sizeof(float);
     if (a.K == 64) { if (has_t) launch_klane<16, true>(a, y->n, kl_lds, stream); else launch_klane<16, false>(a, y->n, kl_lds, stream); }

@@ -74,6 +74,7 @@ struct GArgs {
   float* stats; int stats_rows_per_n;
   float* ws; int ksplit, stages_per_split, nstages;
   int tz, ty, tx;
+  int in_bf, out_bf, add_bf;   // storage of the three activation operands: 1 = bf16 elements (common.h storage helpers)
   int vec4;
   int ovec;        // 16-byte epilogue stores (out / add rows 16-byte aligned, Co % 4 == 0)
   int pipeline;    // box-load software pipeline on (MMTTA_OPT_IGEMM_PIPELINE; default 1)
@@ -112,7 +113,7 @@ constexpr int LDS_PITCH_BF16 = 12;   // x-row pitch (voxels) of the bf16 LDS ima
 // block (8 lanes cover a voxel row), and the fused add / accumulate operands are fetched 16 bytes per lane too.
 // `tr`: 32 x 36 floats of this wave.  Per-lane sums for the following norm: channels colbase + 4*(lane&7) + 0..3,
 // already added up over the 8 row lanes (valid in lanes 0-7).
-template <int TZ, int TY, int TX, int MB, bool PERM>
+template <int TZ, int TY, int TX, int MB, bool PERM, bool ABF>
 __device__ __forceinline__ void epilogue_vec16(const GArgs& a, const ClassInfo& ci, f32x16 (&acc)[MB], float* tr, int lane,
                                                int rowblock0, int colbase, bool colact, int n, int gz0, int gy0, int gx0,
                                                float (&ssum)[4], float (&ssq)[4]) {
@@ -132,8 +133,9 @@ __device__ __forceinline__ void epilogue_vec16(const GArgs& a, const ClassInfo& 
   if (a.add) nl_coeff_vec<4>(a.tadd, n, a.Co, colc, asc, ash);
 #pragma unroll
   for (int j = 0; j < 4; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-  const float* addb = a.add ? a.add + (long long)n * a.asn + colc : nullptr;
-  float* outb = a.out + (long long)n * a.osn + colc;
+  const float* addb = a.add;
+  float* outb = a.out;
+  const long long abase = (long long)n * a.asn + colc, obase = (long long)n * a.osn + colc;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -157,11 +159,11 @@ __device__ __forceinline__ void epilogue_vec16(const GArgs& a, const ClassInfo& 
     float4 addv[4], oldv[4];
     if (a.add) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) addv[k] = *reinterpret_cast<const float4*>(addb + aoff[k]);
+      for (int k = 0; k < 4; ++k) addv[k] = ld4_t<ABF>(addb, abase + aoff[k]);
     }
     if (a.accumulate) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) oldv[k] = *reinterpret_cast<const float4*>(outb + ooff[k]);
+      for (int k = 0; k < 4; ++k) oldv[k] = ld4_t<ABF>(outb, obase + ooff[k]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -173,7 +175,7 @@ __device__ __forceinline__ void epilogue_vec16(const GArgs& a, const ClassInfo& 
       }
       if (a.accumulate) { v[0] += oldv[k].x; v[1] += oldv[k].y; v[2] += oldv[k].z; v[3] += oldv[k].w; }
       if (ok[k]) {
-        if (!(a.pipeline & 2)) *reinterpret_cast<float4*>(outb + ooff[k]) = make_float4(v[0], v[1], v[2], v[3]);
+        if (!(a.pipeline & 2)) st4_t<ABF>(outb, obase + ooff[k], make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
       }
@@ -196,7 +198,9 @@ constexpr int EPI_TILE_FLOATS = 32 * 36;     // LDS words of one wave's transpos
 // (<= 256 registers), 4 for the lean two-block tile <1,2,4,8,8,16> of the 32-channel 64^3 layers (<= 128 registers,
 // smaller weight-fragment groups, no box prefetch): twice the resident waves to cover each other's load, LDS and
 // store latencies (MMTTA_OPT_IGEMM_LEAN).
-template <int NB, int MB, int TZ, int TY, int TX, int KCI, bool BF, int OCC = 2>
+// ABF: the three activation operands (input, output, fused add) are bf16-STORED (forward convolutions of bf16 precision);
+// false: all fp32 (every input-gradient launch, fp32 precision).  Compile-time: see MMTTA_BF_DISPATCH in common.h.
+template <int NB, int MB, int TZ, int TY, int TX, int KCI, bool BF, int OCC = 2, bool ABF = false>
 __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
   extern __shared__ float lds[];
   // LDS voxel stride: fp32: KCI+1 words (odd: the 32 rows of a fragment hit distinct banks);
@@ -254,7 +258,10 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
 
   const int ks0 = lbz * a.stages_per_split;
   const int ks1 = min(a.nstages, ks0 + a.stages_per_split);
-  const float* inb = a.in + (long long)n * a.isn;
+  // batch item base: element offsets are applied by the storage helpers (the pointer itself is never advanced, so the
+  // same code addresses 2-byte and 4-byte elements)
+  const float* inb = a.in;
+  const long long inoff = (long long)n * a.isn;
 
   // Software pipeline of the box loads (bf16, full 3x3x3 stride-1 stages): the first NPF items of a thread for stage
   // ks+1 are requested DURING the MFMA phase of stage ks - after its last weight-fragment request, because loads return
@@ -296,10 +303,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
       const bool ok = bv < boxvox && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
       pok |= (ok ? 1u : 0u) << i;
       // unconditional loads from clamped (always valid) addresses, masked when they are committed
-      const float* src = inb + min(max(iz, 0), a.Di - 1) * a.isd + min(max(iy, 0), a.Hi - 1) * a.ish +
-                         min(max(ix, 0), a.Wi - 1) * a.isw + c;
-      pfa[i] = *reinterpret_cast<const float4*>(src);
-      pfb[i] = *reinterpret_cast<const float4*>(src + 4);
+      const long long so = (long long)min(max(iz, 0), a.Di - 1) * a.isd + (long long)min(max(iy, 0), a.Hi - 1) * a.ish +
+                           (long long)min(max(ix, 0), a.Wi - 1) * a.isw + c;
+      ld8_t<ABF>(inb, inoff + so, pfa[i], pfb[i]);
     }
   };
   if (pipe && ks0 < ks1) {
@@ -386,9 +392,12 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
             x0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             x1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok[u]) {
-              const float* src = inb + iz * a.isd + iy * a.ish + ix * a.isw + c;
-              x0[u] = *reinterpret_cast<const float4*>(src);
-              if (c + 4 < a.Ci) x1[u] = *reinterpret_cast<const float4*>(src + 4);
+              const long long so = inoff + (long long)iz * a.isd + (long long)iy * a.ish + (long long)ix * a.isw + c;
+              if constexpr (ABF) ld8_t<true>(inb, so, x0[u], x1[u]);      // rows of bf16 tensors are padded to 8 channels
+              else {
+                x0[u] = *reinterpret_cast<const float4*>(inb + so);
+                if (c + 4 < a.Ci) x1[u] = *reinterpret_cast<const float4*>(inb + so + 4);
+              }
             }
           }
 #pragma unroll
@@ -425,7 +434,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
           float v = 0.f;
           if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi &&
               c < a.Ci)
-            v = nl_apply(inb[iz * a.isd + iy * a.ish + ix * a.isw + c], sc, sh, a.tin.relu);
+            v = nl_apply(ld1_t<ABF>(inb, inoff + (long long)iz * a.isd + (long long)iy * a.ish + (long long)ix * a.isw + c), sc, sh,
+                         a.tin.relu);
           lh[((bz * BY + by) * LP + bx) * VS + cc] = __builtin_bit_cast(unsigned short, (__bf16)v);
         }
       }
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
           ok[u] = bv < boxvox && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
                   (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
           xin[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok[u]) xin[u] = *reinterpret_cast<const float4*>(inb + iz * a.isd + iy * a.ish + ix * a.isw + c);
+          if (ok[u]) xin[u] = *reinterpret_cast<const float4*>(inb + inoff + iz * a.isd + iy * a.ish + ix * a.isw + c);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
         float v = 0.f;
         if ((unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi &&
             c < a.Ci)
-          v = nl_apply(inb[iz * a.isd + iy * a.ish + ix * a.isw + c], sc, sh, a.tin.relu);
+          v = nl_apply(inb[inoff + iz * a.isd + iy * a.ish + ix * a.isw + c], sc, sh, a.tin.relu);
         lds[bv * VS + cc] = v;
       }
     }
@@ -512,6 +522,12 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
           for (int t = 0; t < G; ++t)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) wset[0][t][ks] = wfirst[t][ks];     // requested before the staging pass
+          uint4 avc[MB];
+          {
+            const int ta0 = ttoff[0] * VS;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) avc[mb] = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta0);
+          }
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) {
@@ -528,14 +544,31 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
 #pragma unroll
             for (int t = 0; t < G; ++t) {
               if (g * G + t < 27) {
-                const int ta = ttoff[g * G + t] * VS;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                   const bf16x8 bfr = __builtin_bit_cast(bf16x8, wset[g & 1][t][ks]);
+                  // the activation fragments of the NEXT (tap, k-step) are read while this one's MFMAs run: left to
+                  // itself the compiler emits read -> wait -> MFMA per fragment (one register set) and every MFMA
+                  // exposes an LDS round trip (measured ~93 cycles per 32-cycle MFMA)
+                  const int idx = g * G + t;
+                  const bool more = !(idx == 26 && ks == KS - 1);
+                  const int nidx = ks + 1 < KS ? idx : idx + 1, nks2 = ks + 1 < KS ? ks + 1 : 0;
+                  uint4 avn[MB];
+                  int tan = 0;
+                  if (more) tan = ttoff[nidx] * VS + nks2 * 16;
 #pragma unroll
                   for (int mb = 0; mb < MB; ++mb) {
-                    const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + ks * 16);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfr, acc[mb], 0, 0, 0);
+                    if (more) avn[mb] = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + tan);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, avc[mb]), bfr, acc[mb], 0, 0, 0);
+                  }
+#pragma unroll
+                  for (int mb = 0; mb < MB; ++mb) {
+                    if (more) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one LDS read ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // ... then one MFMA
+                  }
+                  if (more) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) avc[mb] = avn[mb];
                   }
                 }
               }
@@ -675,7 +708,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
   if (a.ovec) {
     // 16-byte stores through a wave-private LDS tile (the K loop ended with a barrier: the box image is dead)
     float v_sum[4], v_sq[4];
-    epilogue_vec16<TZ, TY, TX, MB, BF>(a, ci, acc, lds + wave * EPI_TILE_FLOATS, lane, mg * MB, colbase, colact, n, gz0, gy0,
+    epilogue_vec16<TZ, TY, TX, MB, BF, ABF>(a, ci, acc, lds + wave * EPI_TILE_FLOATS, lane, mg * MB, colbase, colact, n, gz0, gy0,
                                        gx0, v_sum, v_sq);
     if (a.stats != nullptr) {
       float* red = lds + 4 * EPI_TILE_FLOATS;      // [4 waves][2][32], behind the four tiles
@@ -710,8 +743,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
   // (unconditional, from clamped addresses, under wave-uniform branches), then the arithmetic and the stores: a load
   // inside a per-element branch would be waited for on the spot, 16 exposed round trips per block.
   const int colc = min(col, a.Co - 1);
-  const float* addb = a.add ? a.add + (long long)n * a.asn + colc : nullptr;
-  float* outb = a.out + (long long)n * a.osn + colc;
+  const float* addb = a.add;
+  float* outb = a.out;
+  const long long abase = (long long)n * a.asn + colc, obase = (long long)n * a.osn + colc;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -734,11 +768,11 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
       float addv[8], oldv[8];
       if (a.add) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) addv[j] = addb[aoff[j]];
+        for (int j = 0; j < 8; ++j) addv[j] = ld1_t<ABF>(addb, abase + aoff[j]);
       }
       if (a.accumulate) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) oldv[j] = outb[ooff[j]];
+        for (int j = 0; j < 8; ++j) oldv[j] = ld1_t<ABF>(outb, obase + ooff[j]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -746,7 +780,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
         if (a.add) v += nl_apply(addv[j], asc, ash, a.tadd.relu);
         if (a.accumulate) v += oldv[j];
         if (ok[j]) {
-          outb[ooff[j]] = v;
+          st1_t<ABF>(outb, obase + ooff[j], v);
           s_sum += v;
           s_sq += v * v;
         }
@@ -1130,7 +1164,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(GArgs a, int ntiles, i
     if (a.ovec) {
       // 16-byte stores through this wave's LDS tile (behind the two box buffers)
       float v_sum[4], v_sq[4];
-      epilogue_vec16<TZ, TY, TX, MB, true>(a, ci, acc, lds + bufhw + cw * EPI_TILE_FLOATS, lane1, mg * MB, colbase, colact, n,
+      epilogue_vec16<TZ, TY, TX, MB, true, false>(a, ci, acc, lds + bufhw + cw * EPI_TILE_FLOATS, lane1, mg * MB, colbase, colact, n,
                                            cg.gz0, cg.gy0, cg.gx0, v_sum, v_sq);
       if (a.stats != nullptr && lane1 < 8 && colact) {
         const long long row = (long long)n * a.stats_rows_per_n +
@@ -1225,7 +1259,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(GArgs a, int ntiles, i
 // Reduce split-K slabs: sum over splits, then the same epilogue as above.
 // grid (tiles * MT/32, ceil(Np/32)); 256 threads = 8 row lanes x 32 columns, 4 rows per thread, i.e. one
 // block per 32 rows x 32 columns; each block writes ONE statistics row (rows per tile = MT/32).
-template <int TZ, int TY, int TX, bool PERM>
+template <int TZ, int TY, int TX, bool PERM, bool ABF = false>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles) {
   __shared__ float red[2][8][32];
   constexpr int MT = TZ * TY * TX;
@@ -1282,11 +1316,11 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
   float addv[4] = {0.f, 0.f, 0.f, 0.f}, oldv[4] = {0.f, 0.f, 0.f, 0.f};
   if (a.add) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) addv[q] = a.add[aoff[q]];
+    for (int q = 0; q < 4; ++q) addv[q] = ld1_t<ABF>(a.add, aoff[q]);
   }
   if (a.accumulate) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) oldv[q] = a.out[ooff[q]];
+    for (int q = 0; q < 4; ++q) oldv[q] = ld1_t<ABF>(a.out, ooff[q]);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -1294,7 +1328,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
     if (a.add) val += nl_apply(addv[q], asc, ash, a.tadd.relu);
     if (a.accumulate) val += oldv[q];
     if (ok[q]) {
-      a.out[ooff[q]] = val;
+      st1_t<ABF>(a.out, ooff[q], val);
       s_sum += val;
       s_sq += val * val;
     }
@@ -1551,7 +1585,7 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   g.tiles = g.tiles_per_n * x->n * g.ncls;     // the parity classes share one launch
   g.nstages = (g.K + g.cfg.KCI - 1) / g.cfg.KCI;
   g.launches = 1;
-  g.ws = g.cfg.bf && (g_igemm_ws == 2 || (g_igemm_ws == 1 && g.cfg.NB == 4));
+  g.ws = g.cfg.bf && (g_igemm_ws == 2 || (g_igemm_ws == 1 && g.cfg.NB == 4)) && !is_bf16(x) && !is_bf16(y);
   const int ncolgroups = (g.Np + 32 * g.cfg.NB - 1) / (32 * g.cfg.NB);
   const int wgs = g.tiles * ncolgroups;
   g.ksplit = 1;
@@ -1615,8 +1649,8 @@ static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t
 template <int NB>
 static bool ws_selected() { return g_igemm_ws == 2 || (g_igemm_ws == 1 && NB == 4); }
 
-template <int NB, int MB, int TZ, int TY, int TX, int KCI, bool BF, int OCC = 2>
-static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t s) {
+template <int NB, int MB, int TZ, int TY, int TX, int KCI, bool BF, int OCC, bool ABF>
+static int launch_cfg_t(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t s) {
   GArgs a = a_in;
   size_t lds = 0;
   for (int c = 0; c < a.ncls; ++c) {
@@ -1641,8 +1675,9 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
   MMTTA_CHECK(lds <= 160 * 1024, MMTTA_ERR_UNSUPPORTED, "conv: LDS box of %zu bytes exceeds 160 KiB", lds);
   int st;
   if constexpr (BF) {
-    if (ws_selected<NB>() && 2 * lds_box + 4 * EPI_TILE_FLOATS * sizeof(float) <= 160 * 1024) {
+    if (ws_selected<NB>() && !a.in_bf && !a.out_bf && 2 * lds_box + 4 * EPI_TILE_FLOATS * sizeof(float) <= 160 * 1024) {
       // producer / consumer form: one 512-thread workgroup per CU, two LDS box buffers, a contiguous range of units each
+      MMTTA_CHECK(!a.add_bf, MMTTA_ERR_UNSUPPORTED, "conv (producer/consumer): bf16-stored epilogue operand");
       auto kws = igemm_ws_kernel<NB, MB, TZ, TY, TX, KCI>;
       static bool ws_attr_set = false;
       if (!ws_attr_set) {
@@ -1658,13 +1693,13 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
       if (st) return st;
       if (a.ksplit > 1 && !g_profile_main_only) {
         dim3 g2(tiles * (TZ * TY * TX / 32), (a.Np + 31) / 32);
-        hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX, BF>), g2, dim3(256), 0, s, a, tiles);
+        hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX, BF, ABF>), g2, dim3(256), 0, s, a, tiles);
         st = launch_status("conv split-K finalize");
       }
       return st;
     }
   }
-  auto kern = igemm_kernel<NB, MB, TZ, TY, TX, KCI, BF, OCC>;
+  auto kern = igemm_kernel<NB, MB, TZ, TY, TX, KCI, BF, OCC, ABF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1676,10 +1711,25 @@ static int launch_cfg(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t 
   if (st) return st;
   if (a.ksplit > 1 && !g_profile_main_only) {
     dim3 g2(tiles * (TZ * TY * TX / 32), (a.Np + 31) / 32);
-    hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX, BF>), g2, dim3(256), 0, s, a, tiles);
+    hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX, BF, ABF>), g2, dim3(256), 0, s, a, tiles);
     st = launch_status("conv split-K finalize");
   }
   return st;
+}
+
+// storage dispatch: bf16-stored activations exist for bf16-operand layers only (forward: input, output and fused add all
+// bf16; everything else all fp32)
+template <int NB, int MB, int TZ, int TY, int TX, int KCI, bool BF, int OCC = 2>
+static int launch_cfg(const GArgs& a, const Taps* ht, int tiles, hipStream_t s) {
+  if constexpr (BF) {
+    if (a.in_bf || a.out_bf || a.add_bf) {
+      MMTTA_CHECK(a.in_bf && a.out_bf && (a.add == nullptr || a.add_bf), MMTTA_ERR_UNSUPPORTED,
+                  "conv: input, output and fused add must share one storage type (in %d out %d add %d)", a.in_bf, a.out_bf,
+                  a.add_bf);
+      return launch_cfg_t<NB, MB, TZ, TY, TX, KCI, BF, OCC, true>(a, ht, tiles, s);
+    }
+  }
+  return launch_cfg_t<NB, MB, TZ, TY, TX, KCI, BF, OCC, false>(a, ht, tiles, s);
 }
 
 static int config_id(const Config& c) {
@@ -1837,7 +1887,7 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   if (st) return st;
   MMTTA_CHECK(packed != nullptr, MMTTA_ERR_INVALID, "conv: null packed weights");
   if (direct_applicable(d)) return direct_conv_run(d, x, x_norm, packed, bias, epi, y, accumulate, stats, (hipStream_t)stream);
-  if (pointwise_small_applicable(d, x, y, stats, epi, x_norm) && !use_bf16(d, g.K))
+  if (pointwise_small_applicable(d, x, y, stats, epi, x_norm) && !use_bf16(d, g.K) && is_f32(x) && is_f32(y))
     return pointwise_small_run(x, packed, g.Kp, g.Np, bias, y, accumulate, (hipStream_t)stream);
   if (chan_applicable(d, x, y) && !use_bf16(d, g.K))
     return chan_conv_run(d, x, x_norm, packed, g.Kp, g.Np, bias, epi, y, accumulate, stats, (hipStream_t)stream);
@@ -1863,11 +1913,11 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   }
   a.accumulate = accumulate;
   {
-    auto al16 = [](const void* p, long long sn, long long sd, long long sh, long long sw) {
-      return ((uintptr_t)p) % 16 == 0 && sn % 4 == 0 && sd % 4 == 0 && sh % 4 == 0 && sw % 4 == 0;
+    auto al16 = [](const void* p, long long sn, long long sd, long long sh, long long sw, int bf) {      // 4-channel accesses
+      return ((uintptr_t)p) % (bf ? 8 : 16) == 0 && sn % 4 == 0 && sd % 4 == 0 && sh % 4 == 0 && sw % 4 == 0;
     };
-    const bool oal = al16(y->ptr, y->sn, y->sd, y->sh, y->sw) && y->c % 4 == 0 &&
-                     (a.add == nullptr || al16(a.add, a.asn, a.asd, a.ash, a.asw)) &&
+    const bool oal = al16(y->ptr, y->sn, y->sd, y->sh, y->sw, a.out_bf) && y->c % 4 == 0 &&
+                     (a.add == nullptr || al16(a.add, a.asn, a.asd, a.ash, a.asw, a.add_bf)) &&
                      (bias == nullptr || ((uintptr_t)bias) % 16 == 0);
     a.ovec = (oal && g_epilogue_vec) ? 1 : 0;
   }
@@ -1875,7 +1925,14 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   a.stats = stats; a.stats_rows_per_n = g.ncls * g.tiles_per_n * srt;
   a.ws = (float*)workspace; a.ksplit = g.ksplit; a.stages_per_split = g.sps; a.nstages = g.nstages;
   a.tz = g.tz; a.ty = g.ty; a.tx = g.tx;
-  const bool al = (((uintptr_t)x->ptr) % 16 == 0) && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0;
+  a.in_bf = is_bf16(x) ? 1 : 0;
+  a.out_bf = is_bf16(y) ? 1 : 0;
+  a.add_bf = (epi && epi->add && is_bf16(epi->add)) ? 1 : 0;
+  MMTTA_CHECK(g.cfg.bf || (!a.in_bf && !a.out_bf && !a.add_bf), MMTTA_ERR_UNSUPPORTED,
+              "conv: bf16-stored tensors need a bf16-operand layer (K >= 16 in bf16 precision)");
+  // 8-channel items: 32 bytes of fp32 (two 16-byte loads) or 16 bytes of bf16 (one): strides must keep them aligned
+  const int am = a.in_bf ? 8 : 4;
+  const bool al = (((uintptr_t)x->ptr) % 16 == 0) && x->sw % am == 0 && x->sh % am == 0 && x->sd % am == 0 && x->sn % am == 0;
   a.vec4 = al ? 1 : 0;
   a.pipeline = g_igemm_pipeline;
   a.ovec = 0;       // set below once the epilogue operands are known

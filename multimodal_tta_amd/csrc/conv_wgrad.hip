@@ -33,11 +33,12 @@ struct WArgs {
   int tz, ty, tx, tiles, tiles_per_split;
   int CGp, CDp;
   int gvec4, dvec4;
+  int g_bf, d_bf;   // storage of the gathered / dense tensor: 1 = bf16 elements (the forward activation of bf16 precision)
 };
 
 // NTW = accumulators per wave: 7 for the 27-tap kernel (taps wave, wave+4, ...; slot 27 is a dummy that is
 // never flushed), 1 for a single tap (the four waves then split the voxel pairs instead).
-template <int TZ, int TY, int TX, int NTW>
+template <int TZ, int TY, int TX, int NTW, bool GBF = false, bool DBF = false>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
   extern __shared__ float lds[];
   constexpr int MT = TZ * TY * TX;
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
     const int iz0 = oz0 * a.si + dmin, iy0 = oy0 * a.si + dmin, ix0 = ox0 * a.si + dmin;
     // ---- stage G box: [boxvox][32 channels cg0..cg0+31]
     {
-      const float* gb = a.g + (long long)n * a.gsn;
+      const float* gb = a.g;
+      const long long gbo = (long long)n * a.gsn;
       if (a.gvec4) {
         const int cv = tid & 7;
         const int c = cg0 + cv * 4;
@@ -100,9 +102,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
             const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
             ok[u] = bv < boxvox && (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg &&
                     (unsigned)ix < (unsigned)a.Wgg && c < a.Cg;
-            xin[u] = *reinterpret_cast<const float4*>(gb + (long long)min(max(iz, 0), a.Dgg - 1) * a.gsd +
-                                                      (long long)min(max(iy, 0), a.Hgg - 1) * a.gsh +
-                                                      (long long)min(max(ix, 0), a.Wgg - 1) * a.gsw + min(c, (a.Cg - 1) & ~3));
+            xin[u] = ld4_t<GBF>(gb, gbo + (long long)min(max(iz, 0), a.Dgg - 1) * a.gsd + (long long)min(max(iy, 0), a.Hgg - 1) * a.gsh +
+                                      (long long)min(max(ix, 0), a.Wgg - 1) * a.gsw + min(c, (a.Cg - 1) & ~3));
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
           float v = 0.f;
           if ((unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg && (unsigned)ix < (unsigned)a.Wgg &&
               c < a.Cg)
-            v = nl_apply(gb[iz * a.gsd + iy * a.gsh + ix * a.gsw + c], sc, sh, a.tg.relu);
+            v = nl_apply(ld1_t<GBF>(gb, gbo + (long long)iz * a.gsd + (long long)iy * a.gsh + (long long)ix * a.gsw + c), sc, sh, a.tg.relu);
           gl[bv * 32 + cc] = v;
         }
       }
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
     // thread's loads in flight together (a load behind a per-item branch is waited for at once: 16 exposed round
     // trips per tile before)
     {
-      const float* db = a.dn + (long long)n * a.dsn;
+      const float* db = a.dn;
+      const long long dbo = (long long)n * a.dsn;
       if (a.dvec4) {
         const int cv = tid & 7;
         const int c = cd0 + cv * 4;
@@ -152,9 +154,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
         for (int q = 0; q < NQ; ++q) {
           const int v = (tid >> 3) + 32 * q;
           const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
-          raw[q] = *reinterpret_cast<const float4*>(db + (long long)min(oz0 + zl, a.Dd - 1) * a.dsd +
-                                                   (long long)min(oy0 + yl, a.Hd - 1) * a.dsh +
-                                                   (long long)min(ox0 + xl, a.Wd - 1) * a.dsw + cl4);
+          raw[q] = ld4_t<DBF>(db, dbo + (long long)min(oz0 + zl, a.Dd - 1) * a.dsd + (long long)min(oy0 + yl, a.Hd - 1) * a.dsh +
+                                    (long long)min(ox0 + xl, a.Wd - 1) * a.dsw + cl4);
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
         for (int q = 0; q < NQ; ++q) {
           const int v = (tid >> 5) + 8 * q;
           const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
-          raw[q] = db[(long long)min(oz0 + zl, a.Dd - 1) * a.dsd + (long long)min(oy0 + yl, a.Hd - 1) * a.dsh +
-                      (long long)min(ox0 + xl, a.Wd - 1) * a.dsw + cl];
+          raw[q] = ld1_t<DBF>(db, dbo + (long long)min(oz0 + zl, a.Dd - 1) * a.dsd + (long long)min(oy0 + yl, a.Hd - 1) * a.dsh +
+                                    (long long)min(ox0 + xl, a.Wd - 1) * a.dsw + cl);
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -384,7 +385,7 @@ struct WBGeo {
   static constexpr int LDS_BYTES = 3 * COPY + 32 * CHS_D + 256 * 4;
 };
 
-template <int TZ, int TY, int SI>
+template <int TZ, int TY, int SI, bool GBF = false, bool DBF = false>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WArgs a) {   // two workgroups per CU (LDS allows two)
   using G = WBGeo<TZ, TY, SI>;
   extern __shared__ float lds[];
@@ -438,22 +439,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WArgs a) {   // two 
     const int iz0 = poz0 * SI - 1, iy0 = poy0 * SI - 1, ix0 = pox0 * SI - 1;
     nl_coeff_vec<1>(a.td, pn, a.Cd, dc, &dsc, &dsh);
     nl_coeff_vec<1>(a.tg, pn, a.Cg, gc, &gsc, &gsh);
-    const float* db = a.dn + (long long)pn * a.dsn + min(dc, a.Cd - 1);
+    const long long dbo = (long long)pn * a.dsn + min(dc, a.Cd - 1);
 #pragma unroll
     for (int q = 0; q < ND; ++q) {
       const int xr = min((tid >> 5) + 8 * q, G::NXR - 1);
-      const float* rp = db + (long long)min(poz0 + xr / TY, a.Dd - 1) * a.dsd + (long long)min(poy0 + xr % TY, a.Hd - 1) * a.dsh;
+      const long long rpo = dbo + (long long)min(poz0 + xr / TY, a.Dd - 1) * a.dsd + (long long)min(poy0 + xr % TY, a.Hd - 1) * a.dsh;
 #pragma unroll
-      for (int x = 0; x < 8; ++x) dv[q][x] = rp[(long long)min(pox0 + x, a.Wd - 1) * a.dsw];
+      for (int x = 0; x < 8; ++x) dv[q][x] = ld1_t<DBF>(a.dn, rpo + (long long)min(pox0 + x, a.Wd - 1) * a.dsw);
     }
-    const float* gb = a.g + (long long)pn * a.gsn + min(gc, a.Cg - 1);
+    const long long gbo = (long long)pn * a.gsn + min(gc, a.Cg - 1);
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
       const int row = min((tid >> 5) + 8 * q, G::RG - 1);
       const int bz = row / G::BYr, by = row % G::BYr;
-      const float* rp = gb + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd + (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
+      const long long rpo = gbo + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd + (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
 #pragma unroll
-      for (int x = 0; x < G::NX; ++x) gv[q][x] = rp[(long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw];
+      for (int x = 0; x < G::NX; ++x) gv[q][x] = ld1_t<GBF>(a.g, rpo + (long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw);
     }
   };
   // transform + pack + LDS write of RB box rows starting at row0 (values in v)
@@ -487,17 +488,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WArgs a) {   // two 
     const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
     commit_g(gv, tid >> 5, iz0, iy0, ix0);                       // the prefetched trip
     if (8 * RB < G::RG) {                                        // stride 2: the remaining box rows, RB at a time
-      const float* gb = a.g + (long long)n * a.gsn + min(gc, a.Cg - 1);
+      const long long gbo = (long long)n * a.gsn + min(gc, a.Cg - 1);
       for (int row0 = (tid >> 5) + 8 * RB; row0 < G::RG; row0 += 8 * RB) {
         float v[RB][G::NX];
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
           const int row = min(row0 + 8 * q, G::RG - 1);
           const int bz = row / G::BYr, by = row % G::BYr;
-          const float* rp = gb + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd +
-                            (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
+          const long long rpo = gbo + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd +
+                                (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
 #pragma unroll
-          for (int x = 0; x < G::NX; ++x) v[q][x] = rp[(long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw];
+          for (int x = 0; x < G::NX; ++x) v[q][x] = ld1_t<GBF>(a.g, rpo + (long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw);
         }
         commit_g(v, row0, iz0, iy0, ix0);
       }
@@ -565,10 +566,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WArgs a) {   // two 
   }
 }
 
-template <int TZ, int TY, int SI>
-static int launch_wgrad_bf16(const WArgs& a, int S, hipStream_t s) {
+template <int TZ, int TY, int SI, bool GBF, bool DBF>
+static int launch_wgrad_bf16_t(const WArgs& a, int S, hipStream_t s) {
   using G = WBGeo<TZ, TY, SI>;
-  auto kern = wgrad_bf16_kernel<TZ, TY, SI>;
+  auto kern = wgrad_bf16_kernel<TZ, TY, SI, GBF, DBF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -577,6 +578,216 @@ static int launch_wgrad_bf16(const WArgs& a, int S, hipStream_t s) {
   dim3 grid(S, a.CGp / 32, a.CDp / 32);
   hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, s, a);
   return launch_status("conv wgrad bf16");
+}
+
+// The same kernel with VECTOR staging loads (16-byte-aligned tensors: every pooled buffer).  Above, a thread owns one
+// channel and fetches its voxels one 4-byte (bf16 storage: 2-byte) element at a time - 66 load instructions per thread
+// and tile, and the staging is bound by their count, not by bytes (measured: bf16 storage, half the bytes, made that
+// kernel 8-19 % SLOWER).  Here a thread owns FOUR channels (cq = tid & 7) of one box row (rt = tid >> 3, 32 rows per
+// pass): NX loads of 16 bytes (8 bytes for bf16 storage) per row instead of 4 x NX scalar ones, then 4 channels x 3
+// x-shifted copies = 12 LDS writes of 16 bytes.  The D tile: (channel group, x-row half): 4 loads, 4 LDS writes of 8
+// bytes.  Same LDS images, same MFMA loop, same slabs: results are bit-identical to the scalar loader.
+template <int TZ, int TY, int SI, bool GBF, bool DBF>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16v_kernel(WArgs a) {
+  using G = WBGeo<TZ, TY, SI>;
+  extern __shared__ float lds[];
+  unsigned char* lb = reinterpret_cast<unsigned char*>(lds);
+  unsigned char* gl = lb;                       // 3 copies
+  unsigned char* dl = lb + 3 * G::COPY;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int cg0 = blockIdx.y * 32, cd0 = blockIdx.z * 32;
+  const int cq = tid & 7, rt = tid >> 3;        // staging: channel group (4 channels), row slot
+
+  int toffb[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = min(wave + 4 * j, 26);
+    toffb[j] = (tap % 3) * G::COPY + ((tap / 9) * G::BYr + ((tap / 3) % 3)) * 16;
+  }
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int t0 = sx * a.tiles_per_split;
+  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
+  const int tpn = a.tz * a.ty * a.tx;
+  constexpr int NPASS = (G::RG + 31) / 32;      // box rows: 32 per pass
+  const int gcb = cg0 + 4 * cq, dcb = cd0 + 4 * cq;
+  const int gcl = min(gcb, (a.Cg - 1) & ~3), dcl = min(dcb, (a.Cd - 1) & ~3);     // clamped (always valid) load channels
+  float4 dv[4];                                 // the prefetched D half row (the box rows are loaded per pass: registers)
+  float gsc[4], gsh[4], dsc[4], dsh[4];
+  int pn = 0, poz0 = 0, poy0 = 0, pox0 = 0;
+  const int dxr = rt >> 1, dhalf = rt & 1;      // D item of this thread: x-row, half (4 voxels)
+
+  auto load_g_row = [&](float4 (&v)[G::NX], int n, int row, int iz0, int iy0, int ix0) {
+    const int rowc = min(row, G::RG - 1);
+    const int bz = rowc / G::BYr, by = rowc % G::BYr;
+    const long long rpo = (long long)n * a.gsn + gcl + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd +
+                          (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
+#pragma unroll
+    for (int x = 0; x < G::NX; ++x) v[x] = ld4_t<GBF>(a.g, rpo + (long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw);
+  };
+  auto commit_g_row = [&](float4 (&v)[G::NX], int row, int iz0, int iy0, int ix0) {
+    if (row >= G::RG) return;
+    const int bz = row / G::BYr, by = row % G::BYr;
+    const int iz = iz0 + bz, iy = iy0 + by;
+    const bool rok = (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg;
+    // transform in place (no second register array), then pack per channel and x shift
+#pragma unroll
+    for (int x = 0; x < G::NX; ++x) {
+      const bool ok = rok && (unsigned)(ix0 + x) < (unsigned)a.Wgg;
+      v[x].x = (ok && gcb + 0 < a.Cg) ? nl_apply(v[x].x, gsc[0], gsh[0], a.tg.relu) : 0.f;
+      v[x].y = (ok && gcb + 1 < a.Cg) ? nl_apply(v[x].y, gsc[1], gsh[1], a.tg.relu) : 0.f;
+      v[x].z = (ok && gcb + 2 < a.Cg) ? nl_apply(v[x].z, gsc[2], gsh[2], a.tg.relu) : 0.f;
+      v[x].w = (ok && gcb + 3 < a.Cg) ? nl_apply(v[x].w, gsc[3], gsh[3], a.tg.relu) : 0.f;
+    }
+    unsigned char* gdst = gl + (4 * cq) * G::CHS_G + row * 16;
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      uint4 p0, p1, p2, p3;
+      p0.x = wpack2(v[0 * SI + dxi].x, v[1 * SI + dxi].x); p0.y = wpack2(v[2 * SI + dxi].x, v[3 * SI + dxi].x);
+      p0.z = wpack2(v[4 * SI + dxi].x, v[5 * SI + dxi].x); p0.w = wpack2(v[6 * SI + dxi].x, v[7 * SI + dxi].x);
+      p1.x = wpack2(v[0 * SI + dxi].y, v[1 * SI + dxi].y); p1.y = wpack2(v[2 * SI + dxi].y, v[3 * SI + dxi].y);
+      p1.z = wpack2(v[4 * SI + dxi].y, v[5 * SI + dxi].y); p1.w = wpack2(v[6 * SI + dxi].y, v[7 * SI + dxi].y);
+      p2.x = wpack2(v[0 * SI + dxi].z, v[1 * SI + dxi].z); p2.y = wpack2(v[2 * SI + dxi].z, v[3 * SI + dxi].z);
+      p2.z = wpack2(v[4 * SI + dxi].z, v[5 * SI + dxi].z); p2.w = wpack2(v[6 * SI + dxi].z, v[7 * SI + dxi].z);
+      p3.x = wpack2(v[0 * SI + dxi].w, v[1 * SI + dxi].w); p3.y = wpack2(v[2 * SI + dxi].w, v[3 * SI + dxi].w);
+      p3.z = wpack2(v[4 * SI + dxi].w, v[5 * SI + dxi].w); p3.w = wpack2(v[6 * SI + dxi].w, v[7 * SI + dxi].w);
+      *reinterpret_cast<uint4*>(gdst + dxi * G::COPY + 0 * G::CHS_G) = p0;
+      *reinterpret_cast<uint4*>(gdst + dxi * G::COPY + 1 * G::CHS_G) = p1;
+      *reinterpret_cast<uint4*>(gdst + dxi * G::COPY + 2 * G::CHS_G) = p2;
+      *reinterpret_cast<uint4*>(gdst + dxi * G::COPY + 3 * G::CHS_G) = p3;
+    }
+  };
+  auto issue = [&](int tile) {
+    pn = tile / tpn;
+    int t = tile % tpn;
+    const int txi = t % a.tx; t /= a.tx;
+    const int tyi = t % a.ty;
+    const int tzi = t / a.ty;
+    poz0 = tzi * TZ; poy0 = tyi * TY; pox0 = txi * 8;
+    nl_coeff_vec<4>(a.td, pn, a.Cd, dcb, dsc, dsh);
+    nl_coeff_vec<4>(a.tg, pn, a.Cg, gcb, gsc, gsh);
+    const int xr = min(dxr, G::NXR - 1);
+    const long long dpo = (long long)pn * a.dsn + dcl + (long long)min(poz0 + xr / TY, a.Dd - 1) * a.dsd +
+                          (long long)min(poy0 + xr % TY, a.Hd - 1) * a.dsh;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) dv[x] = ld4_t<DBF>(a.dn, dpo + (long long)min(pox0 + 4 * dhalf + x, a.Wd - 1) * a.dsw);
+  };
+
+  if (t0 < t1) issue(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+    const int n = pn, oz0 = poz0, oy0 = poy0, ox0 = pox0;
+    const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
+#pragma unroll 1
+    for (int p = 0; p < NPASS; ++p) {                            // 32 box rows per pass
+      if (rt + 32 * p < G::RG) {
+        float4 v[G::NX];
+        load_g_row(v, n, rt + 32 * p, iz0, iy0, ix0);
+        commit_g_row(v, rt + 32 * p, iz0, iy0, ix0);
+      }
+    }
+    if (dxr < G::NXR) {  // ---- D tile: thread = (channel group, x-row, half)
+      const int oz = oz0 + dxr / TY, oy = oy0 + dxr % TY;
+      const bool rok = oz < a.Dd && oy < a.Hd;
+      float w[4][4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const bool ok = rok && ox0 + 4 * dhalf + x < a.Wd;
+        const float raw[4] = {dv[x].x, dv[x].y, dv[x].z, dv[x].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          w[c][x] = (ok && dcb + c < a.Cd) ? nl_apply(raw[c], dsc[c], dsh[c], a.td.relu) : 0.f;
+          dbs[c] += w[c][x];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint2 pk;
+        pk.x = wpack2(w[c][0], w[c][1]); pk.y = wpack2(w[c][2], w[c][3]);
+        *reinterpret_cast<uint2*>(dl + (4 * cq + c) * G::CHS_D + dxr * 16 + dhalf * 8) = pk;
+      }
+    }
+    __syncthreads();
+    if (tile + 1 < t1) issue(tile + 1);                          // lands during the MFMAs below
+#pragma unroll 2
+    for (int ks = 0; ks < G::NXR / 2; ++ks) {
+      const int xr = 2 * ks + h;
+      const int z = xr / TY, y = xr % TY;
+      const uint4 bq = *reinterpret_cast<const uint4*>(dl + r * G::CHS_D + xr * 16);
+      const unsigned char* ga = gl + r * G::CHS_G + ((z * SI) * G::BYr + y * SI) * 16;
+      uint4 aq[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) aq[j] = *reinterpret_cast<const uint4*>(ga + toffb[j]);
+      const wbf16x8 bfrag = __builtin_bit_cast(wbf16x8, bq);
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, aq[j]), bfrag, acc[j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int sl = blockIdx.x;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = wave + 4 * j;
+    if (tap < 27) {
+      float* sb = a.slab + (((long long)sl * 27 + tap) * a.CGp + cg0) * a.CDp + cd0 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        sb[(long long)row * a.CDp] = acc[j][i];
+      }
+    }
+  }
+  if (a.dbpart != nullptr && blockIdx.y == 0) {     // bias gradient from the fp32 values seen while staging
+    float* red4 = lds;                              // the images are dead: the loop ended with a barrier
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red4[tid * 4 + c] = dbs[c];
+    __syncthreads();
+    if (tid < 32) {
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < 32; ++q) sacc += red4[((q << 3) | (tid >> 2)) * 4 + (tid & 3)];
+      a.dbpart[(long long)sl * a.CDp + cd0 + tid] = sacc;
+    }
+  }
+}
+
+template <int TZ, int TY, int SI, bool GBF, bool DBF>
+static int launch_wgrad_bf16v_t(const WArgs& a, int S, hipStream_t s) {
+  using G = WBGeo<TZ, TY, SI>;
+  auto kern = wgrad_bf16v_kernel<TZ, TY, SI, GBF, DBF>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(S, a.CGp / 32, a.CDp / 32);
+  const size_t ldsb = G::LDS_BYTES > 4096 ? G::LDS_BYTES : 4096;
+  hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, s, a);
+  return launch_status("conv wgrad bf16 (vector staging)");
+}
+
+// one instantiation per storage combination (the forward activation may be bf16-stored, the gradient never is)
+template <int TZ, int TY, int SI>
+static int launch_wgrad_bf16(const WArgs& a, int S, hipStream_t s) {
+  MMTTA_CHECK(!(a.g_bf && a.d_bf), MMTTA_ERR_UNSUPPORTED, "wgrad: both operands bf16-stored");
+  // measured (profiles/r02_wgrad_vector.txt): the vector loader wins with a bf16-stored operand (1189 -> 1116 us per
+  // step), the element loader with fp32 storage (1075 vs 1116 us: it prefetches the next tile's gradient rows)
+  if (a.gvec4 && a.dvec4 && (g_wgrad_vec == 2 || (g_wgrad_vec == 1 && (a.g_bf || a.d_bf)))) {
+    if (a.g_bf) return launch_wgrad_bf16v_t<TZ, TY, SI, true, false>(a, S, s);
+    if (a.d_bf) return launch_wgrad_bf16v_t<TZ, TY, SI, false, true>(a, S, s);
+    return launch_wgrad_bf16v_t<TZ, TY, SI, false, false>(a, S, s);
+  }
+  if (a.g_bf) return launch_wgrad_bf16_t<TZ, TY, SI, true, false>(a, S, s);
+  if (a.d_bf) return launch_wgrad_bf16_t<TZ, TY, SI, false, true>(a, S, s);
+  return launch_wgrad_bf16_t<TZ, TY, SI, false, false>(a, S, s);
 }
 
 // ------------------------------------------------------------------ small-channel weight gradient
@@ -595,9 +806,11 @@ struct W2Args {
   float* dbpart;   // [nsl][CBp] or null: per-channel sums of P (bias gradient when cb is the output channel)
   int tz, ty, tx, tiles, tiles_per_split, CBp;
   int qvec4, pvec4;
+  int p_bf;        // the dense tensor P is bf16-stored (forward activation of bf16 precision)
   int bf;          // bf16 precision mode: operands rounded to bf16, 16 voxels per v_mfma_f32_32x32x16_bf16
 };
 
+template <bool PBF>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
   extern __shared__ float lds[];
   constexpr int TZ = 4, TY = 4, TX = 8, MT = 128;
@@ -677,7 +890,8 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
       }
     }
     {  // P tile
-      const float* pb = a.p + (long long)n * a.psn;
+      const float* pb = a.p;
+      const long long pbo = (long long)n * a.psn;
       if (a.pvec4) {
         const int cv = tid & 7, c = cb0 + cv * 4;
         float sc[4], sh[4];
@@ -689,7 +903,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
           const int v = (tid >> 3) + 32 * q;
           const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
           const int oz = min(oz0 + zl, a.Dp - 1), oy = min(oy0 + yl, a.Hp - 1), ox = min(ox0 + xl, a.Wp - 1);
-          praw[q] = *reinterpret_cast<const float4*>(pb + oz * a.psd + oy * a.psh + ox * a.psw + cl4);
+          praw[q] = ld4_t<PBF>(pb, pbo + (long long)oz * a.psd + (long long)oy * a.psh + (long long)ox * a.psw + cl4);
         }
 #pragma unroll
         for (int q = 0; q < MT / 32; ++q) {
@@ -715,7 +929,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
           const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
           float val = 0.f;
           if (oz < a.Dp && oy < a.Hp && ox < a.Wp && c < a.Cb)
-            val = nl_apply(pb[oz * a.psd + oy * a.psh + ox * a.psw + c], sc, sh, a.tp.relu);
+            val = nl_apply(ld1_t<PBF>(pb, pbo + (long long)oz * a.psd + (long long)oy * a.psh + (long long)ox * a.psw + c), sc, sh, a.tp.relu);
           pl[v * 32 + cc] = val;
         }
       }
@@ -1052,12 +1266,12 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   return MMTTA_OK;
 }
 
-template <int TZ, int TY, int TX, int NTW>
-static int launch_wgrad(const WArgs& a, int S, hipStream_t s) {
+template <int TZ, int TY, int TX, int NTW, bool GBF, bool DBF>
+static int launch_wgrad_t(const WArgs& a, int S, hipStream_t s) {
   const int ext = a.ntaps == 1 ? 0 : 2;
   const int BZ = (TZ - 1) * a.si + ext + 1, BY = (TY - 1) * a.si + ext + 1, BX = (TX - 1) * a.si + ext + 1;
   const size_t lds = ((size_t)BZ * BY * BX + TZ * TY * TX) * 32 * sizeof(float);
-  auto kern = wgrad_f32_kernel<TZ, TY, TX, NTW>;
+  auto kern = wgrad_f32_kernel<TZ, TY, TX, NTW, GBF, DBF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1066,6 +1280,14 @@ static int launch_wgrad(const WArgs& a, int S, hipStream_t s) {
   dim3 grid(S, a.CGp / 32, a.CDp / 32);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   return launch_status("conv wgrad");
+}
+
+template <int TZ, int TY, int TX, int NTW>
+static int launch_wgrad(const WArgs& a, int S, hipStream_t s) {
+  MMTTA_CHECK(!(a.g_bf && a.d_bf), MMTTA_ERR_UNSUPPORTED, "wgrad: both operands bf16-stored");
+  if (a.g_bf) return launch_wgrad_t<TZ, TY, TX, NTW, true, false>(a, S, s);
+  if (a.d_bf) return launch_wgrad_t<TZ, TY, TX, NTW, false, true>(a, S, s);
+  return launch_wgrad_t<TZ, TY, TX, NTW, false, false>(a, S, s);
 }
 
 }  // namespace mmtta
@@ -1102,6 +1324,7 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
               (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
   if (w.tiny) {
+    MMTTA_CHECK(is_f32(x) && is_f32(dy), MMTTA_ERR_UNSUPPORTED, "wgrad (tiny layer): fp32-stored tensors only");
     WTArgs t;
     t.x = tv(x); t.tx = nl(x_norm); t.dy = tv(dy);
     t.part = (float*)workspace; t.ld = 27 * d->cin * d->cout;
@@ -1133,11 +1356,15 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
       return ((((uintptr_t)t->ptr) % 16 == 0) && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0) ? 1 : 0;
     };
     b.qvec4 = al4(w.q); b.pvec4 = al4(w.pb);
+    MMTTA_CHECK(is_f32(w.q), MMTTA_ERR_UNSUPPORTED, "wgrad (thin layer): the <= 4-channel tensor must be fp32-stored");
+    b.p_bf = is_bf16(w.pb) ? 1 : 0;
+    if (b.p_bf) b.pvec4 = (((uintptr_t)w.pb->ptr) % 8 == 0 && w.pb->sw % 4 == 0 && w.pb->sh % 4 == 0 && w.pb->sd % 4 == 0 && w.pb->sn % 4 == 0) ? 1 : 0;
     b.bf = (d->dtype == MMTTA_BF16 && w.ntaps == 27) ? 1 : 0;
     const int ext = w.ntaps == 1 ? 0 : 2;
     const int BZ = 3 * w.si + ext + 1, BY = 3 * w.si + ext + 1, BX = 7 * w.si + ext + 1;
     const size_t lds = ((size_t)BZ * BY * BX * 4 + 128 * 32) * sizeof(float);
-    hipLaunchKernelGGL(wgrad_small_kernel, dim3(w.S, w.CDp / 32), dim3(256), lds, s, b);
+    if (b.p_bf) hipLaunchKernelGGL(wgrad_small_kernel<true>, dim3(w.S, w.CDp / 32), dim3(256), lds, s, b);
+    else hipLaunchKernelGGL(wgrad_small_kernel<false>, dim3(w.S, w.CDp / 32), dim3(256), lds, s, b);
     st = launch_status("wgrad small");
     if (st || g_profile_main_only) return st;
     const int total = w.ntaps * b.Cs * b.Cb;
@@ -1184,9 +1411,11 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   a.dbpart = (db != nullptr && !w.convt) ? dbws : nullptr;
   a.tz = w.tz; a.ty = w.ty; a.tx = w.tx; a.tiles = w.tiles; a.tiles_per_split = w.tps;
   a.CGp = w.CGp; a.CDp = w.CDp;
-  a.gvec4 = ((((uintptr_t)w.g->ptr) % 16 == 0) && w.g->sw % 4 == 0 && w.g->sh % 4 == 0 && w.g->sd % 4 == 0 &&
+  a.g_bf = is_bf16(w.g) ? 1 : 0;
+  a.d_bf = is_bf16(w.dn) ? 1 : 0;
+  a.gvec4 = ((((uintptr_t)w.g->ptr) % (a.g_bf ? 8 : 16) == 0) && w.g->sw % 4 == 0 && w.g->sh % 4 == 0 && w.g->sd % 4 == 0 &&
              w.g->sn % 4 == 0) ? 1 : 0;
-  a.dvec4 = ((((uintptr_t)w.dn->ptr) % 16 == 0) && w.dn->sw % 4 == 0 && w.dn->sh % 4 == 0 && w.dn->sd % 4 == 0 &&
+  a.dvec4 = ((((uintptr_t)w.dn->ptr) % (a.d_bf ? 8 : 16) == 0) && w.dn->sw % 4 == 0 && w.dn->sh % 4 == 0 && w.dn->sd % 4 == 0 &&
              w.dn->sn % 4 == 0) ? 1 : 0;
   if (w.bf16) st = (w.si == 1) ? launch_wgrad_bf16<4, 4, 1>(a, w.S, s) : launch_wgrad_bf16<2, 4, 2>(a, w.S, s);
   else if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, w.S, s);

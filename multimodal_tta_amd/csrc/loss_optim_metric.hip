@@ -407,6 +407,8 @@ extern "C" int64_t mmtta_entropy_partials(const mmtta_tensor* logits) {
 
 extern "C" int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits, double* partial,
                                   float* loss, void* stream) {
+  MMTTA_CHECK(logits == nullptr || logits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_entropy_loss: `logits` must be fp32-stored");
+  MMTTA_CHECK(dlogits == nullptr || dlogits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_entropy_loss: `dlogits` must be fp32-stored");
   MMTTA_CHECK(logits && dlogits && partial && loss && logits->ptr && dlogits->ptr, MMTTA_ERR_INVALID, "entropy: null argument");
   MMTTA_CHECK(logits->n == dlogits->n && logits->c == dlogits->c && logits->d == dlogits->d && logits->h == dlogits->h &&
                   logits->w == dlogits->w, MMTTA_ERR_INVALID, "entropy: shape mismatch");
@@ -479,6 +481,8 @@ extern "C" int mmtta_optim_step(const mmtta_optim_desc* d, float* p, const float
 
 extern "C" int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label, float threshold, int64_t* counts,
                                       uint8_t* mask, void* stream) {
+  MMTTA_CHECK(logits == nullptr || logits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_mask_dice_counts: `logits` must be fp32-stored");
+  MMTTA_CHECK(label == nullptr || label->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_mask_dice_counts: `label` must be fp32-stored");
   MMTTA_CHECK(logits && label && counts && logits->ptr && label->ptr, MMTTA_ERR_INVALID, "dice: null argument");
   MMTTA_CHECK(logits->n == label->n && logits->c == label->c && logits->d == label->d && logits->h == label->h &&
                   logits->w == label->w, MMTTA_ERR_INVALID, "dice: logits/label shape mismatch");
@@ -513,6 +517,8 @@ extern "C" int64_t mmtta_dice_ce_scratch_bytes(const mmtta_tensor* logits) {
 
 extern "C" int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight,
                                   int squared_pred, double* out, void* scratch, void* stream) {
+  MMTTA_CHECK(logits == nullptr || logits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_dice_ce_sums: `logits` must be fp32-stored");
+  MMTTA_CHECK(label == nullptr || label->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_dice_ce_sums: `label` must be fp32-stored");
   MMTTA_CHECK(logits && label && out && scratch && logits->ptr && label->ptr, MMTTA_ERR_INVALID, "dice_ce: null argument");
   MMTTA_CHECK(logits->n == label->n && logits->c == label->c && logits->d == label->d && logits->h == label->h &&
                   logits->w == label->w, MMTTA_ERR_INVALID, "dice_ce: logits/label shape mismatch");
@@ -531,6 +537,9 @@ extern "C" int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor
 extern "C" int mmtta_dice_ce_grad(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight, int squared_pred,
                                   int jaccard, int include_background, float lambda_dice, float lambda_ce, float smooth_nr,
                                   float smooth_dr, const double* sums, const mmtta_tensor* dlogits, void* stream) {
+  MMTTA_CHECK(logits == nullptr || logits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_dice_ce_grad: `logits` must be fp32-stored");
+  MMTTA_CHECK(label == nullptr || label->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_dice_ce_grad: `label` must be fp32-stored");
+  MMTTA_CHECK(dlogits == nullptr || dlogits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_dice_ce_grad: `dlogits` must be fp32-stored");
   MMTTA_CHECK(logits && label && dlogits && sums && logits->ptr && label->ptr && dlogits->ptr, MMTTA_ERR_INVALID,
               "dice_ce grad: null argument");
   MMTTA_CHECK(logits->n == label->n && logits->c == label->c && logits->d == label->d && logits->h == label->h &&

@@ -47,7 +47,7 @@ struct RedArgs {
 
 // VEC = 4: every thread owns 4 consecutive channels (16-byte loads); VEC = 1: scalar fallback.
 // `regular` tensors (dense voxel order: sh == W*sw, sd == H*sh) are addressed as voxel*sw, no div/mod.
-template <int MODE, int VEC>
+template <int MODE, int VEC, bool XBF = false>
 __global__ __launch_bounds__(256) void channel_reduce_kernel(RedArgs a) {
   __shared__ float red[2][VEC][256];
   const int C = a.x.c;
@@ -93,14 +93,14 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(RedArgs a) {
         }
         float xv[VEC], dv[VEC];
         if (VEC == 4) {
-          const float4 t4 = *reinterpret_cast<const float4*>(a.x.p + ax + c0);
+          const float4 t4 = ld4_t<XBF>(a.x.p, ax + c0);               // the pre-norm activation may be bf16-stored
           xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w;
           if (MODE == 1) {
             const float4 d4 = *reinterpret_cast<const float4*>(a.dout.p + ad + c0);
             dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
           }
         } else {
-          xv[0] = a.x.p[ax + c0];
+          xv[0] = ld1_t<XBF>(a.x.p, ax + c0);
           if (MODE == 1) dv[0] = a.dout.p[ad + c0];
         }
 #pragma unroll
@@ -303,7 +303,7 @@ struct EwArgs {
 
 // MODE 0: combine  out = Ta(a) + Tb(b)
 // MODE 1: norm bwd apply: a = dout, b = y, T = ta(on y)   out = rstd*(g*dz - m1 - xhat*m2)
-template <int MODE, int VEC>
+template <int MODE, int VEC, bool ABF = false, bool BBF = false, bool OBF = false>
 __global__ __launch_bounds__(256) void elementwise_kernel(EwArgs e) {
   const int C = e.o.c;
   const int CV = (C + VEC - 1) / VEC;
@@ -316,15 +316,16 @@ __global__ __launch_bounds__(256) void elementwise_kernel(EwArgs e) {
     int n, z, y, x;
     vox_decompose(e.o, v, n, z, y, x);
     float av[VEC], bv[VEC], ov[VEC];
-    const float* ap = e.a.p + vox_addr(e.a, n, z, y, x) + c0;
-    const float* bp = e.hasb ? e.b.p + vox_addr(e.b, n, z, y, x) + c0 : nullptr;
+    const long long ao = vox_addr(e.a, n, z, y, x) + c0;
+    const long long bo = e.hasb ? vox_addr(e.b, n, z, y, x) + c0 : 0;
+    const bool bp = e.hasb != 0;
     if (VEC == 4) {
-      const float4 t = *reinterpret_cast<const float4*>(ap);
+      const float4 t = ld4_t<ABF>(e.a.p, ao);
       av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-      if (bp) { const float4 u = *reinterpret_cast<const float4*>(bp); bv[0] = u.x; bv[1] = u.y; bv[2] = u.z; bv[3] = u.w; }
+      if (bp) { const float4 u = ld4_t<BBF>(e.b.p, bo); bv[0] = u.x; bv[1] = u.y; bv[2] = u.z; bv[3] = u.w; }
     } else {
-      av[0] = ap[0];
-      if (bp) bv[0] = bp[0];
+      av[0] = ld1_t<ABF>(e.a.p, ao);
+      if (bp) bv[0] = ld1_t<BBF>(e.b.p, bo);
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -350,9 +351,9 @@ __global__ __launch_bounds__(256) void elementwise_kernel(EwArgs e) {
         ov[j] = rs * (g * dz - e.m1[n * C + cc] - xhat * e.m2[n * C + cc]);
       }
     }
-    float* op = e.o.p + vox_addr(e.o, n, z, y, x) + c0;
-    if (VEC == 4) *reinterpret_cast<float4*>(op) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-    else op[0] = ov[0];
+    const long long oo = vox_addr(e.o, n, z, y, x) + c0;
+    if (VEC == 4) st4_t<OBF>(e.o.p, oo, make_float4(ov[0], ov[1], ov[2], ov[3]));
+    else st1_t<OBF>(e.o.p, oo, ov[0]);
   }
 }
 
@@ -533,7 +534,8 @@ static inline int grid_for(long long total, int cap = 8192) {
 // 16-byte access to 4 channels at a time.  C need not be a multiple of 4 when the voxel row is padded to one
 // (sw >= roundup(C,4)): READING the pad lanes is always harmless; WRITING them needs a view that owns its pad.
 static inline bool vec4_rd(const mmtta_tensor* t) {
-  return ((uintptr_t)t->ptr) % 16 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 && t->sc == 1 &&
+  return ((uintptr_t)t->ptr) % (t->dtype == MMTTA_BF16 ? 8 : 16) == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 &&
+         t->sn % 4 == 0 && t->sc == 1 &&
          (t->c % 4 == 0 || t->sw >= (t->c + 3) / 4 * 4);
 }
 static inline bool vec4_wr(const mmtta_tensor* t) {
@@ -573,6 +575,8 @@ int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s) {
 using namespace mmtta;
 
 extern "C" int mmtta_copy_strided(const mmtta_tensor* src, const mmtta_tensor* dst, void* stream) {
+  MMTTA_CHECK(src == nullptr || src->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_copy_strided: `src` must be fp32-stored");
+  MMTTA_CHECK(dst == nullptr || dst->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_copy_strided: `dst` must be fp32-stored");
   MMTTA_CHECK(src && dst && src->ptr && dst->ptr, MMTTA_ERR_INVALID, "copy: null tensor");
   MMTTA_CHECK(same_shape(src, dst), MMTTA_ERR_INVALID, "copy: shape mismatch");
   const long long total = (long long)dst->n * dst->c * dst->d * dst->h * dst->w;
@@ -588,6 +592,7 @@ extern "C" int mmtta_reduce_rows_per_n(const mmtta_tensor* t) {
 }
 
 extern "C" int mmtta_channel_stats(const mmtta_tensor* x, float* part, void* stream) {
+  MMTTA_CHECK(x == nullptr || x->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_channel_stats: `x` must be fp32-stored");
   MMTTA_CHECK(x && x->ptr && part, MMTTA_ERR_INVALID, "channel_stats: null argument");
   MMTTA_CHECK(is_cl(x), MMTTA_ERR_UNSUPPORTED, "channel_stats: tensor must be channels-last");
   RedArgs a;
@@ -642,20 +647,39 @@ extern "C" int mmtta_combine(const mmtta_tensor* a, const mmtta_norm_on_load* ta
   e.a = tv(a); e.b = b ? tv(b) : tv(a); e.o = tv(out); e.ta = nl(ta); e.tb = nl(tb); e.m1 = e.m2 = nullptr; e.hasb = b ? 1 : 0;
   const bool v4 = vec4_rd(a) && vec4_wr(out) && (!b || vec4_rd(b));
   const long long total = (long long)out->n * out->d * out->h * out->w * (v4 ? (out->c + 3) / 4 : out->c);
-  if (v4) hipLaunchKernelGGL((elementwise_kernel<0, 4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
-  else hipLaunchKernelGGL((elementwise_kernel<0, 1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
+  // storage: all fp32, or all bf16 (the wide forward activations of bf16 precision)
+  const bool abf = is_bf16(a), bbf = b ? is_bf16(b) : abf, obf = is_bf16(out);
+  MMTTA_CHECK((abf == bbf && bbf == obf), MMTTA_ERR_UNSUPPORTED, "combine: operands must share one storage type");
+  const dim3 grid(grid_for(total));
+  hipStream_t s = (hipStream_t)stream;
+  if (abf) {
+    if (v4) hipLaunchKernelGGL((elementwise_kernel<0, 4, true, true, true>), grid, dim3(256), 0, s, e);
+    else hipLaunchKernelGGL((elementwise_kernel<0, 1, true, true, true>), grid, dim3(256), 0, s, e);
+  } else {
+    if (v4) hipLaunchKernelGGL((elementwise_kernel<0, 4>), grid, dim3(256), 0, s, e);
+    else hipLaunchKernelGGL((elementwise_kernel<0, 1>), grid, dim3(256), 0, s, e);
+  }
   return launch_status("combine");
 }
 
 extern "C" int mmtta_norm_bwd_reduce(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
                                      float* part, void* stream) {
+  MMTTA_CHECK(dout == nullptr || dout->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_norm_bwd_reduce: `dout` must be fp32-stored");
   MMTTA_CHECK(dout && y && t && part && dout->ptr && y->ptr && t->mean && t->rstd, MMTTA_ERR_INVALID, "norm bwd reduce: null argument");
   MMTTA_CHECK(same_shape(dout, y) && is_cl(dout) && is_cl(y), MMTTA_ERR_INVALID, "norm bwd reduce: shape/layout mismatch");
   RedArgs a;
   a.x = tv(y); a.dout = tv(dout); a.t = nl(t); a.part = part;
   rows_geometry(y, a.rows_per_n, a.vox_per_row);
-  if (vec4_rd(y) && vec4_rd(dout)) hipLaunchKernelGGL((channel_reduce_kernel<1, 4>), dim3(y->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((channel_reduce_kernel<1, 1>), dim3(y->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(y->n * a.rows_per_n);
+  hipStream_t s = (hipStream_t)stream;
+  const bool v4 = vec4_rd(y) && vec4_rd(dout);
+  if (is_bf16(y)) {
+    if (v4) hipLaunchKernelGGL((channel_reduce_kernel<1, 4, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((channel_reduce_kernel<1, 1, true>), grid, dim3(256), 0, s, a);
+  } else {
+    if (v4) hipLaunchKernelGGL((channel_reduce_kernel<1, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((channel_reduce_kernel<1, 1>), grid, dim3(256), 0, s, a);
+  }
   return launch_status("norm bwd reduce");
 }
 
@@ -684,6 +708,8 @@ extern "C" int mmtta_norm_bwd_finalize(int kind, int groups, const float* part, 
 
 extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
                                     const float* m1, const float* m2, const mmtta_tensor* dy, void* stream) {
+  MMTTA_CHECK(dout == nullptr || dout->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_norm_bwd_apply: `dout` must be fp32-stored");
+  MMTTA_CHECK(dy == nullptr || dy->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_norm_bwd_apply: `dy` must be fp32-stored");
   MMTTA_CHECK(dout && y && t && dy && m1 && m2 && t->mean && t->rstd, MMTTA_ERR_INVALID, "norm bwd apply: null argument");
   MMTTA_CHECK(same_shape(dout, y) && same_shape(dy, y), MMTTA_ERR_INVALID, "norm bwd apply: shape mismatch");
   MMTTA_CHECK(is_cl(dout) && is_cl(y) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "norm bwd apply: channels-last only");
@@ -691,12 +717,21 @@ extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor
   e.a = tv(dout); e.b = tv(y); e.o = tv(dy); e.ta = nl(t); e.tb = nl(nullptr); e.m1 = m1; e.m2 = m2; e.hasb = 1;
   const bool v4 = vec4_rd(dout) && vec4_rd(y) && vec4_wr(dy);
   const long long total = (long long)y->n * y->d * y->h * y->w * (v4 ? (y->c + 3) / 4 : y->c);
-  if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
-  else hipLaunchKernelGGL((elementwise_kernel<1, 1>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, e);
+  const dim3 grid(grid_for(total));
+  hipStream_t s = (hipStream_t)stream;
+  if (is_bf16(y)) {
+    if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4, false, true, false>), grid, dim3(256), 0, s, e);
+    else hipLaunchKernelGGL((elementwise_kernel<1, 1, false, true, false>), grid, dim3(256), 0, s, e);
+  } else {
+    if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4>), grid, dim3(256), 0, s, e);
+    else hipLaunchKernelGGL((elementwise_kernel<1, 1>), grid, dim3(256), 0, s, e);
+  }
   return launch_status("norm bwd apply");
 }
 
 extern "C" int mmtta_upsample2x_fwd(const mmtta_tensor* x, const mmtta_tensor* y, void* stream) {
+  MMTTA_CHECK(x == nullptr || x->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_fwd: `x` must be fp32-stored");
+  MMTTA_CHECK(y == nullptr || y->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_fwd: `y` must be fp32-stored");
   MMTTA_CHECK(x && y && x->ptr && y->ptr, MMTTA_ERR_INVALID, "upsample: null tensor");
   MMTTA_CHECK(y->n == x->n && y->c == x->c && y->d == 2 * x->d && y->h == 2 * x->h && y->w == 2 * x->w, MMTTA_ERR_INVALID,
               "upsample: y must be exactly 2x of x");
@@ -709,6 +744,8 @@ extern "C" int mmtta_upsample2x_fwd(const mmtta_tensor* x, const mmtta_tensor* y
 }
 
 extern "C" int mmtta_upsample2x_bwd(const mmtta_tensor* dy, const mmtta_tensor* dx, int accumulate, void* stream) {
+  MMTTA_CHECK(dy == nullptr || dy->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_bwd: `dy` must be fp32-stored");
+  MMTTA_CHECK(dx == nullptr || dx->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_bwd: `dx` must be fp32-stored");
   MMTTA_CHECK(dx && dy && dx->ptr && dy->ptr, MMTTA_ERR_INVALID, "upsample bwd: null tensor");
   MMTTA_CHECK(dy->n == dx->n && dy->c == dx->c && dy->d == 2 * dx->d && dy->h == 2 * dx->h && dy->w == 2 * dx->w,
               MMTTA_ERR_INVALID, "upsample bwd: dy must be exactly 2x of dx");
@@ -722,6 +759,9 @@ extern "C" int mmtta_upsample2x_bwd(const mmtta_tensor* dy, const mmtta_tensor* 
 
 extern "C" int mmtta_lincomb(int count, const mmtta_tensor* const* in, const float* w, const mmtta_tensor* out,
                              int accumulate, void* stream) {
+  MMTTA_CHECK(out == nullptr || out->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "lincomb: fp32-stored tensors only");
+  for (int i = 0; in != nullptr && i < count; ++i)
+    MMTTA_CHECK(in[i] == nullptr || in[i]->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "lincomb: fp32-stored tensors only");
   MMTTA_CHECK(count >= 1 && count <= 8 && in && w && out && out->ptr, MMTTA_ERR_INVALID, "lincomb: bad argument");
   LinArgs e;
   bool v4 = vec4_wr(out);

@@ -99,6 +99,7 @@ extern "C" int64_t mmtta_intensity_scratch_bytes(int channels) {
 
 extern "C" int mmtta_intensity_normalize(const mmtta_tensor* x, const mmtta_intensity_rule* rules, const mmtta_tensor* y,
                                          void* scratch, void* stream) {
+  MMTTA_CHECK(x == nullptr || x->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_intensity_normalize: `x` must be fp32-stored");
   MMTTA_CHECK(x && y && rules && scratch && x->ptr && y->ptr, MMTTA_ERR_INVALID, "intensity: null argument");
   MMTTA_CHECK(x->n == 1 && y->n == 1, MMTTA_ERR_UNSUPPORTED, "intensity: one image per call (statistics are per image)");
   MMTTA_CHECK(x->c == y->c && x->d == y->d && x->h == y->h && x->w == y->w, MMTTA_ERR_INVALID, "intensity: shape mismatch");

@@ -259,6 +259,7 @@ extern "C" int64_t mmtta_surface_scratch_bytes(int64_t n_masks, int64_t d, int64
 extern "C" int mmtta_surface_distances(const uint8_t* pred_mask, const mmtta_tensor* label, const double* spacing,
                                        double percentile, int asd_symmetric, float* hd, float* asd, void* scratch,
                                        void* stream) {
+  MMTTA_CHECK(label == nullptr || label->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_surface_distances: `label` must be fp32-stored");
   MMTTA_CHECK(pred_mask && label && label->ptr && spacing && hd && asd && scratch, MMTTA_ERR_INVALID, "surface: null argument");
   MMTTA_CHECK(label->n >= 1 && label->c >= 1 && label->d >= 1 && label->h >= 1 && label->w >= 1, MMTTA_ERR_INVALID,
               "surface: empty label tensor");

@@ -116,13 +116,13 @@ class Pool:
         self.device = device
         self._b: Dict[Tuple, torch.Tensor] = {}
 
-    def cl(self, key, n, d, h, w, c, ldc=None, zero=False) -> torch.Tensor:
+    def cl(self, key, n, d, h, w, c, ldc=None, zero=False, dtype: torch.dtype = torch.float32) -> torch.Tensor:
         if ldc is None:
-            ldc = (c + 3) // 4 * 4       # 16-byte voxel rows: one aligned vector access per 4 channels, for any C
-        k = ("cl", key, n, d, h, w, c, ldc)
+            ldc = ops.row_pad(c, dtype)  # aligned vector accesses per 4 (fp32) / 8 (bf16) channels, for any C
+        k = ("cl", key, n, d, h, w, c, ldc, dtype)
         t = self._b.get(k)
         if t is None:
-            t = ops.new_cl(n, d, h, w, c, self.device, ldc, zero=zero)
+            t = ops.new_cl(n, d, h, w, c, self.device, ldc, zero=zero, dtype=dtype)
             self._b[k] = t
         return t
 
@@ -241,7 +241,7 @@ class ConvolutionBlock(Block):
         op, pool = self.conv.op, self.rt.pool
         n, d, h, w, c = op.out_shape(x)
         if y is None:
-            y = pool.cl((self.key, "y"), n, d, h, w, c)
+            y = pool.cl((self.key, "y"), n, d, h, w, c, dtype=self.rt.act_dtype(c))
         nl = None
         if self.norm is not None:
             rows = op.stats_rows(x, y)
@@ -328,6 +328,9 @@ class Runtime:
         self.device = device
         self.conv_dtype = conv_dtype   # ops.F32: exact fp32 MFMA; ops.BF16: bf16 operands / fp32 accumulate
         self.pool = Pool(device)
+        # forward activations of more than 4 channels stored as bf16 (torch-autocast style): set by runtimes whose every
+        # layer kind has storage-agnostic kernels (models/unet.py); gradients, logits, statistics, weights stay fp32
+        self.act_bf16 = False
         self.training = False
         self.overlap_wgrad = True      # weight gradients on a side stream (joined before the optimizer)
         self.n_side = 2                # layers alternate between the side streams (a layer always uses the same one)
@@ -337,6 +340,10 @@ class Runtime:
         self.refs: List[ParamRef] = []
         self.buffers: List[torch.nn.Module] = []     # modules owning running statistics (BatchNorm)
         self.arena: Optional[Arena] = None
+
+    def act_dtype(self, channels: int) -> torch.dtype:
+        """Storage type of a forward activation with `channels` channels."""
+        return torch.bfloat16 if (self.act_bf16 and channels > 4) else torch.float32
 
     # -- construction helpers
     def make_ref(self, name: str, param: torch.nn.Parameter) -> ParamRef:

@@ -56,15 +56,21 @@ class HipSegModel(nn.Module):
         self.conv_dtype = ops.F32
 
     # ---- engine binding
-    def set_precision(self, precision: str) -> None:
-        """'fp32': exact fp32 MFMA everywhere (the parity path).  'bf16': forward / input-gradient convolutions
-        round their operands to bf16 and accumulate in fp32; storage, norms, loss, weight gradients and the
-        optimizer stay fp32."""
+    def set_precision(self, precision: str, storage: Optional[str] = None) -> None:
+        """'fp32': exact fp32 MFMA everywhere, fp32 storage (the parity path).  'bf16': forward, input-gradient and
+        27-tap weight-gradient convolutions round their operands to bf16 and accumulate in fp32; norms, loss, the
+        optimizer and the master weights stay fp32.  ``storage`` (bf16 precision only): 'bf16' (default) keeps the wide
+        forward activations in HBM as bf16 - what torch autocast does - where the model's runtime supports it;
+        'fp32' keeps every tensor fp32 (round-1 behaviour)."""
         if precision not in ops.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(ops.PRECISIONS)}, got {precision!r}")
+        storage = "bf16" if storage is None else str(storage).lower()
+        if storage not in ("bf16", "fp32"):
+            raise ValueError(f"storage must be 'bf16' or 'fp32', got {storage!r}")
         dt = ops.PRECISIONS[precision]
-        if dt != self.conv_dtype:
+        if dt != self.conv_dtype or storage != getattr(self, "act_storage", "bf16"):
             self.conv_dtype = dt
+            self.act_storage = storage
             self._rt = None
 
     def configure_training(self, trainable: Optional[Set[str]] = None,

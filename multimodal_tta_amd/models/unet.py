@@ -30,6 +30,15 @@ class UNetRuntime(Runtime):
         self.channels, self.strides = list(model.channels), list(model.strides)
         self.nru = model.num_res_units
         self.in_channels, self.out_channels = model.in_channels, model.out_channels
+        # bf16 precision stores the wide forward activations as bf16 (method.storage: bf16, the default of that
+        # precision): every layer kind of the residual INSTANCE-norm U-Net has storage-agnostic kernels
+        norm_name = model.norm[0] if isinstance(model.norm, (tuple, list)) else model.norm
+        # (the thin first / last layers run on dedicated kernels: 4 -> 32|64 channels in, <= 4 out; narrower toy networks
+        # take generic direct kernels that work on fp32-stored tensors only and keep fp32 storage)
+        self.act_bf16 = (model.conv_dtype == ops.BF16 and getattr(model, "act_storage", "bf16") == "bf16" and self.nru > 0
+                         and str(norm_name).upper() == "INSTANCE" and self.channels[0] in (32, 64)
+                         and all(c % 8 == 0 and c >= 32 for c in self.channels)
+                         and self.in_channels <= 4 and self.out_channels <= 4)
         L = len(self.strides)
         self.L = L
         self.down: List[Any] = []
@@ -63,7 +72,8 @@ class UNetRuntime(Runtime):
         c = self.channels
         width = 2 * c[i] if i < self.L - 1 else c[i] + c[i + 1]
         d, h, w = dims[i]
-        return self.pool.cl(("dcat" if grad else "cat", i), n, d, h, w, width)
+        return self.pool.cl(("dcat" if grad else "cat", i), n, d, h, w, width,
+                            dtype=torch.float32 if grad else self.act_dtype(width))
 
     def _level_dims(self, d, h, w):
         dims = []

@@ -130,10 +130,19 @@ def _nl_ref(nl: Optional[NL]):
 
 
 # ----------------------------------------------------------------------------- layout
-def new_cl(n: int, d: int, h: int, w: int, c: int, device, ldc: Optional[int] = None, zero: bool = False) -> torch.Tensor:
+def row_pad(c: int, dtype: torch.dtype = torch.float32) -> int:
+    """Padded channel count of a voxel row: 16-byte rows for fp32 (4 channels), and for bf16 rows of more than 4 channels
+    (8 channels: the implicit GEMM stages 8 channels per 16-byte load); a bf16 row of <= 4 channels is 8 bytes."""
+    if dtype == torch.bfloat16 and c > 4:
+        return (c + 7) // 8 * 8
+    return (c + 3) // 4 * 4
+
+
+def new_cl(n: int, d: int, h: int, w: int, c: int, device, ldc: Optional[int] = None, zero: bool = False,
+           dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """Allocate a channels-last buffer [n,d,h,w,ldc] and return the [.., :c] view."""
     ldc = c if ldc is None else ldc
-    buf = (torch.zeros if zero else torch.empty)((n, d, h, w, ldc), dtype=torch.float32, device=device)
+    buf = (torch.zeros if zero else torch.empty)((n, d, h, w, ldc), dtype=dtype, device=device)
     if ldc == c:
         return buf
     view = buf[..., :c]

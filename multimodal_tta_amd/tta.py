@@ -76,6 +76,7 @@ class EntropyMinimizationTTA:
         self.episodic = bool(get_config(m, "episodic", True))
         self.params_spec = get_config(m, "params", "all")
         self.precision = str(get_config(m, "precision", "fp32")).lower()
+        self.storage = str(get_config(m, "storage", "bf16")).lower()      # activation storage of bf16 precision
         self.missing = [int(i) for i in (get_config(m, "missing_modalities", []) or [])]
         md = get_config(m, "moddrop", {}) or {}
         self.moddrop_p = float(get_config(md, "p", 0.0)) if bool(get_config(md, "enabled", False)) else 0.0
@@ -128,7 +129,7 @@ class EntropyMinimizationTTA:
         device = torch.device(device)
         self.model = model
         names = select_params(model, self.params_spec)
-        model.set_precision(self.precision)
+        model.set_precision(self.precision, self.storage)
         model.configure_training(set(names), self.no_decay_keys, self.treat_1d)
         model.to(device)
         self.rt = model.runtime(device)

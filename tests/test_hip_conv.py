@@ -220,6 +220,60 @@ BF16_CASES = [
 ]
 
 
+def cl_bf16(x):
+    """NCDHW cpu fp32 -> bf16-stored channels-last cuda view (rows padded to 8 channels)."""
+    from multimodal_tta_amd import ops
+    n, c, d, h, w = x.shape
+    out = ops.new_cl(n, d, h, w, c, "cuda", ldc=ops.row_pad(c, torch.bfloat16), zero=True, dtype=torch.bfloat16)
+    out.copy_(x.permute(0, 2, 3, 4, 1).to(torch.bfloat16))
+    return out
+
+
+BF16_STORED = [c for c in BF16_CASES if c[0] >= 16 and c[1] > 4]      # layers whose input and output are "wide" activations
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", BF16_STORED)
+def test_conv_bf16_stored_activations(cin, cout, k, stride, transposed, shape):
+    """`bf16` precision with bf16 STORAGE of the forward activations (x read as bf16, y and the fused residual operand
+    written / read as bf16, statistics from the fp32 accumulators): forward, and the weight gradient reading the bf16 x,
+    against torch fp32 on the bf16-rounded input.  Bound: 1.5e-2 * max|ref| like the bf16-operand test (the output is
+    rounded once more when it is stored: 2^-9 relative)."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(77 + cin + cout)
+    n, d, h, w = shape
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = torch.randn(n, cin, d, h, w).to(torch.bfloat16).float()          # exactly representable: isolates the kernel
+    x.requires_grad_(True)
+    res = torch.randn_like(mod(x.detach())).to(torch.bfloat16).float()
+    y_ref = mod(x) + res
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+    wt = mod.weight.detach().cuda().contiguous()
+    op.pack(wt)
+    x_cl, r_cl = cl_bf16(x.detach()), cl_bf16(res)
+    y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda", ldc=ops.row_pad(cout, torch.bfloat16), dtype=torch.bfloat16)
+    rows = op.stats_rows(x_cl, y_cl)
+    stats = torch.empty((rows, 2, cout), device="cuda")
+    op.forward(x_cl, None, mod.bias.detach().cuda(), y_cl, stats=stats, add=r_cl)
+    dw = torch.empty_like(wt)
+    dbias = torch.empty(cout, device="cuda")
+    op.wgrad(x_cl, None, cl(gy), dw, dbias)
+    torch.cuda.synchronize()
+    assert y_cl.dtype == torch.bfloat16
+    got = y_cl.float().permute(0, 4, 1, 2, 3).cpu()
+    err = (got - y_ref.detach()).abs().max().item() / y_ref.abs().max().item()
+    assert err <= 1.5e-2, f"bf16-stored forward: {err:.3e}"
+    werr = (dw.cpu() - mod.weight.grad).abs().max().item() / mod.weight.grad.abs().max().item()
+    assert werr <= 1.5e-2, f"weight gradient from bf16-stored x: {werr:.3e}"
+    close("bias gradient", dbias, mod.bias.grad)
+    # statistics describe the fp32 values BEFORE the bf16 rounding of the store: compare with the stored tensor loosely
+    st = stats.view(n, rows // n, 2, cout).double().sum(1).cpu()
+    got_sum = got.double().sum(dim=(2, 3, 4))
+    assert torch.allclose(st[:, 0], got_sum, rtol=2e-2, atol=2e-2 * max(1.0, got.abs().sum(dim=(2, 3, 4)).max().item()) ** 0.5 + 1.0)
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", BF16_CASES)
 def test_conv_bf16_operands(cin, cout, k, stride, transposed, shape):
     """dtype=BF16: operands rounded to bf16 (8 significant bits), fp32 accumulation.  Against the fp32 torch
