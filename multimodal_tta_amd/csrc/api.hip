@@ -42,7 +42,7 @@ extern "C" int mmtta_set_option(int key, int value) {
   }
   if (key == MMTTA_OPT_WGRAD_VECTOR_STAGING) {
     const int prev = mmtta::g_wgrad_vec;
-    mmtta::g_wgrad_vec = value < 0 ? 0 : (value > 2 ? 2 : value);
+    mmtta::g_wgrad_vec = value < 0 ? 0 : (value > 3 ? 3 : value);
     return prev;
   }
   if (key == MMTTA_OPT_IGEMM_LEAN) {

@@ -34,6 +34,7 @@ struct WArgs {
   int CGp, CDp;
   int gvec4, dvec4;
   int g_bf, d_bf;   // storage of the gathered / dense tensor: 1 = bf16 elements (the forward activation of bf16 precision)
+  int diag;         // timing ablations of the transposed-read kernel (MMTTA_OPT_IGEMM_PIPELINE bits 1-3; results invalid)
 };
 
 // NTW = accumulators per wave: 7 for the 27-tap kernel (taps wave, wave+4, ...; slot 27 is a dummy that is
@@ -774,13 +775,273 @@ static int launch_wgrad_bf16v_t(const WArgs& a, int S, hipStream_t s) {
   return launch_status("conv wgrad bf16 (vector staging)");
 }
 
+// ------------------------------------------------------------------ transposed-read weight gradient (bf16 operands)
+// The kernels above keep the contraction index (voxels) contiguous per lane by transposing while staging: a thread owns
+// channels, walks x with element (or 4-channel) loads and writes three x-shifted [channel][voxel] copies.  gfx950 can do
+// that transpose in the LDS read instead (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns of 16-bit
+// elements and each lane receives one column), so here both operands sit in LDS exactly as they sit in HBM -
+// [voxel][32 channels] bf16, 64-byte rows - staged with 16-byte (bf16 storage: 8-byte) coalesced loads, ONE copy of the
+// gathered box, and a tap is a constant byte offset.  Lane l of the MFMA operand (column l & 31, k = 8 (l >> 5) + j)
+// receives, from two transposed reads, channel l & 31 of the 8 voxels x = 0..7 of tile row 2 ks + (l >> 5): the k order
+// is the same for A and B, which is all the contraction needs.  Every address in the k loop is lane base + immediate.
+// Stride 2: the box's x positions are stored even-first so that the stride-2 walk of a tap is contiguous (4 rows of a
+// transposed read 64 bytes apart: conflict-free), the same as stride 1.
+template <int TZ, int TY, int SI>
+struct WTGeo {
+  static constexpr int BZ = (TZ - 1) * SI + 3, BY = (TY - 1) * SI + 3, BX = 7 * SI + 3;
+  static constexpr int XH = (BX + 1) / 2;
+  static constexpr int NG = BZ * BY * BX, ND = TZ * TY * 8;
+  static constexpr int G_BYTES = NG * 64, D_BYTES = ND * 64;
+  static constexpr int LDS_BYTES = G_BYTES + D_BYTES;
+  static constexpr int NK = ND / 16;                  // k steps: two tile rows of 8 voxels each
+  __host__ __device__ static constexpr int xmap(int x) { return SI == 1 ? x : (x & 1) * XH + (x >> 1); }
+  __host__ __device__ static constexpr int tap_off(int tap) {        // bytes; tap = (kz*3 + ky)*3 + kx
+    return (((tap / 9) * BY + (tap / 3) % 3) * BX + xmap(tap % 3)) * 64;
+  }
+  __host__ __device__ static constexpr int row_off(int ks) {         // bytes; tile row 2 ks (the lane adds its half)
+    return ((((2 * ks) / TY) * SI * BY + ((2 * ks) % TY) * SI) * BX) * 64;
+  }
+};
+
+typedef short wshort4 __attribute__((ext_vector_type(4)));
+typedef short wshort8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) wshort4* wlds4_t;
+
+// 8 k values of one operand column: two transposed reads 4 voxels (256 bytes) apart
+#define MMTTA_TR_FRAG(ptr, off)                                                                          \
+  __builtin_bit_cast(wbf16x8, __builtin_shufflevector(__builtin_amdgcn_ds_read_tr16_b64_v4i16((wlds4_t)((ptr) + (off))),       \
+                                                      __builtin_amdgcn_ds_read_tr16_b64_v4i16((wlds4_t)((ptr) + (off) + 256)), \
+                                                      0, 1, 2, 3, 4, 5, 6, 7))
+
+// raw 4-channel quads (converted when they are committed: a conversion right behind the load would wait for it)
+template <bool BF> struct WQuad { typedef float4 T; };
+template <> struct WQuad<true> { typedef uint2 T; };
+template <bool BF> __device__ __forceinline__ typename WQuad<BF>::T wquad_ld(const float* base, long long eoff) {
+  if constexpr (BF) return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + eoff);
+  else return *reinterpret_cast<const float4*>(base + eoff);
+}
+__device__ __forceinline__ float4 wquad_f4(float4 q) { return q; }
+__device__ __forceinline__ float4 wquad_f4(uint2 u) {
+  return make_float4(bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu),
+                     bf16_bits_to_f32(u.y >> 16));
+}
+
+// Software pipeline over the tiles of a workgroup: the loads of tile i+1 - the whole dense tile and as many passes of the
+// gathered box as ~72 registers hold (all of them when the box is bf16-stored) - are issued right before tile i's MFMA
+// loop, which reads LDS only, and land under it; the passes that did not fit are issued first thing in tile i+1 and
+// land under the commit (transform, pack, LDS write) of the prefetched ones.  Without this a tile paid seven dependent
+// HBM round trips (4 loads in flight per thread): 11 us per 256-voxel tile for 1.8 us of MFMA.
+template <int TZ, int TY, int SI, bool GBF, bool DBF>
+__global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
+  using G = WTGeo<TZ, TY, SI>;
+  static_assert(TY % 2 == 0 && G::ND % 32 == 0, "a k step is two rows of one z slice; the D tile is staged 32 voxels a pass");
+  extern __shared__ float lds[];
+  unsigned char* gl = reinterpret_cast<unsigned char*>(lds);
+  unsigned char* dl = gl + G::G_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int cg0 = blockIdx.y * 32, cd0 = blockIdx.z * 32;
+  const int cq = tid & 7, vs = tid >> 3;        // staging: channel group (4 channels), voxel slot (32 voxels per pass)
+
+  // operand addresses: lane part (group row q, 8-byte column chunk, row half) + tap (A only)
+  const int lq = (lane & 15) >> 2, lp = lane & 3, lc = (lane >> 4) & 1;
+  const unsigned char* dread = dl + (h * 8 + lq) * 64 + lc * 32 + lp * 8;
+  const unsigned char* gread[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = min(wave + 4 * j, 26);
+    gread[j] = gl + (h * SI * G::BX + lq) * 64 + lc * 32 + lp * 8 + G::tap_off(tap);
+  }
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int t0 = sx * a.tiles_per_split;
+  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
+  const int tpn = a.tz * a.ty * a.tx;
+  const int gcb = cg0 + 4 * cq, dcb = cd0 + 4 * cq;
+  const int gcl = min(gcb, (a.Cg - 1) & ~3), dcl = min(dcb, (a.Cd - 1) & ~3);     // clamped (always valid) load channels
+  // channels past the tensor's last one stage as zeros: bit masks on the packed pairs (gathered) / the fp32 values (dense)
+  const unsigned gmask01 = (gcb + 0 < a.Cg ? 0xffffu : 0u) | (gcb + 1 < a.Cg ? 0xffff0000u : 0u);
+  const unsigned gmask23 = (gcb + 2 < a.Cg ? 0xffffu : 0u) | (gcb + 3 < a.Cg ? 0xffff0000u : 0u);
+  unsigned dmask[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dmask[c] = dcb + c < a.Cd ? 0xffffffffu : 0u;
+  constexpr int GP = (G::NG + 31) / 32, DP = G::ND / 32;
+  constexpr int PREF = (GBF || DBF) ? 48 : 32;                         // registers the cross-loop prefetch may hold (more spills)
+  constexpr int PGmax = (PREF - DP * (DBF ? 2 : 4)) / (GBF ? 2 : 4);
+  constexpr int PG = PGmax < GP ? PGmax : GP;                          // box passes prefetched across the MFMA loop
+  typename WQuad<GBF>::T gv[GP];
+  typename WQuad<DBF>::T dq[DP];
+  int pn = -1, poz0 = 0, poy0 = 0, pox0 = 0;     // tile whose loads are in gv[0..PG) / dq
+  int cn = -1;                                   // batch item the transform coefficients belong to
+  float gsc[4], gsh[4], dsc[4], dsh[4];
+
+  auto box_voxel = [&](int pass, int& bz, int& by, int& bx) {
+    // opaque per call: the decode depends on the thread only, so the compiler would hoist all GP of them (and the LDS
+    // addresses) out of the tile loop and hold ~4 registers per pass for the whole kernel (measured: 170-315 spills)
+    int vsl = vs;
+    asm volatile("" : "+v"(vsl));
+    const int bv = min(vsl + 32 * pass, G::NG - 1);
+    bz = bv / (G::BY * G::BX);
+    const int brem = bv - bz * (G::BY * G::BX);
+    by = brem / G::BX;
+    bx = brem - by * G::BX;
+  };
+  auto load_g = [&](int pass, int n, int iz0, int iy0, int ix0) {
+    int bz, by, bx;
+    box_voxel(pass, bz, by, bx);
+    gv[pass] = wquad_ld<GBF>(a.g, (long long)n * a.gsn + gcl + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd +
+                                      (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh +
+                                      (long long)min(max(ix0 + bx, 0), a.Wgg - 1) * a.gsw);
+  };
+  auto commit_g = [&](int pass, int iz0, int iy0, int ix0) {
+    if (vs + 32 * pass < G::NG) {
+      int bz, by, bx;
+      box_voxel(pass, bz, by, bx);
+      const bool ok = (unsigned)(iz0 + bz) < (unsigned)a.Dgg && (unsigned)(iy0 + by) < (unsigned)a.Hgg &&
+                      (unsigned)(ix0 + bx) < (unsigned)a.Wgg;
+      // branch-free: written as `ok ? f(v) : 0` hipcc branches around every channel (and reloads a spilled quad in each)
+      const unsigned okm = ok ? 0xffffffffu : 0u;
+      const float4 v = wquad_f4(gv[pass]);
+      uint2 pk;
+      pk.x = wpack2(nl_apply(v.x, gsc[0], gsh[0], a.tg.relu), nl_apply(v.y, gsc[1], gsh[1], a.tg.relu)) & (okm & gmask01);
+      pk.y = wpack2(nl_apply(v.z, gsc[2], gsh[2], a.tg.relu), nl_apply(v.w, gsc[3], gsh[3], a.tg.relu)) & (okm & gmask23);
+      const int bxm = SI == 1 ? bx : (bx & 1) * G::XH + (bx >> 1);
+      *reinterpret_cast<uint2*>(gl + ((bz * G::BY + by) * G::BX + bxm) * 64 + cq * 8) = pk;
+    }
+  };
+  auto issue = [&](int tile) {
+    pn = tile / tpn;
+    int t = tile % tpn;
+    const int txi = t % a.tx; t /= a.tx;
+    const int tyi = t % a.ty;
+    const int tzi = t / a.ty;
+    poz0 = tzi * TZ; poy0 = tyi * TY; pox0 = txi * 8;
+    const long long dno = (long long)pn * a.dsn + dcl;
+#pragma unroll
+    for (int p = 0; p < DP; ++p) {
+      const int dv = vs + 32 * p;
+      const int z = dv / (TY * 8), y = (dv >> 3) % TY, x = dv & 7;
+      dq[p] = wquad_ld<DBF>(a.dn, dno + (long long)min(poz0 + z, a.Dd - 1) * a.dsd + (long long)min(poy0 + y, a.Hd - 1) * a.dsh +
+                                      (long long)min(pox0 + x, a.Wd - 1) * a.dsw);
+    }
+#pragma unroll
+    for (int p = 0; p < PG; ++p) load_g(p, pn, poz0 * SI - 1, poy0 * SI - 1, pox0 * SI - 1);
+  };
+
+  if (t0 < t1) issue(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+    const int n = pn, oz0 = poz0, oy0 = poy0, ox0 = pox0;
+    const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
+#pragma unroll
+    for (int p = PG; p < GP; ++p) load_g(p, n, iz0, iy0, ix0);       // what the prefetch had no registers for
+    if (n != cn) {                                                    // per-(n, channel) transform: once per batch item
+      nl_coeff_vec<4>(a.td, n, a.Cd, dcb, dsc, dsh);
+      nl_coeff_vec<4>(a.tg, n, a.Cg, gcb, gsc, gsh);
+      cn = n;
+    }
+#pragma unroll
+    for (int p = 0; p < DP; ++p) {
+      const int dv = vs + 32 * p;
+      const int z = dv / (TY * 8), y = (dv >> 3) % TY, x = dv & 7;
+      const bool ok = oz0 + z < a.Dd && oy0 + y < a.Hd && ox0 + x < a.Wd;
+      const unsigned okm = ok ? 0xffffffffu : 0u;
+      const float4 v = wquad_f4(dq[p]);
+      const float w0 = __uint_as_float(__float_as_uint(nl_apply(v.x, dsc[0], dsh[0], a.td.relu)) & (okm & dmask[0]));
+      const float w1 = __uint_as_float(__float_as_uint(nl_apply(v.y, dsc[1], dsh[1], a.td.relu)) & (okm & dmask[1]));
+      const float w2 = __uint_as_float(__float_as_uint(nl_apply(v.z, dsc[2], dsh[2], a.td.relu)) & (okm & dmask[2]));
+      const float w3 = __uint_as_float(__float_as_uint(nl_apply(v.w, dsc[3], dsh[3], a.td.relu)) & (okm & dmask[3]));
+      dbs[0] += w0; dbs[1] += w1; dbs[2] += w2; dbs[3] += w3;
+      uint2 pk;
+      pk.x = wpack2(w0, w1); pk.y = wpack2(w2, w3);
+      *reinterpret_cast<uint2*>(dl + dv * 64 + cq * 8) = pk;
+    }
+#pragma unroll
+    for (int p = 0; p < GP; ++p) commit_g(p, iz0, iy0, ix0);
+    __syncthreads();
+    if (tile + 1 < t1) issue(tile + 1);                               // lands during the MFMAs below
+    // ---- MFMAs.  Fragment f = (k step, tap slot) is read LA MFMAs before it multiplies (a ring of LA + 1 register sets;
+    // a fence per MFMA, or the scheduler sinks every read to one MFMA ahead and the MFMA waits out the LDS latency)
+    constexpr int LA = 4, NF = G::NK * 7;
+    wbf16x8 ra[LA + 1], fb[2];
+    fb[0] = MMTTA_TR_FRAG(dread, 0);
+#pragma unroll
+    for (int f = 0; f < LA; ++f) ra[f] = MMTTA_TR_FRAG(gread[f % 7], G::row_off(f / 7));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int ks = f / 7, j = f % 7;
+      if (f + LA < NF) ra[(f + LA) % (LA + 1)] = MMTTA_TR_FRAG(gread[(f + LA) % 7], G::row_off((f + LA) / 7));
+      if (j == 2 && ks + 1 < G::NK) fb[(ks + 1) & 1] = MMTTA_TR_FRAG(dread, (ks + 1) * 1024);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[f % (LA + 1)], fb[ks & 1], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  const int sl = blockIdx.x;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = wave + 4 * j;
+    if (tap < 27) {
+      float* sb = a.slab + (((long long)sl * 27 + tap) * a.CGp + cg0) * a.CDp + cd0 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        sb[(long long)row * a.CDp] = acc[j][i];
+      }
+    }
+  }
+  if (a.dbpart != nullptr && blockIdx.y == 0) {     // bias gradient from the fp32 values seen while staging
+    float* red4 = lds;                              // the images are dead: the loop ended with a barrier
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red4[tid * 4 + c] = dbs[c];
+    __syncthreads();
+    if (tid < 32) {
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < 32; ++q) sacc += red4[((q << 3) | (tid >> 2)) * 4 + (tid & 3)];
+      a.dbpart[(long long)sl * a.CDp + cd0 + tid] = sacc;
+    }
+  }
+}
+
+template <int TZ, int TY, int SI, bool GBF, bool DBF>
+static int launch_wgrad_tr_t(const WArgs& a, int S, hipStream_t s) {
+  using G = WTGeo<TZ, TY, SI>;
+  auto kern = wgrad_tr_kernel<TZ, TY, SI, GBF, DBF>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(S, a.CGp / 32, a.CDp / 32);
+  hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, s, a);
+  return launch_status("conv wgrad bf16 (transposed reads)");
+}
+
+template <int TZ, int TY, int SI>
+static int launch_wgrad_tr(const WArgs& a, int S, hipStream_t s) {
+  MMTTA_CHECK(!(a.g_bf && a.d_bf), MMTTA_ERR_UNSUPPORTED, "wgrad: both operands bf16-stored");
+  MMTTA_CHECK(a.gvec4 && a.dvec4, MMTTA_ERR_INVALID, "wgrad: transposed-read kernel selected for unaligned tensors");
+  if (a.g_bf) return launch_wgrad_tr_t<TZ, TY, SI, true, false>(a, S, s);
+  if (a.d_bf) return launch_wgrad_tr_t<TZ, TY, SI, false, true>(a, S, s);
+  return launch_wgrad_tr_t<TZ, TY, SI, false, false>(a, S, s);
+}
+
 // one instantiation per storage combination (the forward activation may be bf16-stored, the gradient never is)
 template <int TZ, int TY, int SI>
 static int launch_wgrad_bf16(const WArgs& a, int S, hipStream_t s) {
   MMTTA_CHECK(!(a.g_bf && a.d_bf), MMTTA_ERR_UNSUPPORTED, "wgrad: both operands bf16-stored");
-  // measured (profiles/r02_wgrad_vector.txt): the vector loader wins with a bf16-stored operand (1189 -> 1116 us per
-  // step), the element loader with fp32 storage (1075 vs 1116 us: it prefetches the next tile's gradient rows)
-  if (a.gvec4 && a.dvec4 && (g_wgrad_vec == 2 || (g_wgrad_vec == 1 && (a.g_bf || a.d_bf)))) {
+  // MMTTA_OPT_WGRAD_VECTOR_STAGING = 2: the staging-transposed kernel with 4-channel vector loads (measured,
+  // profiles/r02_wgrad_vector.txt: 1116 us of weight gradient per step either storage; the element loader 1075 us with
+  // fp32 storage, 1189 us with bf16 storage; the transposed-read kernel 1090 us with bf16 storage, 1204 us with fp32)
+  if (a.gvec4 && a.dvec4 && g_wgrad_vec == 2) {
     if (a.g_bf) return launch_wgrad_bf16v_t<TZ, TY, SI, true, false>(a, S, s);
     if (a.d_bf) return launch_wgrad_bf16v_t<TZ, TY, SI, false, true>(a, S, s);
     return launch_wgrad_bf16v_t<TZ, TY, SI, false, false>(a, S, s);
@@ -1154,6 +1415,11 @@ static void launch_tiny(const WTArgs& a, int cs, int cb, int blocks, hipStream_t
   }
 }
 
+// 4-channel vector loads of a tensor are legal: base and every stride keep a quad aligned (16 bytes fp32, 8 bytes bf16)
+static bool wvec_ok(const mmtta_tensor* t) {
+  return ((uintptr_t)t->ptr) % (is_bf16(t) ? 8 : 16) == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0;
+}
+
 struct WGeo {
   bool tiny; int tiny_blocks;
   bool bf16; bool small; int small_is_cd; const mmtta_tensor *q, *pb; bool q_is_x;
@@ -1162,6 +1428,7 @@ struct WGeo {
   int tz, ty, tx, tiles, S, tps, nsl, CGp, CDp;
   int64_t slab_floats, db_floats, colsum_blocks, pre_floats; int pre_chunks;
   bool convt;
+  bool tr;        // bf16 27-tap layer on the transposed-read kernel (its own tile shape)
 };
 
 static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* dy, WGeo& w) {
@@ -1176,6 +1443,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   MMTTA_CHECK(is_cl(x) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "wgrad: tensors must be channels-last");
   MMTTA_CHECK(x->c == d->cin && dy->c == d->cout && x->n == dy->n, MMTTA_ERR_INVALID, "wgrad: channel/batch mismatch");
   w.convt = d->op == MMTTA_CONVT_FWD;
+  w.tr = false;
   if (w.convt) MMTTA_CHECK(d->ksize == 3 && d->stride == 2, MMTTA_ERR_UNSUPPORTED, "wgrad: conv_transpose is k3 s2 only");
   w.g = w.convt ? dy : x;
   w.dn = w.convt ? x : dy;
@@ -1234,7 +1502,10 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     return MMTTA_OK;
   }
   w.bf16 = d->dtype == MMTTA_BF16 && w.ntaps == 27;
-  if (w.si == 1) { w.TZ = 4; w.TY = 4; w.TX = 8; }
+  w.tr = w.bf16 && wvec_ok(w.g) && wvec_ok(w.dn) &&
+         (g_wgrad_vec == 3 || (g_wgrad_vec == 1 && (is_bf16(w.g) || is_bf16(w.dn))));
+  if (w.tr && w.si == 1) { w.TZ = 4; w.TY = 8; w.TX = 8; }
+  else if (w.si == 1) { w.TZ = 4; w.TY = 4; w.TX = 8; }
   else if (w.bf16) { w.TZ = 2; w.TY = 4; w.TX = 8; }
   else { w.TZ = 2; w.TY = 2; w.TX = 8; }
   w.tz = (w.dn->d + w.TZ - 1) / w.TZ;
@@ -1307,6 +1578,7 @@ extern "C" int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* d, const mmtta_ten
   if (st) return st < 0 ? st : -st;
   if (w.tiny) return 6;
   if (w.small) return 3;
+  if (w.tr) return w.si == 1 ? 7 : 8;
   if (w.bf16) return w.si == 1 ? 4 : 5;
   if (w.ntaps == 1) return 2;
   return w.si == 1 ? 0 : 1;
@@ -1413,11 +1685,11 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   a.CGp = w.CGp; a.CDp = w.CDp;
   a.g_bf = is_bf16(w.g) ? 1 : 0;
   a.d_bf = is_bf16(w.dn) ? 1 : 0;
-  a.gvec4 = ((((uintptr_t)w.g->ptr) % (a.g_bf ? 8 : 16) == 0) && w.g->sw % 4 == 0 && w.g->sh % 4 == 0 && w.g->sd % 4 == 0 &&
-             w.g->sn % 4 == 0) ? 1 : 0;
-  a.dvec4 = ((((uintptr_t)w.dn->ptr) % (a.d_bf ? 8 : 16) == 0) && w.dn->sw % 4 == 0 && w.dn->sh % 4 == 0 && w.dn->sd % 4 == 0 &&
-             w.dn->sn % 4 == 0) ? 1 : 0;
-  if (w.bf16) st = (w.si == 1) ? launch_wgrad_bf16<4, 4, 1>(a, w.S, s) : launch_wgrad_bf16<2, 4, 2>(a, w.S, s);
+  a.diag = g_igemm_pipeline;
+  a.gvec4 = wvec_ok(w.g) ? 1 : 0;
+  a.dvec4 = wvec_ok(w.dn) ? 1 : 0;
+  if (w.tr) st = (w.si == 1) ? launch_wgrad_tr<4, 8, 1>(a, w.S, s) : launch_wgrad_tr<2, 4, 2>(a, w.S, s);
+  else if (w.bf16) st = (w.si == 1) ? launch_wgrad_bf16<4, 4, 1>(a, w.S, s) : launch_wgrad_bf16<2, 4, 2>(a, w.S, s);
   else if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, w.S, s);
   else st = (w.si == 1) ? launch_wgrad<4, 4, 8, 7>(a, w.S, s) : launch_wgrad<2, 2, 8, 7>(a, w.S, s);
   if (st || g_profile_main_only) return st;

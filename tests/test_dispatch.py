@@ -3,13 +3,14 @@ parity cases (tests/test_hip_conv.py::CASES / BF16_CASES) - asserted through the
 (``mmtta_conv_plan`` / ``mmtta_conv_wgrad_kernel`` are host-only, so this runs without a GPU too).
 
 config ids: csrc/conv_igemm.hip::config_id (0-5 fp32 igemm, 6 direct, 7-12 bf16 igemm, 13 channel kernel);
-weight-gradient ids: mmtta_conv_wgrad_kernel (0 f32 s1, 1 f32 s2, 2 1x1, 3 small-channel, 4 bf16 s1, 5 bf16 s2, 6 tiny).
+weight-gradient ids: mmtta_conv_wgrad_kernel (0 f32 s1, 1 f32 s2, 2 1x1, 3 small-channel, 4 bf16 s1, 5 bf16 s2, 6 tiny,
+7 / 8 transposed-read bf16 s1 / s2: the default for a bf16-STORED module input, parity cases test_transposed_read_wgrad).
 VERDICT r1 P1: ids 2 and 9 (igemm <4,4,4,4,8,32>) used to be reachable only by the full-size bench."""
 import ctypes as C
 
 import torch
 
-from test_hip_conv import BF16_CASES, CASES
+from test_hip_conv import BF16_CASES, CASES, TR_CASES
 
 # (case, (fwd, dgrad) config in fp32 mode, the same in bf16 mode, weight-gradient kernel (fp32 mode, bf16 mode))
 DISPATCH = [
@@ -28,11 +29,11 @@ DISPATCH = [
 ]
 
 
-def _desc(t):
+def _desc(t, dtype=None):
     from multimodal_tta_amd._lib import F32, Tensor
     n, d, h, w, c = t.shape
     sn, sd, sh, sw, _ = t.stride()
-    return Tensor(t.data_ptr(), n, c, d, h, w, sn, 1, sd, sh, sw, F32, 0)
+    return Tensor(t.data_ptr(), n, c, d, h, w, sn, 1, sd, sh, sw, F32 if dtype is None else dtype, 0)
 
 
 def _cl(n, d, h, w, c):
@@ -73,6 +74,13 @@ def test_every_kernel_instantiation_is_reached_by_a_parity_case():
             assert kid == wg, f"{case} dtype {dtype}: weight-gradient kernel {kid}, expected {wg}"
             seen_cfg.update(got)
             seen_wg.add(kid)
+            if dtype == BF16 and wg in (4, 5):
+                # the same layer with its module input bf16-stored (method.storage: bf16): the transposed-read kernel
+                sx, sy = _desc(x, BF16), ty
+                kid = int(lib.mmtta_conv_wgrad_kernel(C.byref(dsc), C.byref(sx), C.byref(sy)))
+                assert kid == wg + 3, f"{case} bf16-stored: weight-gradient kernel {kid}, expected {wg + 3}"
+                assert case in TR_CASES, f"{case}: transposed-read instantiation without a parity case"
+                seen_wg.add(kid)
     assert seen_cfg == set(range(14)), f"conv configs without a parity case: {sorted(set(range(14)) - seen_cfg)}"
-    assert seen_wg == set(range(7)), f"weight-gradient kernels without a parity case: {sorted(set(range(7)) - seen_wg)}"
+    assert seen_wg == set(range(9)), f"weight-gradient kernels without a parity case: {sorted(set(range(9)) - seen_wg)}"
     assert {2, 9} <= splitk_wide, "the 32-channel-stage igemm also needs a split-K parity case"

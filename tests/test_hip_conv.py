@@ -385,3 +385,54 @@ def test_producer_consumer_igemm_matches_the_default_kernel(case, mode):
     assert torch.equal(outs[0][0], outs[mode][0]), "forward differs"
     assert torch.equal(outs[0][1], outs[mode][1]), "input gradient differs"
     assert torch.allclose(outs[0][2], outs[mode][2], rtol=1e-5, atol=1e-4)
+
+
+TR_CASES = [c for c in BF16_CASES if c[2] == 3 and min(c[0], c[1]) > 4] + [
+    (40, 72, 3, 1, False, (2, 5, 9, 11)),       # ragged tiles on every axis, channel counts that are no multiple of 32
+    (32, 64, 3, 2, False, (1, 7, 9, 13)),       # stride 2 on odd extents
+    (64, 32, 3, 2, True, (1, 3, 5, 7)),
+]
+
+
+@pytest.mark.parametrize("stored", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", TR_CASES)
+def test_transposed_read_wgrad(cin, cout, k, stride, transposed, shape, stored):
+    """MMTTA_OPT_WGRAD_VECTOR_STAGING = 3: the weight gradient whose operands sit in LDS as [voxel][channel] and are
+    transposed by ds_read_b64_tr_b16 on the way into the MFMA.  Same bf16-rounded products as the staging-transposed
+    kernels, another summation order over the voxels: within 2e-3 * max|ref| of them, within the bf16-operand bound of
+    torch fp32, bias gradient fp32-exact, with the norm-on-load of the module input and the accumulate path."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(31 + cin + 3 * cout)
+    n, d, h, w = shape
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = (torch.randn(n, cin, d, h, w) * 1.5 + 0.25).to(torch.bfloat16).float()
+    mu = x.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    xin = F.relu((x - mu[:, :, None, None, None]) * rstd[:, :, None, None, None]).requires_grad_(True)
+    y_ref = mod(xin)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    wt = mod.weight.detach().cuda().contiguous()
+    x_cl = cl_bf16(x) if stored == "bf16" else cl(x)
+    gy_cl = cl(gy)
+    out = {}
+    for mode in (0, 3):
+        prev = ops.set_option(11, mode)
+        try:
+            op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+            op.pack(wt)
+            dw = torch.empty_like(wt)
+            db = torch.empty(cout, device="cuda")
+            op.wgrad(x_cl, nl, gy_cl, dw, db)
+            op.wgrad(x_cl, nl, gy_cl, dw, db, accumulate=True)
+            torch.cuda.synchronize()
+            out[mode] = (dw.cpu() / 2, db.cpu() / 2)
+        finally:
+            ops.set_option(11, prev)
+    ref = mod.weight.grad
+    scale = ref.abs().max().item()
+    assert (out[3][0] - ref).abs().max().item() <= 1.5e-2 * scale + 1e-5
+    assert (out[3][0] - out[0][0]).abs().max().item() <= 2e-3 * scale + 1e-6, "differs from the staging-transposed kernel"
+    close("bias gradient", out[3][1], mod.bias.grad)
