@@ -49,7 +49,8 @@ PEAK_HBM_GBPS = 8000.0
 
 def mfma_peak(kernel_name: str) -> float:
     """Dense MFMA peak of the operand type the named kernel feeds the matrix cores with."""
-    return PEAK_BF16_MFMA_TFLOPS if "bf16" in kernel_name else PEAK_FP32_MFMA_TFLOPS
+    bf = "bf16" in kernel_name or kernel_name.startswith("wgrad_tr_kernel")     # the transposed-read kernel is bf16-only
+    return PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
 
 
 def parse():
@@ -293,8 +294,9 @@ def main():
                         f"S={args.tta_steps} entropy-min steps (fwd+bwd+Adam, all parameters) + final forward + Dice",
             "tta_steps": args.tta_steps, "volume": [C, *shape], "adapted_params": str(cfg["method"]["params"]),
             "precision": ("bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulate, for forward, input-gradient "
-                          "and 27-tap weight-gradient convs; fp32 storage, norms, loss, 1x1/thin weight gradients, "
-                          "Adam and master weights") if args.precision == "bf16"
+                          "and 27-tap weight-gradient convs; forward activations with >= 32 channels stored as "
+                          f"{getattr(plug, 'storage', None) or 'fp32'}, gradients / statistics / norms / loss / 1x1 and thin "
+                          "weight gradients / optimizer / master weights fp32") if args.precision == "bf16"
             else "fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32)", "weights": "seeded default init (no checkpoint offline)",
             "parallelism": f"{world} rank(s), one per GPU, volumes sharded round-robin, no data-path collective; the "
                            f"per-volume Dice table is merged by one all_gather; {lanes} volume(s) in flight per GPU on "

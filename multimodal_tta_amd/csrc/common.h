@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libmmtta.so.  CDNA4 only: wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -83,6 +84,16 @@ __device__ __forceinline__ void ld8_any(const float* base, long long eoff, int b
   } else {
     lo = *reinterpret_cast<const float4*>(base + eoff);
     hi = *reinterpret_cast<const float4*>(base + eoff + 4);
+  }
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) - the index is usable as a template argument
+// and an array subscript that never becomes a run-time value (register arrays stay in registers)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
   }
 }
 

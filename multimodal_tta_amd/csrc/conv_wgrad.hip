@@ -34,7 +34,7 @@ struct WArgs {
   int CGp, CDp;
   int gvec4, dvec4;
   int g_bf, d_bf;   // storage of the gathered / dense tensor: 1 = bf16 elements (the forward activation of bf16 precision)
-  int diag;         // timing ablations of the transposed-read kernel (MMTTA_OPT_IGEMM_PIPELINE bits 1-3; results invalid)
+  int convt;        // transposed module: the dense operand is the module input (carries the norm-on-load)
 };
 
 // NTW = accumulators per wave: 7 for the 27-tap kernel (taps wave, wave+4, ...; slot 27 is a dummy that is
@@ -792,8 +792,16 @@ struct WTGeo {
   static constexpr int XH = (BX + 1) / 2;
   static constexpr int NG = BZ * BY * BX, ND = TZ * TY * 8;
   static constexpr int G_BYTES = NG * 64, D_BYTES = ND * 64;
-  static constexpr int LDS_BYTES = G_BYTES + D_BYTES;
+  static constexpr int LDS_BYTES = G_BYTES + D_BYTES + 256;       // + scale / shift of the 32 module-input channels
   static constexpr int NK = ND / 16;                  // k steps: two tile rows of 8 voxels each
+  // staging: an item = 8 channels (16 bytes of the bf16 image) of one voxel; a thread keeps ONE (x, channel chunk) of the
+  // box and walks the box rows RPP at a time, so x, the channel offset and the LDS column are per-thread constants
+  static constexpr int IPR = BX * 4;                  // items per box row
+  static constexpr int RPP = 256 / IPR;               // box rows per pass (threads >= RPP * IPR repeat row RPP - 1)
+  static constexpr int NROW = BZ * BY;
+  static constexpr int GP = NROW / RPP;               // passes over the box
+  static constexpr int DP = ND * 4 / 256;             // dense-tile items per thread
+  static_assert(NROW % RPP == 0 && (ND * 4) % 256 == 0 && RPP <= BY, "whole passes; at most one y wrap inside a pass");
   __host__ __device__ static constexpr int xmap(int x) { return SI == 1 ? x : (x & 1) * XH + (x >> 1); }
   __host__ __device__ static constexpr int tap_off(int tap) {        // bytes; tap = (kz*3 + ky)*3 + kx
     return (((tap / 9) * BY + (tap / 3) % 3) * BX + xmap(tap % 3)) * 64;
@@ -813,28 +821,47 @@ typedef __attribute__((address_space(3))) wshort4* wlds4_t;
                                                       __builtin_amdgcn_ds_read_tr16_b64_v4i16((wlds4_t)((ptr) + (off) + 256)), \
                                                       0, 1, 2, 3, 4, 5, 6, 7))
 
-// raw 4-channel quads (converted when they are committed: a conversion right behind the load would wait for it)
-template <bool BF> struct WQuad { typedef float4 T; };
-template <> struct WQuad<true> { typedef uint2 T; };
-template <bool BF> __device__ __forceinline__ typename WQuad<BF>::T wquad_ld(const float* base, long long eoff) {
-  if constexpr (BF) return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + eoff);
-  else return *reinterpret_cast<const float4*>(base + eoff);
+// raw 8-channel items (converted when they are committed: a conversion right behind the load would wait for it)
+template <bool BF> struct WOct { float4 lo, hi; };
+template <> struct WOct<true> { uint4 q; };
+// `base` points at the batch item (wave-uniform), the offsets are ELEMENTS below 2^31 (checked on the host): the loads
+// take the scalar-base + 32-bit-offset form, no 64-bit vector arithmetic
+template <bool BF>
+__device__ __forceinline__ WOct<BF> woct_ld(const float* base, unsigned eoff_lo, unsigned eoff_hi) {
+  WOct<BF> o;
+  if constexpr (BF) {
+    o.q = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + eoff_lo);
+  } else {
+    o.lo = *reinterpret_cast<const float4*>(base + eoff_lo);
+    o.hi = *reinterpret_cast<const float4*>(base + eoff_hi);
+  }
+  return o;
 }
-__device__ __forceinline__ float4 wquad_f4(float4 q) { return q; }
-__device__ __forceinline__ float4 wquad_f4(uint2 u) {
-  return make_float4(bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu),
-                     bf16_bits_to_f32(u.y >> 16));
+__device__ __forceinline__ void woct_f8(const WOct<false>& o, float (&v)[8]) {
+  v[0] = o.lo.x; v[1] = o.lo.y; v[2] = o.lo.z; v[3] = o.lo.w; v[4] = o.hi.x; v[5] = o.hi.y; v[6] = o.hi.z; v[7] = o.hi.w;
+}
+__device__ __forceinline__ void woct_f8(const WOct<true>& o, float (&v)[8]) {
+  v[0] = bf16_bits_to_f32(o.q.x & 0xffffu); v[1] = __uint_as_float(o.q.x & 0xffff0000u);
+  v[2] = bf16_bits_to_f32(o.q.y & 0xffffu); v[3] = __uint_as_float(o.q.y & 0xffff0000u);
+  v[4] = bf16_bits_to_f32(o.q.z & 0xffffu); v[5] = __uint_as_float(o.q.z & 0xffff0000u);
+  v[6] = bf16_bits_to_f32(o.q.w & 0xffffu); v[7] = __uint_as_float(o.q.w & 0xffff0000u);
 }
 
-// Software pipeline over the tiles of a workgroup: the loads of tile i+1 - the whole dense tile and as many passes of the
-// gathered box as ~72 registers hold (all of them when the box is bf16-stored) - are issued right before tile i's MFMA
-// loop, which reads LDS only, and land under it; the passes that did not fit are issued first thing in tile i+1 and
-// land under the commit (transform, pack, LDS write) of the prefetched ones.  Without this a tile paid seven dependent
-// HBM round trips (4 loads in flight per thread): 11 us per 256-voxel tile for 1.8 us of MFMA.
-template <int TZ, int TY, int SI, bool GBF, bool DBF>
+// Staging is the vector-ALU cost of this kernel, and with several volumes in flight vector-ALU issue is what bounds the
+// chip (profiles/r02c_sq_counters.md), so the loader is built for few instructions per element:
+//  * an item is 8 channels; a thread owns one (x, chunk) column of the box: x bounds, x / channel offsets, the x
+//    de-interleave of stride 2 and the LDS column are computed once per tile, the LDS row is an immediate offset;
+//  * a pass covers RPP whole box rows: z is wave-uniform up to one wrap (two scalar candidates, one select), y is one add;
+//  * element offsets are 32-bit, products are 24-bit multiply-adds (strides < 2^24, tensor < 2^31 elements: host check);
+//  * the norm-on-load exists on the module-input side only (template TD: the dense operand of a transposed module, else
+//    the gathered one): the gradient side is a plain fp32 -> bf16 pack;  ReLU is max(x, lo) with lo = 0 or -inf.
+// Software pipeline over the tiles of a workgroup: the dense tile and the first PG box passes of tile i+1 are requested
+// right before tile i's MFMA loop (which reads LDS only) and land under it; the remaining passes are requested first
+// thing in tile i+1 and land under the commit of the prefetched ones.
+template <int TZ, int TY, int SI, bool GBF, bool DBF, bool TD>
 __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
   using G = WTGeo<TZ, TY, SI>;
-  static_assert(TY % 2 == 0 && G::ND % 32 == 0, "a k step is two rows of one z slice; the D tile is staged 32 voxels a pass");
+  static_assert(TY % 2 == 0, "a k step is two rows of one z slice");
   extern __shared__ float lds[];
   unsigned char* gl = reinterpret_cast<unsigned char*>(lds);
   unsigned char* dl = gl + G::G_BYTES;
@@ -842,7 +869,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
   const int cg0 = blockIdx.y * 32, cd0 = blockIdx.z * 32;
-  const int cq = tid & 7, vs = tid >> 3;        // staging: channel group (4 channels), voxel slot (32 voxels per pass)
 
   // operand addresses: lane part (group row q, 8-byte column chunk, row half) + tap (A only)
   const int lq = (lane & 15) >> 2, lp = lane & 3, lc = (lane >> 4) & 1;
@@ -858,63 +884,89 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
   for (int j = 0; j < 7; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-  float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+  float dbs[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) dbs[c] = 0.f;
+  const bool want_db = a.dbpart != nullptr && blockIdx.y == 0;
+
+  // ---- staging roles (per-thread constants)
+  const int rsub = min(tid / G::IPR, G::RPP - 1);                // box row inside a pass
+  const int rem = tid % G::IPR, bx = rem >> 2, c8 = rem & 3;     // box x, 8-channel chunk
+  const int bxm = SI == 1 ? bx : (bx & 1) * G::XH + (bx >> 1);
+  unsigned char* gst = gl + (rsub * G::BX + bxm) * 64 + c8 * 16;  // + pass * RPP * BX * 64
+  const int dvox0 = tid >> 2, d8 = tid & 3;                      // dense item p: voxel dvox0 + 64 p, chunk d8
+  unsigned char* dst = dl + dvox0 * 64 + d8 * 16;                // + p * 4096
+  const int dzl = dvox0 / (TY * 8), dyl = (dvox0 >> 3) % TY, dxl = dvox0 & 7;     // (pass p adds 64 / (TY * 8) to z)
+  const int gcb = cg0 + 8 * c8, dcb = cd0 + 8 * d8;
+  // clamped (always valid) load channels; rows of bf16 tensors are padded to 8 channels, of fp32 tensors to 4
+  const unsigned gc_lo = GBF ? min(gcb, (a.Cg - 1) & ~7) : min(gcb, (a.Cg - 1) & ~3), gc_hi = min(gcb + 4, (a.Cg - 1) & ~3);
+  const unsigned dc_lo = DBF ? min(dcb, (a.Cd - 1) & ~7) : min(dcb, (a.Cd - 1) & ~3), dc_hi = min(dcb + 4, (a.Cd - 1) & ~3);
+  const bool gtail = (a.Cg & 7) != 0, dtail = (a.Cd & 7) != 0;  // only then can a chunk hold channels past the last one
+  auto pair_mask = [](int c, int C) { return (c < C ? 0xffffu : 0u) | (c + 1 < C ? 0xffff0000u : 0u); };
+  const unsigned gsd = (unsigned)a.gsd, gsh = (unsigned)a.gsh, gsw = (unsigned)a.gsw;
+  const unsigned dsd = (unsigned)a.dsd, dsh = (unsigned)a.dsh, dsw = (unsigned)a.dsw;
 
   const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
   const int t0 = sx * a.tiles_per_split;
   const int t1 = min(a.tiles, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
-  const int gcb = cg0 + 4 * cq, dcb = cd0 + 4 * cq;
-  const int gcl = min(gcb, (a.Cg - 1) & ~3), dcl = min(dcb, (a.Cd - 1) & ~3);     // clamped (always valid) load channels
-  // channels past the tensor's last one stage as zeros: bit masks on the packed pairs (gathered) / the fp32 values (dense)
-  const unsigned gmask01 = (gcb + 0 < a.Cg ? 0xffffu : 0u) | (gcb + 1 < a.Cg ? 0xffff0000u : 0u);
-  const unsigned gmask23 = (gcb + 2 < a.Cg ? 0xffffu : 0u) | (gcb + 3 < a.Cg ? 0xffff0000u : 0u);
-  unsigned dmask[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) dmask[c] = dcb + c < a.Cd ? 0xffffffffu : 0u;
-  constexpr int GP = (G::NG + 31) / 32, DP = G::ND / 32;
-  constexpr int PREF = (GBF || DBF) ? 48 : 32;                         // registers the cross-loop prefetch may hold (more spills)
-  constexpr int PGmax = (PREF - DP * (DBF ? 2 : 4)) / (GBF ? 2 : 4);
-  constexpr int PG = PGmax < GP ? PGmax : GP;                          // box passes prefetched across the MFMA loop
-  typename WQuad<GBF>::T gv[GP];
-  typename WQuad<DBF>::T dq[DP];
+  constexpr int GP = G::GP, DP = G::DP;
+  constexpr int PREF = 40;                                             // registers the cross-loop prefetch may hold
+  constexpr int PGmax = (PREF - DP * (DBF ? 4 : 8)) / (GBF ? 4 : 8);
+  constexpr int PG = PGmax < 0 ? 0 : (PGmax < GP ? PGmax : GP);        // box passes prefetched across the MFMA loop
+  WOct<GBF> gv[GP];
+  WOct<DBF> dq[DP];
+  unsigned pok = 0u;                             // bit p: box item of pass p lies inside the tensor
+  unsigned dok = 0u;                             // bit p: dense item p lies inside the tensor
   int pn = -1, poz0 = 0, poy0 = 0, pox0 = 0;     // tile whose loads are in gv[0..PG) / dq
   int cn = -1;                                   // batch item the transform coefficients belong to
-  float gsc[4], gsh[4], dsc[4], dsh[4];
+  float* coefl = reinterpret_cast<float*>(dl + G::D_BYTES);     // [2][32]: scale, shift of the module-input channels
+  const float relu_lo = (TD ? a.td.relu : a.tg.relu) ? 0.f : -__builtin_inff();
+  unsigned gxoff = 0u;                           // per tile: x / channel part of the box offsets, x in bounds
+  bool gxok = false;
 
-  auto box_voxel = [&](int pass, int& bz, int& by, int& bx) {
-    // opaque per call: the decode depends on the thread only, so the compiler would hoist all GP of them (and the LDS
-    // addresses) out of the tile loop and hold ~4 registers per pass for the whole kernel (measured: 170-315 spills)
-    int vsl = vs;
-    asm volatile("" : "+v"(vsl));
-    const int bv = min(vsl + 32 * pass, G::NG - 1);
-    bz = bv / (G::BY * G::BX);
-    const int brem = bv - bz * (G::BY * G::BX);
-    by = brem / G::BX;
-    bx = brem - by * G::BX;
+  auto tile_x = [&](int ix0) {
+    const int ix = ix0 + bx;
+    gxok = (unsigned)ix < (unsigned)a.Wgg;
+    gxoff = __umul24((unsigned)min(max(ix, 0), a.Wgg - 1), gsw);
   };
-  auto load_g = [&](int pass, int n, int iz0, int iy0, int ix0) {
-    int bz, by, bx;
-    box_voxel(pass, bz, by, bx);
-    gv[pass] = wquad_ld<GBF>(a.g, (long long)n * a.gsn + gcl + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd +
-                                      (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh +
-                                      (long long)min(max(ix0 + bx, 0), a.Wgg - 1) * a.gsw);
-  };
-  auto commit_g = [&](int pass, int iz0, int iy0, int ix0) {
-    if (vs + 32 * pass < G::NG) {
-      int bz, by, bx;
-      box_voxel(pass, bz, by, bx);
-      const bool ok = (unsigned)(iz0 + bz) < (unsigned)a.Dgg && (unsigned)(iy0 + by) < (unsigned)a.Hgg &&
-                      (unsigned)(ix0 + bx) < (unsigned)a.Wgg;
-      // branch-free: written as `ok ? f(v) : 0` hipcc branches around every channel (and reloads a spilled quad in each)
-      const unsigned okm = ok ? 0xffffffffu : 0u;
-      const float4 v = wquad_f4(gv[pass]);
-      uint2 pk;
-      pk.x = wpack2(nl_apply(v.x, gsc[0], gsh[0], a.tg.relu), nl_apply(v.y, gsc[1], gsh[1], a.tg.relu)) & (okm & gmask01);
-      pk.y = wpack2(nl_apply(v.z, gsc[2], gsh[2], a.tg.relu), nl_apply(v.w, gsc[3], gsh[3], a.tg.relu)) & (okm & gmask23);
-      const int bxm = SI == 1 ? bx : (bx & 1) * G::XH + (bx >> 1);
-      *reinterpret_cast<uint2*>(gl + ((bz * G::BY + by) * G::BX + bxm) * 64 + cq * 8) = pk;
+  auto load_g = [&](auto pc, const float* gbase, int iz0, int iy0) {
+    constexpr int P = decltype(pc)::value;
+    constexpr int row0 = G::RPP * P, bz0 = row0 / G::BY, by0 = row0 % G::BY;
+    constexpr bool can_wrap = by0 + G::RPP > G::BY;
+    int by = by0 + rsub;
+    bool wrap = false;
+    if constexpr (can_wrap) {
+      wrap = by >= G::BY;
+      by = wrap ? by - G::BY : by;
     }
+    const int izA = iz0 + bz0, izB = izA + 1;                    // wave-uniform candidates
+    const unsigned zoA = __umul24((unsigned)min(max(izA, 0), a.Dgg - 1), gsd), zoB = __umul24((unsigned)min(max(izB, 0), a.Dgg - 1), gsd);
+    const bool zkA = (unsigned)izA < (unsigned)a.Dgg, zkB = (unsigned)izB < (unsigned)a.Dgg;
+    const unsigned zo = (can_wrap && wrap) ? zoB : zoA;
+    const bool zk = (can_wrap && wrap) ? zkB : zkA;
+    const int iy = iy0 + by;
+    const bool ok = zk && gxok && (unsigned)iy < (unsigned)a.Hgg;
+    pok |= (ok ? 1u : 0u) << P;
+    const unsigned off = zo + __umul24((unsigned)min(max(iy, 0), a.Hgg - 1), gsh) + gxoff;
+    gv[P] = woct_ld<GBF>(gbase, off + gc_lo, off + gc_hi);
+  };
+  auto commit_g = [&](auto pc, const float (&sc)[8], const float (&sh)[8]) {
+    constexpr int P = decltype(pc)::value;
+    float v[8];
+    woct_f8(gv[P], v);
+    if constexpr (!TD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), relu_lo);
+    }
+    const unsigned okm = ((pok >> P) & 1u) ? 0xffffffffu : 0u;
+    uint4 pk;
+    pk.x = wpack2(v[0], v[1]) & okm; pk.y = wpack2(v[2], v[3]) & okm;
+    pk.z = wpack2(v[4], v[5]) & okm; pk.w = wpack2(v[6], v[7]) & okm;
+    if (gtail) {
+      pk.x &= pair_mask(gcb, a.Cg); pk.y &= pair_mask(gcb + 2, a.Cg); pk.z &= pair_mask(gcb + 4, a.Cg); pk.w &= pair_mask(gcb + 6, a.Cg);
+    }
+    *reinterpret_cast<uint4*>(gst + P * (G::RPP * G::BX * 64)) = pk;
   };
   auto issue = [&](int tile) {
     pn = tile / tpn;
@@ -923,52 +975,91 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
     const int tyi = t % a.ty;
     const int tzi = t / a.ty;
     poz0 = tzi * TZ; poy0 = tyi * TY; pox0 = txi * 8;
-    const long long dno = (long long)pn * a.dsn + dcl;
+    const float* dbase = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.dn) + (long long)pn * a.dsn * (DBF ? 2 : 4));
+    const int oy = poy0 + dyl, ox = pox0 + dxl;
+    const bool yxok = oy < a.Hd && ox < a.Wd;
+    const unsigned yxoff = __umul24((unsigned)min(oy, a.Hd - 1), dsh) + __umul24((unsigned)min(ox, a.Wd - 1), dsw);
+    dok = 0u;
 #pragma unroll
     for (int p = 0; p < DP; ++p) {
-      const int dv = vs + 32 * p;
-      const int z = dv / (TY * 8), y = (dv >> 3) % TY, x = dv & 7;
-      dq[p] = wquad_ld<DBF>(a.dn, dno + (long long)min(poz0 + z, a.Dd - 1) * a.dsd + (long long)min(poy0 + y, a.Hd - 1) * a.dsh +
-                                      (long long)min(pox0 + x, a.Wd - 1) * a.dsw);
+      const int oz = poz0 + dzl + p * (64 / (TY * 8));
+      dok |= ((yxok && oz < a.Dd) ? 1u : 0u) << p;
+      const unsigned off = __umul24((unsigned)min(oz, a.Dd - 1), dsd) + yxoff;
+      dq[p] = woct_ld<DBF>(dbase, off + dc_lo, off + dc_hi);
     }
-#pragma unroll
-    for (int p = 0; p < PG; ++p) load_g(p, pn, poz0 * SI - 1, poy0 * SI - 1, pox0 * SI - 1);
+    pok = 0u;
+    tile_x(pox0 * SI - 1);
+    const float* gbase = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.g) + (long long)pn * a.gsn * (GBF ? 2 : 4));
+    static_for<0, PG>([&](auto pc) { load_g(pc, gbase, poz0 * SI - 1, poy0 * SI - 1); });
   };
 
   if (t0 < t1) issue(t0);
   for (int tile = t0; tile < t1; ++tile) {
-    const int n = pn, oz0 = poz0, oy0 = poy0, ox0 = pox0;
-    const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
+    const int n = pn;
+    // what the prefetch had no registers for comes in rounds of RB passes (all loads of a round in flight together);
+    // the first round is requested before the prefetched part is committed
+    constexpr int RB = GBF ? 12 : 6;
+    constexpr int R1 = PG + RB < GP ? PG + RB : GP;
+    const float* gbase = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.g) + (long long)n * a.gsn * (GBF ? 2 : 4));
+    const int iz0 = poz0 * SI - 1, iy0 = poy0 * SI - 1;
+    static_for<PG, R1>([&](auto pc) { load_g(pc, gbase, iz0, iy0); });
+    if (n != cn) {       // per-(n, channel) transform, once per batch item; kept in LDS (16 registers across the MFMA loop
+                         // cost more than four LDS reads per tile); every thread of a chunk writes the same values
+      float s8[8], h8[8];
+      if constexpr (TD) nl_coeff_vec<8>(a.td, n, a.Cd, dcb, s8, h8);
+      else nl_coeff_vec<8>(a.tg, n, a.Cg, gcb, s8, h8);
+      const int k8 = TD ? d8 : c8;
 #pragma unroll
-    for (int p = PG; p < GP; ++p) load_g(p, n, iz0, iy0, ix0);       // what the prefetch had no registers for
-    if (n != cn) {                                                    // per-(n, channel) transform: once per batch item
-      nl_coeff_vec<4>(a.td, n, a.Cd, dcb, dsc, dsh);
-      nl_coeff_vec<4>(a.tg, n, a.Cg, gcb, gsc, gsh);
+      for (int j = 0; j < 8; ++j) { coefl[8 * k8 + j] = s8[j]; coefl[32 + 8 * k8 + j] = h8[j]; }
       cn = n;
+      __syncthreads();
+    }
+    float sc[8], sh[8];
+    {
+      const float4* cq = reinterpret_cast<const float4*>(coefl + 8 * (TD ? d8 : c8));
+      const float4 s0 = cq[0], s1 = cq[1], h0 = cq[8], h1 = cq[9];
+      sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+      sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
     }
 #pragma unroll
     for (int p = 0; p < DP; ++p) {
-      const int dv = vs + 32 * p;
-      const int z = dv / (TY * 8), y = (dv >> 3) % TY, x = dv & 7;
-      const bool ok = oz0 + z < a.Dd && oy0 + y < a.Hd && ox0 + x < a.Wd;
-      const unsigned okm = ok ? 0xffffffffu : 0u;
-      const float4 v = wquad_f4(dq[p]);
-      const float w0 = __uint_as_float(__float_as_uint(nl_apply(v.x, dsc[0], dsh[0], a.td.relu)) & (okm & dmask[0]));
-      const float w1 = __uint_as_float(__float_as_uint(nl_apply(v.y, dsc[1], dsh[1], a.td.relu)) & (okm & dmask[1]));
-      const float w2 = __uint_as_float(__float_as_uint(nl_apply(v.z, dsc[2], dsh[2], a.td.relu)) & (okm & dmask[2]));
-      const float w3 = __uint_as_float(__float_as_uint(nl_apply(v.w, dsc[3], dsh[3], a.td.relu)) & (okm & dmask[3]));
-      dbs[0] += w0; dbs[1] += w1; dbs[2] += w2; dbs[3] += w3;
-      uint2 pk;
-      pk.x = wpack2(w0, w1); pk.y = wpack2(w2, w3);
-      *reinterpret_cast<uint2*>(dl + dv * 64 + cq * 8) = pk;
-    }
+      float v[8];
+      woct_f8(dq[p], v);
+      if constexpr (TD) {
 #pragma unroll
-    for (int p = 0; p < GP; ++p) commit_g(p, iz0, iy0, ix0);
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), relu_lo);
+      }
+      const unsigned okm = ((dok >> p) & 1u) ? 0xffffffffu : 0u;
+      if (want_db) {                                                  // bias gradient: fp32 sums of what is staged
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned cm = (dcb + j < a.Cd) ? okm : 0u;
+          dbs[j] += __uint_as_float(__float_as_uint(v[j]) & cm);
+        }
+      }
+      uint4 pk;
+      pk.x = wpack2(v[0], v[1]) & okm; pk.y = wpack2(v[2], v[3]) & okm;
+      pk.z = wpack2(v[4], v[5]) & okm; pk.w = wpack2(v[6], v[7]) & okm;
+      if (dtail) {
+        pk.x &= pair_mask(dcb, a.Cd); pk.y &= pair_mask(dcb + 2, a.Cd); pk.z &= pair_mask(dcb + 4, a.Cd); pk.w &= pair_mask(dcb + 6, a.Cd);
+      }
+      *reinterpret_cast<uint4*>(dst + p * 4096) = pk;
+    }
+    static_for<0, R1>([&](auto pc) { commit_g(pc, sc, sh); });
+    if constexpr (R1 < GP) {
+      constexpr int R2 = R1 + RB < GP ? R1 + RB : GP;
+      static_for<R1, R2>([&](auto pc) { load_g(pc, gbase, iz0, iy0); });
+      static_for<R1, R2>([&](auto pc) { commit_g(pc, sc, sh); });
+      if constexpr (R2 < GP) {
+        static_for<R2, GP>([&](auto pc) { load_g(pc, gbase, iz0, iy0); });
+        static_for<R2, GP>([&](auto pc) { commit_g(pc, sc, sh); });
+      }
+    }
     __syncthreads();
     if (tile + 1 < t1) issue(tile + 1);                               // lands during the MFMAs below
     // ---- MFMAs.  Fragment f = (k step, tap slot) is read LA MFMAs before it multiplies (a ring of LA + 1 register sets;
     // a fence per MFMA, or the scheduler sinks every read to one MFMA ahead and the MFMA waits out the LDS latency)
-    constexpr int LA = 4, NF = G::NK * 7;
+    constexpr int LA = 3, NF = G::NK * 7;
     wbf16x8 ra[LA + 1], fb[2];
     fb[0] = MMTTA_TR_FRAG(dread, 0);
 #pragma unroll
@@ -997,24 +1088,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
       }
     }
   }
-  if (a.dbpart != nullptr && blockIdx.y == 0) {     // bias gradient from the fp32 values seen while staging
-    float* red4 = lds;                              // the images are dead: the loop ended with a barrier
+  if (want_db) {                                    // thread (voxel slot, chunk d8) holds channels 8 d8 .. 8 d8 + 7
+    float* red8 = lds;                              // the images are dead: the loop ended with a barrier
 #pragma unroll
-    for (int c = 0; c < 4; ++c) red4[tid * 4 + c] = dbs[c];
+    for (int c = 0; c < 8; ++c) red8[tid * 8 + c] = dbs[c];
     __syncthreads();
     if (tid < 32) {
       float sacc = 0.f;
 #pragma unroll 8
-      for (int q = 0; q < 32; ++q) sacc += red4[((q << 3) | (tid >> 2)) * 4 + (tid & 3)];
+      for (int q = 0; q < 64; ++q) sacc += red8[((q << 2) | (tid >> 3)) * 8 + (tid & 7)];
       a.dbpart[(long long)sl * a.CDp + cd0 + tid] = sacc;
     }
   }
 }
 
-template <int TZ, int TY, int SI, bool GBF, bool DBF>
+template <int TZ, int TY, int SI, bool GBF, bool DBF, bool TD>
 static int launch_wgrad_tr_t(const WArgs& a, int S, hipStream_t s) {
   using G = WTGeo<TZ, TY, SI>;
-  auto kern = wgrad_tr_kernel<TZ, TY, SI, GBF, DBF>;
+  auto kern = wgrad_tr_kernel<TZ, TY, SI, GBF, DBF, TD>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1025,13 +1116,22 @@ static int launch_wgrad_tr_t(const WArgs& a, int S, hipStream_t s) {
   return launch_status("conv wgrad bf16 (transposed reads)");
 }
 
+// the module input (norm-on-load, possibly bf16-stored) is the gathered operand of a convolution and the dense one of a
+// transposed convolution (stride 2 only); the other operand is a gradient: fp32, read as is
 template <int TZ, int TY, int SI>
 static int launch_wgrad_tr(const WArgs& a, int S, hipStream_t s) {
-  MMTTA_CHECK(!(a.g_bf && a.d_bf), MMTTA_ERR_UNSUPPORTED, "wgrad: both operands bf16-stored");
   MMTTA_CHECK(a.gvec4 && a.dvec4, MMTTA_ERR_INVALID, "wgrad: transposed-read kernel selected for unaligned tensors");
-  if (a.g_bf) return launch_wgrad_tr_t<TZ, TY, SI, true, false>(a, S, s);
-  if (a.d_bf) return launch_wgrad_tr_t<TZ, TY, SI, false, true>(a, S, s);
-  return launch_wgrad_tr_t<TZ, TY, SI, false, false>(a, S, s);
+  if (a.convt) {
+    MMTTA_CHECK(!a.g_bf, MMTTA_ERR_UNSUPPORTED, "wgrad: bf16-stored output gradient");
+    if constexpr (SI == 2) {
+      if (a.d_bf) return launch_wgrad_tr_t<TZ, TY, SI, false, true, true>(a, S, s);
+      return launch_wgrad_tr_t<TZ, TY, SI, false, false, true>(a, S, s);
+    }
+    return MMTTA_ERR_UNSUPPORTED;
+  }
+  MMTTA_CHECK(!a.d_bf, MMTTA_ERR_UNSUPPORTED, "wgrad: bf16-stored output gradient");
+  if (a.g_bf) return launch_wgrad_tr_t<TZ, TY, SI, true, false, false>(a, S, s);
+  return launch_wgrad_tr_t<TZ, TY, SI, false, false, false>(a, S, s);
 }
 
 // one instantiation per storage combination (the forward activation may be bf16-stored, the gradient never is)
@@ -1420,6 +1520,17 @@ static bool wvec_ok(const mmtta_tensor* t) {
   return ((uintptr_t)t->ptr) % (is_bf16(t) ? 8 : 16) == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0;
 }
 
+// the transposed-read kernel's loader: 16-byte items of 8 channels (fp32: two quads), 32-bit element offsets built
+// from 24-bit multiply-adds
+static bool wtr_ok(const mmtta_tensor* t) {
+  const int64_t q = is_bf16(t) ? 8 : 4;
+  if (((uintptr_t)t->ptr) % 16 != 0 || t->sw % q != 0 || t->sh % q != 0 || t->sd % q != 0 || t->sn % q != 0) return false;
+  const int64_t lim24 = (int64_t)1 << 24;
+  if (t->sw >= lim24 || t->sh >= lim24 || t->sd >= lim24 || t->d >= lim24 || t->h >= lim24 || t->w >= lim24) return false;
+  const int64_t last = (int64_t)(t->d - 1) * t->sd + (int64_t)(t->h - 1) * t->sh + (int64_t)(t->w - 1) * t->sw + roundup(t->c, 8) + 8;
+  return last < ((int64_t)1 << 31);
+}
+
 struct WGeo {
   bool tiny; int tiny_blocks;
   bool bf16; bool small; int small_is_cd; const mmtta_tensor *q, *pb; bool q_is_x;
@@ -1502,7 +1613,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     return MMTTA_OK;
   }
   w.bf16 = d->dtype == MMTTA_BF16 && w.ntaps == 27;
-  w.tr = w.bf16 && wvec_ok(w.g) && wvec_ok(w.dn) &&
+  w.tr = w.bf16 && wtr_ok(w.g) && wtr_ok(w.dn) && !(w.convt && is_bf16(w.g)) && !(!w.convt && is_bf16(w.dn)) &&
          (g_wgrad_vec == 3 || (g_wgrad_vec == 1 && (is_bf16(w.g) || is_bf16(w.dn))));
   if (w.tr && w.si == 1) { w.TZ = 4; w.TY = 8; w.TX = 8; }
   else if (w.si == 1) { w.TZ = 4; w.TY = 4; w.TX = 8; }
@@ -1685,7 +1796,7 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   a.CGp = w.CGp; a.CDp = w.CDp;
   a.g_bf = is_bf16(w.g) ? 1 : 0;
   a.d_bf = is_bf16(w.dn) ? 1 : 0;
-  a.diag = g_igemm_pipeline;
+  a.convt = w.convt ? 1 : 0;
   a.gvec4 = wvec_ok(w.g) ? 1 : 0;
   a.dvec4 = wvec_ok(w.dn) ? 1 : 0;
   if (w.tr) st = (w.si == 1) ? launch_wgrad_tr<4, 8, 1>(a, w.S, s) : launch_wgrad_tr<2, 4, 2>(a, w.S, s);

@@ -18,9 +18,16 @@ def short(name):
 def bench_name(k):
     """Trace kernel name -> the name bench.py's profiler uses (ops.IGEMM_KERNELS / WGRAD_KERNELS)."""
     k = k.replace(" ", "")
-    m = re.match(r"igemm_kernel<(.*),(true|false)>$", k)
+    # igemm_kernel<NB,MB,TZ,TY,TX,KCI,BF[,OCC[,ABF]]>: the profiler's name carries the tile and the operand type only
+    m = re.match(r"igemm_kernel<(\d+,\d+,\d+,\d+,\d+,\d+),(true|false)(,\d+)?(,(true|false))?>$", k)
     if m:
         return f"igemm_kernel<{m.group(1)},bf16>" if m.group(2) == "true" else f"igemm_f32_kernel<{m.group(1)}>"
+    m = re.match(r"(wgrad_tr_kernel|wgrad_bf16v?_kernel)<(\d+,\d+,\d+)(,(true|false),(true|false))?>$", k)
+    if m:
+        return f"{m.group(1).replace('bf16v', 'bf16')}<{m.group(2)}>"
+    m = re.match(r"wgrad_f32_kernel<(\d+,\d+,\d+,\d+)(,(true|false),(true|false))?>$", k)
+    if m:
+        return f"wgrad_f32_kernel<{m.group(1)}>"
     m = re.match(r"wgrad_f32_kernel<(\d+),(\d+),(\d+),(\d+)>$", k)
     if m:
         return k
@@ -60,16 +67,21 @@ def main(paths):
         print(" | ".join(row))
     if json_out:
         import json
-        out = {}
+        acc = {}        # several instantiations (storage variants) share one profiler name: launch-weighted average
         for k in vals:
             f, w = vals[k].get("FETCH_SIZE"), vals[k].get("WRITE_SIZE")
             if f is None and w is None:
                 continue
-            nf, nw = len(calls[k]["FETCH_SIZE"]) or 1, len(calls[k]["WRITE_SIZE"]) or 1
-            # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies a 128-byte read request as 64 bytes: reads x2
-            # (MI355X_MICROARCH.md, HBM section)
-            out[bench_name(k)] = {"fetch_bytes": (f or 0.0) / nf * 1024.0 * 2.0, "write_bytes": (w or 0.0) / nw * 1024.0,
-                                  "launches_averaged": int(dur[k][0] // max(1, len(paths)))}
+            nf, nw = len(calls[k]["FETCH_SIZE"]), len(calls[k]["WRITE_SIZE"])
+            a = acc.setdefault(bench_name(k), [0.0, 0, 0.0, 0])
+            a[0] += f or 0.0
+            a[1] += nf
+            a[2] += w or 0.0
+            a[3] += nw
+        # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies a 128-byte read request as 64 bytes: reads x2
+        # (MI355X_MICROARCH.md, HBM section)
+        out = {name: {"fetch_bytes": a[0] / max(a[1], 1) * 1024.0 * 2.0, "write_bytes": a[2] / max(a[3], 1) * 1024.0,
+                      "launches_averaged": max(a[1], a[3])} for name, a in acc.items()}
         json.dump(out, open(json_out, "w"), indent=1, sort_keys=True)
 
 
