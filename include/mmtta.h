@@ -85,7 +85,7 @@ int mmtta_abi_version(void);
  * result beyond fp32 summation order.  A caller that caches mmtta_conv_plan results (workspace size, statistics rows)
  * must drop them after changing a knob and set knobs before capturing launches into a graph (the Python layer does
  * both: ops.set_option).  Defaults are the measured optimum for four volumes in flight per GPU (DESIGN.md section
- * 3.2); `scripts/sweep_tuning.py` sweeps them inside one process.
+ * 3.3); `scripts/sweep_tuning.py` sweeps them inside one process.
  *   SPLITK_BELOW / SPLITK_TARGET  implicit GEMM: split the reduction when a launch has fewer workgroups than BELOW, up
  *                                 to about TARGET workgroups                                    (defaults 96 / 128)
  *   WGRAD_WORKGROUPS              workgroups (slabs x channel blocks) of a weight-gradient launch      (default 128)
@@ -95,13 +95,16 @@ int mmtta_abi_version(void);
 #define MMTTA_OPT_SPLITK_TARGET 3
 #define MMTTA_OPT_WGRAD_WORKGROUPS 4
 #define MMTTA_OPT_WGRAD_THIN_SLABS 5
-/* 1 (default): the implicit GEMM requests the input box of stage k+1 while the matrix cores work on stage k (bf16
- * mode, full 3x3x3 stride-1 stages); 0: load -> barrier -> MFMA -> barrier as in round 1.  Same results bit for bit. */
+/* 1 (default): the bf16 3x3x3 stride-1 stages of the implicit GEMM use the row-structured loader (8-channel items, a
+ * thread owns one (x, channel chunk) column of the halo box, geometry paid once per tile, 32-bit offsets; needs strides
+ * < 2^24 and < 2^31 elements per tensor, else the generic loader runs) and request the first passes of stage k+1 while
+ * the matrix cores work on stage k; 0: the generic loader, load -> barrier -> MFMA -> barrier as in round 1.  Same
+ * results bit for bit. */
 #define MMTTA_OPT_IGEMM_PIPELINE 6
 /* Producer / consumer form of the bf16-operand implicit GEMM (512-thread workgroups: four loader waves and four MFMA
  * waves, double-buffered LDS, persistent over a contiguous range of tiles).  0 (default): off; 1: the wide small-grid
  * configurations only; 2: every bf16 configuration.  Same results as the default kernel up to the summation order of
- * the statistics rows.  Measured round 2 (DESIGN.md section 3.2): 5-15 % faster per launch on the 8^3 / 16^3 levels
+ * the statistics rows.  Measured round 2 (DESIGN.md section 3.3): 5-15 % faster per launch on the 8^3 / 16^3 levels
  * when a lane runs alone, but 4 % SLOWER for four lanes (a 512-thread, 256-register workgroup owns its CU), and 2x
  * slower on the 64^3 layers - kept as a measured, tested alternative, not the default.  It changes the number of
  * statistics rows a convolution writes (mmtta_conv_plan reports it): set before planning.

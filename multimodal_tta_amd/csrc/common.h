@@ -87,6 +87,33 @@ __device__ __forceinline__ void ld8_any(const float* base, long long eoff, int b
   }
 }
 
+// raw 8-channel items (converted when they are committed: a conversion right behind the load would wait for it)
+template <bool BF> struct Oct8 { float4 lo, hi; };
+template <> struct Oct8<true> { uint4 q; };
+// `base` points at the batch item (wave-uniform), the offsets are ELEMENTS below 2^31 (checked on the host): the loads
+// take the scalar-base + 32-bit-offset form, no 64-bit vector arithmetic
+template <bool BF>
+__device__ __forceinline__ Oct8<BF> oct8_ld(const float* base, unsigned eoff_lo, unsigned eoff_hi) {
+  Oct8<BF> o;
+  if constexpr (BF) {
+    o.q = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + eoff_lo);
+  } else {
+    o.lo = *reinterpret_cast<const float4*>(base + eoff_lo);
+    o.hi = *reinterpret_cast<const float4*>(base + eoff_hi);
+  }
+  return o;
+}
+__device__ __forceinline__ void oct8_f8(const Oct8<false>& o, float (&v)[8]) {
+  v[0] = o.lo.x; v[1] = o.lo.y; v[2] = o.lo.z; v[3] = o.lo.w; v[4] = o.hi.x; v[5] = o.hi.y; v[6] = o.hi.z; v[7] = o.hi.w;
+}
+__device__ __forceinline__ void oct8_f8(const Oct8<true>& o, float (&v)[8]) {
+  v[0] = bf16_bits_to_f32(o.q.x & 0xffffu); v[1] = __uint_as_float(o.q.x & 0xffff0000u);
+  v[2] = bf16_bits_to_f32(o.q.y & 0xffffu); v[3] = __uint_as_float(o.q.y & 0xffff0000u);
+  v[4] = bf16_bits_to_f32(o.q.z & 0xffffu); v[5] = __uint_as_float(o.q.z & 0xffff0000u);
+  v[6] = bf16_bits_to_f32(o.q.w & 0xffffu); v[7] = __uint_as_float(o.q.w & 0xffff0000u);
+}
+
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) - the index is usable as a template argument
 // and an array subscript that never becomes a run-time value (register arrays stay in registers)
 template <int I, int N, class F>
@@ -94,6 +121,14 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
     f(std::integral_constant<int, I>{});
     static_for<I + 1, N>(f);
+  }
+}
+
+template <int I, int N, int STEP, class F>
+__device__ __forceinline__ void static_for_step(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_step<I + STEP, N, STEP>(f);
   }
 }
 

@@ -79,6 +79,7 @@ struct GArgs {
   int ovec;        // 16-byte epilogue stores (out / add rows 16-byte aligned, Co % 4 == 0)
   int pipeline;    // box-load software pipeline on (MMTTA_OPT_IGEMM_PIPELINE; default 1)
   int coef_off;    // word offset of the coefficient table behind the LDS box image
+  int rowload;     // the input admits the row-structured loader (alignment, 24-bit strides, < 2^31 elements)
   int ncls, tiles_per_cls;
   ClassInfo cls[8];
   int toff[27];   // box-relative voxel offset of each tap (int32 tables: read with SCALAR loads)
@@ -136,6 +137,75 @@ __device__ __forceinline__ void epilogue_vec16(const GArgs& a, const ClassInfo& 
   const float* addb = a.add;
   float* outb = a.out;
   const long long abase = (long long)n * a.asn + colc, obase = (long long)n * a.osn + colc;
+  // value path of one (block, row slot): bias, fused add, accumulate, store, statistics - shared by both address paths
+  auto finish = [&](const float4& val, const float4& addq, const float4& oldq, bool okk, int oo) {
+    float v[4] = {val.x + bias4.x, val.y + bias4.y, val.z + bias4.z, val.w + bias4.w};
+    if (a.add) {
+      const float av[4] = {addq.x, addq.y, addq.z, addq.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += nl_apply(av[j], asc[j], ash[j], a.tadd.relu);
+    }
+    if (a.accumulate) { v[0] += oldq.x; v[1] += oldq.y; v[2] += oldq.z; v[3] += oldq.w; }
+    if (okk) {
+      if (!(a.pipeline & 2)) st4_t<ABF>(outb, obase + oo, make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+    }
+  };
+  // Interior tiles of the un-decomposed ops (every row inside the tensor, output voxel = grid voxel): the offsets of the
+  // 4 row slots of a block are wave-uniform terms plus two per-lane constants (the row permutation keeps x = 4 (k & 1) +
+  // (lane >> 3 & 3) and picks y from one of two compile-time values by lane bit 5), ~2 vector instructions per row
+  // instead of ~35 (decode, bounds, clamps, six 32-bit multiplies); and because nothing depends on the accumulators, the
+  // fused-add (or accumulate) operand of ALL blocks is requested up front - one exposed round trip per tile, not one per
+  // block (the weight-fragment registers are free by now).
+  const bool interior = PERM && so == 1 && coz == 0 && coy == 0 && cox == 0 && gz0 + TZ <= min(cDg, Do) && gy0 + TY <= min(cHg, Ho) &&
+                        gx0 + TX <= min(cWg, Wo);
+  if (interior) {
+    const bool lb = (rsub >> 2) != 0;
+    const int lxo = (rsub & 3) * osw, lxa = (rsub & 3) * asw;
+    constexpr int T = 0xEB14;                         // row_to_local's y table
+    auto row_off = [&](int mb, int k, int sd_, int sh_, int sw_, int lx) {     // (block, row slot) -> element offset
+      const int rb = rowblock0 + mb;
+      const int zl = TY == 4 ? rb : (rb >> 1), yb = TY == 4 ? 0 : (rb & 1) * 4;
+      const int u = (gz0 + zl) * sd_ + (gy0 + yb) * sh_ + (gx0 + 4 * (k & 1)) * sw_;              // wave-uniform
+      const int y0 = (T >> (2 * (2 * k))) & 3, y1 = (T >> (2 * (2 * k + 1))) & 3;
+      return (lb ? u + y1 * sh_ : u + y0 * sh_) + lx;
+    };
+    const bool one_operand = (a.add != nullptr) != (a.accumulate != 0);
+    float4 pre[MB][4];
+    if (one_operand) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          pre[mb][k] = a.add ? ld4_t<ABF>(addb, abase + row_off(mb, k, asd, ash_, asw, lxa))
+                             : ld4_t<ABF>(outb, obase + row_off(mb, k, osd, osh, osw, lxo));
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tr[((i & 3) + 8 * (i >> 2) + 4 * h) * 36 + r] = acc[mb][i];
+      float4 val[4], addv[4], oldv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) val[k] = *reinterpret_cast<const float4*>(tr + (rsub + 8 * k) * 36 + c4);
+      if (!one_operand) {
+        if (a.add) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) addv[k] = ld4_t<ABF>(addb, abase + row_off(mb, k, asd, ash_, asw, lxa));
+        }
+        if (a.accumulate) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) oldv[k] = ld4_t<ABF>(outb, obase + row_off(mb, k, osd, osh, osw, lxo));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int oo = row_off(mb, k, osd, osh, osw, lxo);
+        if (one_operand) finish(val[k], pre[mb][k], pre[mb][k], cvok, oo);
+        else finish(val[k], addv[k], oldv[k], cvok, oo);
+      }
+    }
+  } else {
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -166,20 +236,8 @@ __device__ __forceinline__ void epilogue_vec16(const GArgs& a, const ClassInfo& 
       for (int k = 0; k < 4; ++k) oldv[k] = ld4_t<ABF>(outb, obase + ooff[k]);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v[4] = {val[k].x + bias4.x, val[k].y + bias4.y, val[k].z + bias4.z, val[k].w + bias4.w};
-      if (a.add) {
-        const float av[4] = {addv[k].x, addv[k].y, addv[k].z, addv[k].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += nl_apply(av[j], asc[j], ash[j], a.tadd.relu);
-      }
-      if (a.accumulate) { v[0] += oldv[k].x; v[1] += oldv[k].y; v[2] += oldv[k].z; v[3] += oldv[k].w; }
-      if (ok[k]) {
-        if (!(a.pipeline & 2)) st4_t<ABF>(outb, obase + ooff[k], make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
-      }
-    }
+    for (int k = 0; k < 4; ++k) finish(val[k], addv[k], oldv[k], ok[k], ooff[k]);
+  }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -263,53 +321,82 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
   const float* inb = a.in;
   const long long inoff = (long long)n * a.isn;
 
-  // Software pipeline of the box loads (bf16, full 3x3x3 stride-1 stages): the first NPF items of a thread for stage
-  // ks+1 are requested DURING the MFMA phase of stage ks - after its last weight-fragment request, because loads return
-  // in order and a weight fetch issued behind them would wait for them - and converted / written to LDS after the
-  // barrier that ends the phase.  The HBM / L2 round trip of the box then hides behind 2/3 of the MFMAs instead of
-  // opening every stage (measured before: 35 % of a workgroup's life was the load burst).
-  constexpr int PCV8 = BF ? KCI / 8 : 1;
-  constexpr int PSTEP = 256 / PCV8;
-  constexpr int PNI = ((TZ + 2) * (TY + 2) * (TX + 2) + PSTEP - 1) / PSTEP;    // items per thread of the stride-1 3x3x3 box
-  // register budget (two workgroups per CU: 256 per lane): the 16-channel stages have ~34 registers to spare, the
-  // 32-channel stages none (their two weight-fragment sets take 80) - those keep the unpipelined order
-  constexpr int NPF = (BF && KCI == 16 && OCC <= 2) ? (PNI < 3 ? PNI : 3) : 0;           // of which prefetched (8 registers each)
-  constexpr int NPFA = NPF > 0 ? NPF : 1;
-  float4 pfa[NPFA], pfb[NPFA];
+  // Row-structured loader of the bf16 3x3x3 stride-1 stages (the bulk of the network).  With several volumes in flight
+  // the chip is bound by vector-ALU issue (profiles/r02c_sq_counters.md) and the generic walk below spends ~100 vector
+  // instructions per 8-channel item on index decoding, bounds and 64-bit addressing.  Here an item's geometry is paid
+  // ONCE PER TILE: a thread owns one (x, channel chunk) column of the box and walks the box rows RPP at a time, so its
+  // 32-bit element offset of pass P (voff[P], channel base folded into the wave-uniform pointer) and its in-bounds bit
+  // are the same for every stage, the LDS address is a per-thread constant plus an immediate, and a stage costs the
+  // conversion / norm-on-load / pack only.  The first PG passes of stage ks+1 are requested during the MFMA phase of
+  // stage ks - after its last weight-fragment request, because loads return in order - and land under it.
+  constexpr int RCV8 = BF ? KCI / 8 : 1;                  // 8-channel chunks per voxel
+  constexpr int RBY = TY + 2, RBZ = TZ + 2, RBX = TX + 2;
+  constexpr int RIPR = RBX * RCV8;                        // items per box row
+  constexpr int RRPP = 256 / RIPR;                        // box rows per pass (threads beyond repeat the last row)
+  constexpr int RNROW = RBZ * RBY;
+  constexpr int RGP = (RNROW + RRPP - 1) / RRPP;          // passes per stage
+  constexpr int RPG = !BF ? 0 : (OCC > 2 ? 0 : (KCI == 16 ? (ABF ? 4 : 2) : 0));   // of which prefetched across the MFMA phase
+  constexpr int RGPA = BF ? RGP : 1;
+  const bool fast = BF && a.rowload && ci.ntaps == 27 && a.si == 1;      // workgroup-uniform: all 256 threads stage
+  const bool pipe = fast && RPG > 0;
+  Oct8<ABF> gv[RGPA];
+  unsigned voff[RGPA];
   unsigned pok = 0u;
-  const bool pipe = NPF > 0 && a.vec4 && a.pipeline && ci.ntaps == 27 && a.si == 1 && (a.Ci % KCI) == 0 && colact;
+  // the 16-channel stages keep the offsets across the stages; the 32-channel stages have no registers to spare during
+  // their MFMA phase (two weight-fragment sets of 40) and rebuild them per stage (~12 instructions per item, still 1/8 of
+  // the generic walk) - `rrsub` goes through an opaque copy there, or the compiler hoists the rebuild out of the K loop
+  constexpr bool RHOIST = KCI == 16;
+  const int rrsub = min(tid / RIPR, RRPP - 1), rrem = tid % RIPR, rbx = rrem / RCV8, rcv = rrem % RCV8;
+  auto geometry = [&]() {
+    int rs = rrsub;
+    if constexpr (!RHOIST) asm volatile("" : "+v"(rs));
+    const int ix = ix0 + rbx;
+    const bool xok = (unsigned)ix < (unsigned)a.Wi;
+    const unsigned xoff = __umul24((unsigned)min(max(ix, 0), a.Wi - 1), (unsigned)a.isw) + rcv * 8;
+    pok = 0u;
+    static_for<0, RGP>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      const int row = min(RRPP * P + rs, RNROW - 1);
+      const int bz = row / RBY, by = row - bz * RBY;
+      const int iz = iz0 + bz, iy = iy0 + by;
+      const bool ok = xok && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi;
+      pok |= (ok ? 1u : 0u) << P;
+      voff[P] = __umul24((unsigned)min(max(iz, 0), a.Di - 1), (unsigned)a.isd) + __umul24((unsigned)min(max(iy, 0), a.Hi - 1), (unsigned)a.ish) + xoff;
+    });
+  };
+  unsigned short* lh0 = reinterpret_cast<unsigned short*>(lds);
+  unsigned short* rst = lh0 + (rrsub * LDS_PITCH_BF16 + rbx) * VS + rcv * 8;       // + P * RRPP * LDS_PITCH_BF16 * VS
   // norm-on-load coefficients of every channel this workgroup will stage, once, in LDS behind the box image (a
   // per-stage fetch from global memory would be an exposed round trip in front of every commit)
   float* coef = lds + a.coef_off;
   const int cbase = ks0 * KCI, nch = (ks1 - ks0) * KCI;
-  if (pipe) {
+  if (fast) {
     for (int cch = tid; cch < nch; cch += 256) {
-      float sc1, sh1;
-      nl_coeff(a.tin, n, a.Ci, min(cbase + cch, a.Ci - 1), sc1, sh1);
+      float sc1 = 0.f, sh1 = 0.f;
+      if (cbase + cch < a.Ci) nl_coeff(a.tin, n, a.Ci, cbase + cch, sc1, sh1);     // channels past the last one stage as zeros
       coef[cch] = sc1;
       coef[nch + cch] = sh1;
     }
+    if constexpr (RHOIST) geometry();
   }
-  auto issue = [&](int ks) {
-    const int c = ks * KCI + (tid % PCV8) * 8;
-    pok = 0u;
-#pragma unroll
-    for (int i = 0; i < NPF; ++i) {
-      const int bv = tid / PCV8 + i * PSTEP;
-      const int bvc = min(bv, boxvox - 1);
-      const int bz = (int)__umulhi((unsigned)bvc, ci.mBXY), brem = bvc - bz * ci.BXY;
-      const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
-      const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
-      const bool ok = bv < boxvox && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-      pok |= (ok ? 1u : 0u) << i;
-      // unconditional loads from clamped (always valid) addresses, masked when they are committed
-      const long long so = (long long)min(max(iz, 0), a.Di - 1) * a.isd + (long long)min(max(iy, 0), a.Hi - 1) * a.ish +
-                           (long long)min(max(ix, 0), a.Wi - 1) * a.isw + c;
-      ld8_t<ABF>(inb, inoff + so, pfa[i], pfb[i]);
-    }
+  // channel part of an item's address: wave-uniform (folded into the pointer); the last stage of a Ci that is no multiple
+  // of KCI clamps to the last valid chunk (its coefficients are zero)
+  auto stage_base = [&](int ks) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + ((long long)n * a.isn + (long long)ks * KCI) * (ABF ? 2 : 4));
   };
-  if (pipe && ks0 < ks1) {
-    issue(ks0);
+  const int cmax8 = ABF ? ((a.Ci - 1) & ~7) : ((a.Ci - 1) & ~3);
+  auto load_item = [&](auto pc, const float* sb, int c0) {
+    constexpr int P = decltype(pc)::value;
+    // chunks past the tensor's last one (partial last stage) re-read the last valid chunk; their coefficients are zero
+    const int over = max(c0 + rcv * 8 - cmax8, 0), over_hi = max(c0 + rcv * 8 + 4 - cmax8, 0);
+    gv[P] = oct8_ld<ABF>(sb, voff[P] - over, voff[P] + 4 - over_hi);
+  };
+  auto issue = [&](int ks) {
+    const float* sb = stage_base(ks);
+    static_for<0, RPG>([&](auto pc) { load_item(pc, sb, ks * KCI); });
+  };
+  if (fast && ks0 < ks1) {
+    if (pipe) issue(ks0);
     __syncthreads();      // coefficients visible
   }
 
@@ -336,43 +423,50 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
     // ---------------- stage the input box (KCI channels) into LDS ----------------
     if constexpr (BF) {
       unsigned short* lh = reinterpret_cast<unsigned short*>(lds);
-      if (a.vec4) {
+      if (fast) {
+        const float* sb = stage_base(ks);
+        // what the prefetch had no registers for comes in rounds of RB passes (all loads of a round in flight together);
+        // the first round is requested before the prefetched passes are committed
+        constexpr int RB = ABF ? 6 : 4;
+        constexpr int R1 = RPG + RB < RGP ? RPG + RB : RGP;
+        if constexpr (!RHOIST) geometry();
+        static_for<RPG, R1>([&](auto pc) { load_item(pc, sb, c0); });
+        float sc[8], sh[8];
+        {
+          const float4* cq = reinterpret_cast<const float4*>(coef + (c0 - cbase) + rcv * 8);
+          const float4* hq = reinterpret_cast<const float4*>(coef + nch + (c0 - cbase) + rcv * 8);
+          const float4 s0 = cq[0], s1 = cq[1], h0 = hq[0], h1 = hq[1];
+          sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+          sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+        }
+        const float relu_lo = a.tin.relu ? 0.f : -__builtin_inff();
+        auto commit_item = [&](auto pc) {
+          constexpr int P = decltype(pc)::value;
+          float v[8];
+          oct8_f8(gv[P], v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), relu_lo);
+          const unsigned okm = ((pok >> P) & 1u) ? 0xffffffffu : 0u;
+          uint4 pk;
+          pk.x = pack_bf16x2(v[0], v[1]) & okm; pk.y = pack_bf16x2(v[2], v[3]) & okm;
+          pk.z = pack_bf16x2(v[4], v[5]) & okm; pk.w = pack_bf16x2(v[6], v[7]) & okm;
+          if (RNROW % RRPP == 0 || P + 1 < RGP || RRPP * P + rrsub < RNROW)       // the last pass may be partial
+            *reinterpret_cast<uint4*>(rst + P * (RRPP * LDS_PITCH_BF16 * VS)) = pk;
+        };
+        static_for<0, R1>(commit_item);
+        static_for_step<R1, RGP, RB>([&](auto r0) {
+          constexpr int A = decltype(r0)::value, B = A + RB < RGP ? A + RB : RGP;
+          static_for<A, B>([&](auto pc) { load_item(pc, sb, c0); });
+          static_for<A, B>(commit_item);
+        });
+      } else if (a.vec4) {
         constexpr int CV8 = KCI / 8;
         const int cv = tid % CV8;          // 256 % CV8 == 0
         const int c = c0 + cv * 8;
         float sc[8], sh[8];
         constexpr int STEP = 256 / CV8;
-        int first_item = 0;
-        if (pipe) {
-          {
-            const float4* cq = reinterpret_cast<const float4*>(coef + (c - cbase));
-            const float4* hq = reinterpret_cast<const float4*>(coef + nch + (c - cbase));
-            const float4 s0 = cq[0], s1 = cq[1], h0 = hq[0], h1 = hq[1];
-            sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
-            sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
-          }
-#pragma unroll
-          for (int i = 0; i < NPF; ++i) {
-            const int bv = tid / CV8 + i * STEP;
-            if (bv < boxvox) {
-              uint4 pk = make_uint4(0u, 0u, 0u, 0u);
-              if ((pok >> i) & 1u) {
-                const float xs[8] = {pfa[i].x, pfa[i].y, pfa[i].z, pfa[i].w, pfb[i].x, pfb[i].y, pfb[i].z, pfb[i].w};
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = nl_apply(xs[j], sc[j], sh[j], a.tin.relu);
-                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-                pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
-              }
-              const int bz = (int)__umulhi((unsigned)bv, ci.mBXY), brem = bv - bz * ci.BXY;
-              const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
-              *reinterpret_cast<uint4*>(lh + ((bz * BY + by) * LP + bx) * VS + cv * 8) = pk;
-            }
-          }
-          first_item = NPF;
-        } else {
-          nl_coeff_vec<8>(a.tin, n, a.Ci, c, sc, sh);
-        }
+        const int first_item = 0;
+        nl_coeff_vec<8>(a.tin, n, a.Ci, c, sc, sh);
         // U items per trip: all their global loads are issued before the first use (one exposed latency per
         // trip instead of one per item)
         // all of a thread's items in as few trips as the register budget allows: one exposed memory latency per trip
@@ -1671,7 +1765,7 @@ static int launch_cfg_t(const GArgs& a_in, const Taps* ht, int tiles, hipStream_
   lds = (lds + 15) / 16 * 16;
   const size_t lds_box = lds;
   a.coef_off = (int)(lds / sizeof(float));
-  if (BF && KCI == 16) lds += (size_t)2 * a.stages_per_split * KCI * sizeof(float);     // scale | shift of the staged channels
+  if (BF) lds += (size_t)2 * a.stages_per_split * KCI * sizeof(float);     // scale | shift of the staged channels
   MMTTA_CHECK(lds <= 160 * 1024, MMTTA_ERR_UNSUPPORTED, "conv: LDS box of %zu bytes exceeds 160 KiB", lds);
   int st;
   if constexpr (BF) {
@@ -1935,6 +2029,12 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   const bool al = (((uintptr_t)x->ptr) % 16 == 0) && x->sw % am == 0 && x->sh % am == 0 && x->sd % am == 0 && x->sn % am == 0;
   a.vec4 = al ? 1 : 0;
   a.pipeline = g_igemm_pipeline;
+  {  // row-structured loader of the 3x3x3 stride-1 stages: 32-bit element offsets from 24-bit multiply-adds
+    const int64_t lim24 = (int64_t)1 << 24;
+    const int64_t last = (int64_t)(x->d - 1) * x->sd + (int64_t)(x->h - 1) * x->sh + (int64_t)(x->w - 1) * x->sw + x->c + 16;
+    a.rowload = (al && x->sd < lim24 && x->sh < lim24 && x->sw < lim24 && x->d < lim24 && x->h < lim24 && x->w < lim24 &&
+                 last < ((int64_t)1 << 31) && (g_igemm_pipeline & 1)) ? 1 : 0;
+  }
   a.ovec = 0;       // set below once the epilogue operands are known
   Taps ht[8];
   a.ncls = g.classes ? 8 : 1;

@@ -821,32 +821,6 @@ typedef __attribute__((address_space(3))) wshort4* wlds4_t;
                                                       __builtin_amdgcn_ds_read_tr16_b64_v4i16((wlds4_t)((ptr) + (off) + 256)), \
                                                       0, 1, 2, 3, 4, 5, 6, 7))
 
-// raw 8-channel items (converted when they are committed: a conversion right behind the load would wait for it)
-template <bool BF> struct WOct { float4 lo, hi; };
-template <> struct WOct<true> { uint4 q; };
-// `base` points at the batch item (wave-uniform), the offsets are ELEMENTS below 2^31 (checked on the host): the loads
-// take the scalar-base + 32-bit-offset form, no 64-bit vector arithmetic
-template <bool BF>
-__device__ __forceinline__ WOct<BF> woct_ld(const float* base, unsigned eoff_lo, unsigned eoff_hi) {
-  WOct<BF> o;
-  if constexpr (BF) {
-    o.q = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + eoff_lo);
-  } else {
-    o.lo = *reinterpret_cast<const float4*>(base + eoff_lo);
-    o.hi = *reinterpret_cast<const float4*>(base + eoff_hi);
-  }
-  return o;
-}
-__device__ __forceinline__ void woct_f8(const WOct<false>& o, float (&v)[8]) {
-  v[0] = o.lo.x; v[1] = o.lo.y; v[2] = o.lo.z; v[3] = o.lo.w; v[4] = o.hi.x; v[5] = o.hi.y; v[6] = o.hi.z; v[7] = o.hi.w;
-}
-__device__ __forceinline__ void woct_f8(const WOct<true>& o, float (&v)[8]) {
-  v[0] = bf16_bits_to_f32(o.q.x & 0xffffu); v[1] = __uint_as_float(o.q.x & 0xffff0000u);
-  v[2] = bf16_bits_to_f32(o.q.y & 0xffffu); v[3] = __uint_as_float(o.q.y & 0xffff0000u);
-  v[4] = bf16_bits_to_f32(o.q.z & 0xffffu); v[5] = __uint_as_float(o.q.z & 0xffff0000u);
-  v[6] = bf16_bits_to_f32(o.q.w & 0xffffu); v[7] = __uint_as_float(o.q.w & 0xffff0000u);
-}
-
 // Staging is the vector-ALU cost of this kernel, and with several volumes in flight vector-ALU issue is what bounds the
 // chip (profiles/r02c_sq_counters.md), so the loader is built for few instructions per element:
 //  * an item is 8 channels; a thread owns one (x, chunk) column of the box: x bounds, x / channel offsets, the x
@@ -914,8 +888,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
   constexpr int PREF = 40;                                             // registers the cross-loop prefetch may hold
   constexpr int PGmax = (PREF - DP * (DBF ? 4 : 8)) / (GBF ? 4 : 8);
   constexpr int PG = PGmax < 0 ? 0 : (PGmax < GP ? PGmax : GP);        // box passes prefetched across the MFMA loop
-  WOct<GBF> gv[GP];
-  WOct<DBF> dq[DP];
+  Oct8<GBF> gv[GP];
+  Oct8<DBF> dq[DP];
   unsigned pok = 0u;                             // bit p: box item of pass p lies inside the tensor
   unsigned dok = 0u;                             // bit p: dense item p lies inside the tensor
   int pn = -1, poz0 = 0, poy0 = 0, pox0 = 0;     // tile whose loads are in gv[0..PG) / dq
@@ -949,12 +923,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
     const bool ok = zk && gxok && (unsigned)iy < (unsigned)a.Hgg;
     pok |= (ok ? 1u : 0u) << P;
     const unsigned off = zo + __umul24((unsigned)min(max(iy, 0), a.Hgg - 1), gsh) + gxoff;
-    gv[P] = woct_ld<GBF>(gbase, off + gc_lo, off + gc_hi);
+    gv[P] = oct8_ld<GBF>(gbase, off + gc_lo, off + gc_hi);
   };
   auto commit_g = [&](auto pc, const float (&sc)[8], const float (&sh)[8]) {
     constexpr int P = decltype(pc)::value;
     float v[8];
-    woct_f8(gv[P], v);
+    oct8_f8(gv[P], v);
     if constexpr (!TD) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), relu_lo);
@@ -985,7 +959,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
       const int oz = poz0 + dzl + p * (64 / (TY * 8));
       dok |= ((yxok && oz < a.Dd) ? 1u : 0u) << p;
       const unsigned off = __umul24((unsigned)min(oz, a.Dd - 1), dsd) + yxoff;
-      dq[p] = woct_ld<DBF>(dbase, off + dc_lo, off + dc_hi);
+      dq[p] = oct8_ld<DBF>(dbase, off + dc_lo, off + dc_hi);
     }
     pok = 0u;
     tile_x(pox0 * SI - 1);
@@ -1024,7 +998,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
 #pragma unroll
     for (int p = 0; p < DP; ++p) {
       float v[8];
-      woct_f8(dq[p], v);
+      oct8_f8(dq[p], v);
       if constexpr (TD) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), relu_lo);

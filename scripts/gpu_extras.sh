@@ -1,16 +1,20 @@
 #!/bin/bash
-# Extra GPU checks of a round: smoke(), the HECKTOR-shaped and deep-fusion bench configurations, PMC passes.
+# Extra GPU checks of a round: smoke(), the other bench configurations (each with its roofline block), whole-volume PMC.
 set -e -o pipefail
 out=gpurun_out/${1:-extras}
 mkdir -p $out
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1 || { tail -20 $out/smoke.log; exit 1; }
 tail -1 $out/smoke.log
-timeout -k 10 400 python bench.py --task hecktor21 --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass > $out/bench_hecktor.json 2> $out/bench_hecktor.err || { tail -20 $out/bench_hecktor.err; exit 1; }
-python -c "import json;d=json.load(open('$out/bench_hecktor.json'));print('hecktor unet', d['value'], d['ms_per_step'], d['config']['workload'][:60])"
-timeout -k 10 500 python bench.py --model unet_multimodal_deepfusion --steps 3 --warmup 1 --no-cpu-baseline --no-profile-pass > $out/bench_deepfusion.json 2> $out/bench_deepfusion.err || { tail -20 $out/bench_deepfusion.err; exit 1; }
-python -c "import json;d=json.load(open('$out/bench_deepfusion.json'));print('deepfusion brats', d['value'], d['ms_per_step'])"
-timeout -k 10 300 python bench.py --precision fp32 --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass > $out/bench_fp32.json 2> $out/bench_fp32.err || { tail -20 $out/bench_fp32.err; exit 1; }
-python -c "import json;d=json.load(open('$out/bench_fp32.json'));print('unet fp32', d['value'], d['ms_per_step'])"
-bash scripts/pmc_layers.sh > $out/pmc.log 2>&1 || { tail -20 $out/pmc.log; exit 1; }
-python scripts/pmc_summary.py gpurun_out/pmc_lt/p1/run_results.db gpurun_out/pmc_lt/p2/run_results.db gpurun_out/pmc_lt/p3/run_results.db gpurun_out/pmc_lt/p4/run_results.db --json $out/pmc_traffic.json > $out/pmc_summary.txt
-head -5 $out/pmc_summary.txt | cut -c1-200
+run() {   # name, bench arguments...
+  local name=$1; shift
+  timeout -k 10 500 python bench.py "$@" --no-cpu-baseline --no-variants > $out/bench_$name.json 2> $out/bench_$name.err || { tail -20 $out/bench_$name.err; exit 1; }
+  python -c "import json;d=json.load(open('$out/bench_$name.json'));r=d['roofline'];print('$name', round(d['value'],2), 'vol/s', round(d['ms_per_step'],2), 'ms;', r['kernel'], 'frac', round(r['frac'],3), '| whole volume', {k: round(v,3) for k,v in r['whole_volume'].items() if k.startswith('frac') or k.startswith('eff')})"
+}
+run hecktor_unet --task hecktor21 --steps 8 --warmup 2
+run deepfusion_brats --model unet_multimodal_deepfusion --steps 4 --warmup 1
+run unet_fp32 --precision fp32 --steps 8 --warmup 2
+run brats_full_160x192x160 --shape 160 192 160 --steps 8 --warmup 2
+if [ "$2" != "nopmc" ]; then
+  bash scripts/pmc_bench.sh > $out/pmc.log 2>&1 || { tail -20 $out/pmc.log; exit 1; }
+  cp gpurun_out/pmc_bench/sq_per_kernel.txt gpurun_out/pmc_bench/mem_per_kernel.txt gpurun_out/pmc_bench/traffic.json $out/
+fi

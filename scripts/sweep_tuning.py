@@ -79,7 +79,11 @@ def main():
     ap.add_argument("--lanes", type=int, nargs="+", default=[2])
     ap.add_argument("--volumes", type=int, default=8)
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--quick", action="store_true", help="the neighbourhood of the current defaults only")
     a = ap.parse_args()
+    if a.quick:
+        SETTINGS[:] = [dict(splitk_below=b, splitk_target=t, wgrad_workgroups=w, wgrad_thin_slabs=th)
+                       for (b, t) in ((96, 128), (192, 256)) for (w, th) in ((128, 256), (256, 256), (192, 256), (128, 128), (96, 256))]
     for rep in range(a.repeat):
         for lanes in a.lanes:
             for s in SETTINGS:

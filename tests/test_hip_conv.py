@@ -436,3 +436,49 @@ def test_transposed_read_wgrad(cin, cout, k, stride, transposed, shape, stored):
     assert (out[3][0] - ref).abs().max().item() <= 1.5e-2 * scale + 1e-5
     assert (out[3][0] - out[0][0]).abs().max().item() <= 2e-3 * scale + 1e-6, "differs from the staging-transposed kernel"
     close("bias gradient", out[3][1], mod.bias.grad)
+
+
+@pytest.mark.parametrize("stored", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(32, 32, 3, 1, False, (1, 16, 16, 16)), (33, 32, 3, 1, False, (1, 8, 8, 16)),
+                                  (40, 72, 3, 1, False, (2, 5, 9, 11)), (128, 136, 3, 1, False, (2, 4, 6, 8)),
+                                  (512, 512, 3, 1, False, (1, 4, 4, 4)), (64, 64, 3, 1, False, (1, 8, 8, 8))])
+def test_row_loader_matches_the_generic_loader(case, stored):
+    """MMTTA_OPT_IGEMM_PIPELINE: the row-structured loader of the bf16 3x3x3 stride-1 stages (8-channel items, geometry
+    once per tile, coefficients in LDS, ReLU as max(x, lo)) stages the same bf16 image as the generic walk: forward (with
+    norm-on-load and ReLU, fp32- and bf16-stored input, channel counts that are no multiple of the stage) and input
+    gradient are equal bit for bit, the statistics rows too."""
+    from multimodal_tta_amd import ops
+
+    cin, cout, k, stride, transposed, shape = case
+    n, d, h, w = shape
+    torch.manual_seed(11)
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = (torch.randn(n, cin, d, h, w) * 2 + 0.5).to(torch.bfloat16).float()
+    mu = x.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    outs = {}
+    for mode in (0, 1):
+        prev = ops.set_option(6, mode)
+        try:
+            op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+            op.pack(mod.weight.detach().cuda().contiguous())
+            x_cl = cl_bf16(x) if stored == "bf16" else cl(x)
+            if stored == "bf16":       # input, output and fused add share one storage type
+                y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda", ldc=ops.row_pad(cout, torch.bfloat16), dtype=torch.bfloat16)
+            else:
+                y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda")
+            rows = op.stats_rows(x_cl, y_cl)
+            stats = torch.zeros((rows, 2, cout), device="cuda")
+            op.forward(x_cl, nl, mod.bias.detach().cuda(), y_cl, stats=stats)
+            gy_cl = cl(torch.randn(n, cout, *y_cl.shape[1:4], generator=torch.Generator().manual_seed(5)))
+            dx_cl = ops.new_cl(n, d, h, w, cin, "cuda")
+            op.dgrad(gy_cl, dx_cl)
+            torch.cuda.synchronize()
+            outs[mode] = (y_cl.clone(), dx_cl.clone(), stats.clone())
+        finally:
+            ops.set_option(6, prev)
+    assert torch.isfinite(outs[1][0].float()).all()
+    assert torch.equal(outs[0][0], outs[1][0]), "forward differs"
+    assert torch.equal(outs[0][1], outs[1][1]), "input gradient differs"
+    assert torch.equal(outs[0][2], outs[1][2]), "statistics differ"
