@@ -124,6 +124,13 @@ int mmtta_abi_version(void);
  *      accumulation: equal to 0 within 2e-3 of max|dw|, tests/test_hip_conv.py::test_transposed_read_wgrad). */
 #define MMTTA_OPT_WGRAD_VECTOR_STAGING 11
 #define MMTTA_OPT_IGEMM_WS_WORKGROUPS 8
+/* Stride-2 transposed forms (ConvTranspose3d forward, input gradient of a stride-2 Conv3d) in bf16 mode: when one
+ * workgroup per coarse 4 x 4 x 8 tile and 32 output channels makes at least this many workgroups (default 128), all 8
+ * output parity classes of a tile are produced by ONE workgroup from one staged halo box (csrc/conv_igemm.hip,
+ * igemm_cls8_kernel) instead of 8 x tiles workgroups that each stage their own; 0: never.  Same products, the taps of a
+ * class summed before the channel stages instead of after: equal to the per-class kernel within fp32 summation order.
+ * Changes the statistics rows a convolution writes (mmtta_conv_plan reports them): set before planning. */
+#define MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS 12
 int mmtta_set_option(int key, int value);
 
 /* ------------------------------------------------------------------ layout (boundary) ---- */

@@ -152,6 +152,8 @@ def load() -> C.CDLL:
         lib.mmtta_set_option(9, 0)
     if "MMTTA_WGVEC" in os.environ:                      # A/B aid: MMTTA_OPT_WGRAD_VECTOR_STAGING
         lib.mmtta_set_option(11, int(os.environ["MMTTA_WGVEC"]))
+    if "MMTTA_CLSFUSE" in os.environ:                    # A/B aid: MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS
+        lib.mmtta_set_option(12, int(os.environ["MMTTA_CLSFUSE"]))
     if "MMTTA_LEAN" in os.environ:                       # A/B aid: MMTTA_OPT_IGEMM_LEAN
         lib.mmtta_set_option(10, int(os.environ["MMTTA_LEAN"]))
     if "MMTTA_WS" in os.environ:                         # A/B aid: MMTTA_OPT_IGEMM_PRODUCER_CONSUMER = 0 / 1 / 2

@@ -17,6 +17,7 @@ int g_ws_workgroups = 256;
 void* g_ws_debug = nullptr;
 int g_epilogue_vec = 1;
 int g_igemm_lean = 0;
+int g_cls_fused_min = 128;
 int g_wgrad_vec = 1;
 // split-K below / target, weight-gradient workgroups, thin-layer slabs.  Swept with the lanes bound to their own hardware
 // queues (profiles/r02_tuning_sweep.txt): four volumes in flight want half the splitting two did (96/128, 128 slabs)
@@ -43,6 +44,11 @@ extern "C" int mmtta_set_option(int key, int value) {
   if (key == MMTTA_OPT_WGRAD_VECTOR_STAGING) {
     const int prev = mmtta::g_wgrad_vec;
     mmtta::g_wgrad_vec = value < 0 ? 0 : (value > 3 ? 3 : value);
+    return prev;
+  }
+  if (key == MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS) {
+    const int prev = mmtta::g_cls_fused_min;
+    mmtta::g_cls_fused_min = value < 0 ? 0 : value;
     return prev;
   }
   if (key == MMTTA_OPT_IGEMM_LEAN) {

@@ -905,6 +905,203 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- class-fused stride-2 transposed forms (bf16 operands)
+// ConvTranspose3d forward and the input gradient of a stride-2 Conv3d are 8 output parity classes, each a dense
+// convolution over 1 / 2 / 4 / 8 taps of the coarse input grid (27 taps in all).  igemm_kernel runs them as 8 x tiles
+// independent workgroups that each stage their own halo box for 1-8 taps: per 16-channel stage 4-32 MFMAs per wave
+// against a full staging pass and two barriers (measured: convT 128->32 at 64^3 out = 70 us at 105 TFLOP/s, the slowest
+// implicit-GEMM launches of the network).  Here ONE workgroup produces all 8 classes of a coarse 4 x 4 x 8 tile (= an
+// 8 x 8 x 16 block of the output): the box (tile + 1 on the high side of every axis: all tap offsets are 0 or 1) is staged
+// once, the 27 taps' weight fragments of the stage go through LDS too (every wave needs all of them), and wave w owns
+// row block w (z slice w of the tile) of EVERY class - 27 MFMAs per k step and wave, perfectly balanced, fed by 8
+// activation fragments (one per offset, shared by the classes) and 27 weight fragments from LDS.
+struct ClsTap { int cls, d, slab; };
+__host__ __device__ constexpr ClsTap cls_tap(int f) {        // f-th (class, tap) in class order; d = (dz*2 + dy)*2 + dx
+  int idx = 0;
+  for (int cls = 0; cls < 8; ++cls) {
+    const int pz = (cls >> 2) & 1, py = (cls >> 1) & 1, px = cls & 1;
+    for (int a = 0; a <= pz; ++a)
+      for (int b = 0; b <= py; ++b)
+        for (int c = 0; c <= px; ++c) {
+          // parity 0: k = 1 reads g (d = 0); parity 1: k = 0 reads g + 1, k = 2 reads g   (build_taps)
+          const int kz = pz ? (a == 0 ? 0 : 2) : 1, dz = pz ? (a == 0 ? 1 : 0) : 0;
+          const int ky = py ? (b == 0 ? 0 : 2) : 1, dy = py ? (b == 0 ? 1 : 0) : 0;
+          const int kx = px ? (c == 0 ? 0 : 2) : 1, dx = px ? (c == 0 ? 1 : 0) : 0;
+          if (idx == f) return ClsTap{cls, (dz * 2 + dy) * 2 + dx, (kz * 3 + ky) * 3 + kx};
+          ++idx;
+        }
+  }
+  return ClsTap{0, 0, 0};
+}
+
+template <int KCI, bool ABF>
+__global__ __launch_bounds__(256, 2) void igemm_cls8_kernel(GArgs a) {
+  constexpr int TZ = 4, TY = 4, TX = 8, VS = KCI + 8, LP = LDS_PITCH_BF16, KS = KCI / 16, KC8 = KCI / 8;
+  constexpr int BZ = TZ + 1, BY = TY + 1, BX = TX + 1;
+  constexpr int BOX_HW = BZ * BY * LP * VS;                 // halfwords of the box image
+  constexpr int WIMG = 27 * KC8 * 32;                       // uint4 entries of the stage's weight image
+  extern __shared__ float lds[];
+  unsigned short* lh = reinterpret_cast<unsigned short*>(lds);
+  uint4* wimg = reinterpret_cast<uint4*>(lh + (BOX_HW + 7) / 8 * 8);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  int t = blockIdx.x;
+  const int tile_in_n = t % (a.tz * a.ty * a.tx);
+  const int txi = t % a.tx; t /= a.tx;
+  const int tyi = t % a.ty; t /= a.ty;
+  const int tzi = t % a.tz;
+  const int n = t / a.tz;
+  const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;
+  const int colbase = blockIdx.y * 32;
+  const bool colact = colbase < a.Np;
+
+  int zl, yl, xl;
+  row_to_local<TZ, TY, TX, true>(wave * 32 + r, zl, yl, xl);
+  const unsigned short* arow = lh + ((zl * BY + yl) * LP + xl) * VS + 8 * h;
+  const uint4* brow = wimg + h * 32 + r;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+  const uint4* wq = reinterpret_cast<const uint4*>(a.wp);
+  const long long slabsz8 = (long long)(a.Kp / 8) * a.Np;
+  const unsigned isd = (unsigned)a.isd, ish = (unsigned)a.ish, isw = (unsigned)a.isw;
+  const int cmax = ABF ? ((a.Ci - 1) & ~7) : ((a.Ci - 1) & ~3);
+  constexpr int AIT = (BZ * BY * BX * KC8 + 255) / 256;      // box items per thread
+  constexpr int BIT = (WIMG + 255) / 256;                    // weight entries per thread
+  const float relu_lo = a.tin.relu ? 0.f : -__builtin_inff();
+
+  for (int ks = 0; ks < a.nstages; ++ks) {
+    const int c0 = ks * KCI;
+    const float* sb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + ((long long)n * a.isn + c0) * (ABF ? 2 : 4));
+    // ---- requests first: weights of the stage, norm-on-load coefficients, box items (one round trip for all of them)
+    uint4 wv[BIT];
+#pragma unroll
+    for (int j = 0; j < BIT; ++j) {
+      const int i = min(tid + 256 * j, WIMG - 1);
+      const int tap = i / (KC8 * 32), rem = i - tap * (KC8 * 32), k8l = rem >> 5, col = rem & 31;
+      wv[j] = wq[tap * slabsz8 + (long long)(c0 / 8 + k8l) * a.Np + colbase + col];
+    }
+    Oct8<ABF> av[AIT];
+    unsigned aok = 0u;
+    int alds[AIT];
+#pragma unroll
+    for (int j = 0; j < AIT; ++j) {
+      const int i = min(tid + 256 * j, BZ * BY * BX * KC8 - 1);
+      const int cv = i % KC8, bv = i / KC8;
+      const int bz = bv / (BY * BX), brem = bv - bz * (BY * BX), by = brem / BX, bx = brem - by * BX;
+      const int iz = gz0 + bz, iy = gy0 + by, ix = gx0 + bx;
+      const bool ok = iz < a.Di && iy < a.Hi && ix < a.Wi;
+      aok |= (ok ? 1u : 0u) << j;
+      const unsigned off = __umul24((unsigned)min(iz, a.Di - 1), isd) + __umul24((unsigned)min(iy, a.Hi - 1), ish) +
+                           __umul24((unsigned)min(ix, a.Wi - 1), isw) + cv * 8;
+      const int over = max(c0 + cv * 8 - cmax, 0), over_hi = max(c0 + cv * 8 + 4 - cmax, 0);
+      av[j] = oct8_ld<ABF>(sb, off - over, off + 4 - over_hi);
+      alds[j] = ((bz * BY + by) * LP + bx) * VS + cv * 8;
+    }
+    float sc[AIT][8], sh[AIT][8];
+#pragma unroll
+    for (int j = 0; j < AIT; ++j) {
+      const int i = min(tid + 256 * j, BZ * BY * BX * KC8 - 1);
+      nl_coeff_vec<8>(a.tin, n, a.Ci, c0 + (i % KC8) * 8, sc[j], sh[j]);
+    }
+    // ---- commit
+#pragma unroll
+    for (int j = 0; j < BIT; ++j)
+      if (tid + 256 * j < WIMG) wimg[tid + 256 * j] = wv[j];
+#pragma unroll
+    for (int j = 0; j < AIT; ++j) {
+      float v[8];
+      oct8_f8(av[j], v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = fmaxf(fmaf(v[q], sc[j][q], sh[j][q]), relu_lo);
+      const unsigned okm = ((aok >> j) & 1u) ? 0xffffffffu : 0u;
+      uint4 pk;
+      pk.x = pack_bf16x2(v[0], v[1]) & okm; pk.y = pack_bf16x2(v[2], v[3]) & okm;
+      pk.z = pack_bf16x2(v[4], v[5]) & okm; pk.w = pack_bf16x2(v[6], v[7]) & okm;
+      if (tid + 256 * j < BZ * BY * BX * KC8) *reinterpret_cast<uint4*>(lh + alds[j]) = pk;
+    }
+    __syncthreads();
+    // ---- MFMAs: 8 activation fragments per k step (one per tap offset), then the 27 (class, tap) products; weight
+    // fragment f is read LA products ahead through a ring (a fence per MFMA keeps the reads where they are written)
+    if (colact) {
+#pragma unroll
+      for (int k16 = 0; k16 < KS; ++k16) {
+        uint4 af[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+          af[d] = *reinterpret_cast<const uint4*>(arow + ((((d >> 2) & 1) * BY + ((d >> 1) & 1)) * LP + (d & 1)) * VS + k16 * 16);
+        constexpr int LA = 3;
+        uint4 bring[LA + 1];
+        static_for<0, LA>([&](auto fc) {
+          constexpr int f = decltype(fc)::value;
+          bring[f] = brow[(cls_tap(f).slab * KC8 + k16 * 2) * 32];
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 27>([&](auto fc) {
+          constexpr int f = decltype(fc)::value;
+          constexpr ClsTap ct = cls_tap(f);
+          if constexpr (f + LA < 27) bring[(f + LA) % (LA + 1)] = brow[(cls_tap(f + LA).slab * KC8 + k16 * 2) * 32];
+          acc[ct.cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ct.d]),
+                                                                __builtin_bit_cast(bf16x8, bring[f % (LA + 1)]), acc[ct.cls], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: every class's 32 x 32 block through this wave's LDS transposition tile (the box image is dead)
+  float tsum[4] = {0.f, 0.f, 0.f, 0.f}, tsq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float v_sum[4], v_sq[4];
+    epilogue_vec16<TZ, TY, TX, 1, true, ABF>(a, a.cls[c], *reinterpret_cast<f32x16(*)[1]>(&acc[c]), lds + wave * EPI_TILE_FLOATS, lane,
+                                             wave, colbase, colact, n, gz0, gy0, gx0, v_sum, v_sq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { tsum[j] += v_sum[j]; tsq[j] += v_sq[j]; }
+  }
+  if (a.stats != nullptr) {
+    float* red = lds + 4 * EPI_TILE_FLOATS;      // [4 waves][2][32], behind the four tiles
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[(wave * 2 + 0) * 32 + lane * 4 + j] = tsum[j];
+        red[(wave * 2 + 1) * 32 + lane * 4 + j] = tsq[j];
+      }
+    }
+    __syncthreads();
+    const int col = colbase + tid;
+    if (tid < 32 && col < a.Co) {
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { ts += red[(g * 2 + 0) * 32 + tid]; tq += red[(g * 2 + 1) * 32 + tid]; }
+      const long long row = (long long)n * a.stats_rows_per_n + tile_in_n;
+      a.stats[(row * 2 + 0) * a.Co + col] = ts;
+      a.stats[(row * 2 + 1) * a.Co + col] = tq;
+    }
+  }
+}
+
+template <int KCI, bool ABF>
+static int launch_cls8_t(const GArgs& a, int tiles, hipStream_t s) {
+  constexpr int VS = KCI + 8;
+  size_t lds = ((size_t)(5 * 5 * LDS_PITCH_BF16 * VS + 7) / 8 * 8) * 2 + (size_t)27 * (KCI / 8) * 32 * 16;
+  const size_t epi = (4 * EPI_TILE_FLOATS + 4 * 2 * 32) * sizeof(float);
+  if (lds < epi) lds = epi;
+  auto kern = igemm_cls8_kernel<KCI, ABF>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles, a.Np / 32), dim3(256), lds, s, a);
+  return launch_status("conv igemm (class-fused stride-2 form)");
+}
+
 // ---------------------------------------------------------------- producer / consumer form (bf16 operands)
 // The same gather GEMM with the two halves of a stage on DIFFERENT waves of one 512-thread workgroup per CU:
 //   waves 4-7 (loaders)   fetch the input box of step i+1 from HBM / L2, apply norm + ReLU, round to bf16 and write
@@ -1632,6 +1829,7 @@ struct Geometry {
   int nstages, ksplit, sps;
   int launches;
   bool ws;        // producer / consumer kernel (bf16 operands)
+  bool fused;     // class-fused kernel of the stride-2 transposed forms (its own tiling: coarse 4 x 4 x 8, one row per tile)
 };
 
 static int expected_out_dim(const mmtta_conv_desc* d, int in) {
@@ -1694,12 +1892,35 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
     g.sps = (g.nstages + want - 1) / want;
     g.ksplit = (g.nstages + g.sps - 1) / g.sps;
   }
+  // Class-fused kernel (MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS): all 8 parity classes of a coarse 4 x 4 x 8 tile in one
+  // workgroup, when that still makes enough workgroups (no split-K there) and the tensors admit its 16-byte accesses
+  g.fused = false;
+  if (g.classes && g.cfg.bf && g_cls_fused_min > 0) {
+    const int ftz = (Dg + 3) / 4, fty = (Hg + 3) / 4, ftx = (Wg + 7) / 8;
+    const long long fw = (long long)ftz * fty * ftx * x->n * (g.Np / 32);
+    auto al = [](const mmtta_tensor* t) {
+      const int64_t q = is_bf16(t) ? 8 : 4, lim24 = (int64_t)1 << 24;
+      const int64_t last = (int64_t)(t->d - 1) * t->sd + (int64_t)(t->h - 1) * t->sh + (int64_t)(t->w - 1) * t->sw + t->c + 16;
+      return ((uintptr_t)t->ptr) % 16 == 0 && t->sw % q == 0 && t->sh % q == 0 && t->sd % q == 0 && t->sn % q == 0 &&
+             t->sw < lim24 && t->sh < lim24 && t->sd < lim24 && last < ((int64_t)1 << 31);
+    };
+    if (fw >= g_cls_fused_min && al(x) && al(y) && y->c % 4 == 0 && is_bf16(x) == is_bf16(y) && g_epilogue_vec) {
+      g.fused = true;
+      g.tz = ftz; g.ty = fty; g.tx = ftx;
+      g.tiles_per_n = ftz * fty * ftx;
+      g.ncls = 1;                                  // one statistics row per fused tile
+      g.tiles = g.tiles_per_n * x->n;
+      g.nstages = (g.K + 15) / 16;
+      g.ksplit = 1; g.sps = g.nstages; g.ws = false;
+    }
+  }
   return MMTTA_OK;
 }
 
 // statistics rows written per tile: 1 by the conv epilogue, MT/32 by the split-K finalize
 // (the producer / consumer kernel: one row per consumer wave group, 4 / NB of them)
 static int stats_rows_per_tile(const Geometry& g) {
+  if (g.fused) return 1;
   return g.ksplit > 1 ? g.cfg.TZ * g.cfg.TY * g.cfg.TX / 32 : (g.ws ? 4 / g.cfg.NB : 1);
 }
 
@@ -1965,7 +2186,7 @@ extern "C" int mmtta_conv_plan(const mmtta_conv_desc* d, const mmtta_tensor* x, 
   plan->launches = g.launches;
   plan->ksplit = g.ksplit;
   plan->stats_rows = g.tiles * stats_rows_per_tile(g);
-  plan->config = config_id(g.cfg);
+  plan->config = g.fused ? 15 : config_id(g.cfg);
   plan->_pad = 0;
   plan->workspace_bytes =
       g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * (int64_t)sizeof(float) : 0;
@@ -2006,6 +2227,9 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
     a.tadd = nl(&epi->add_norm);
   }
   a.accumulate = accumulate;
+  a.in_bf = is_bf16(x) ? 1 : 0;
+  a.out_bf = is_bf16(y) ? 1 : 0;
+  a.add_bf = (epi && epi->add && is_bf16(epi->add)) ? 1 : 0;
   {
     auto al16 = [](const void* p, long long sn, long long sd, long long sh, long long sw, int bf) {      // 4-channel accesses
       return ((uintptr_t)p) % (bf ? 8 : 16) == 0 && sn % 4 == 0 && sd % 4 == 0 && sh % 4 == 0 && sw % 4 == 0;
@@ -2019,9 +2243,6 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   a.stats = stats; a.stats_rows_per_n = g.ncls * g.tiles_per_n * srt;
   a.ws = (float*)workspace; a.ksplit = g.ksplit; a.stages_per_split = g.sps; a.nstages = g.nstages;
   a.tz = g.tz; a.ty = g.ty; a.tx = g.tx;
-  a.in_bf = is_bf16(x) ? 1 : 0;
-  a.out_bf = is_bf16(y) ? 1 : 0;
-  a.add_bf = (epi && epi->add && is_bf16(epi->add)) ? 1 : 0;
   MMTTA_CHECK(g.cfg.bf || (!a.in_bf && !a.out_bf && !a.add_bf), MMTTA_ERR_UNSUPPORTED,
               "conv: bf16-stored tensors need a bf16-operand layer (K >= 16 in bf16 precision)");
   // 8-channel items: 32 bytes of fp32 (two 16-byte loads) or 16 bytes of bf16 (one): strides must keep them aligned
@@ -2035,7 +2256,6 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
     a.rowload = (al && x->sd < lim24 && x->sh < lim24 && x->sw < lim24 && x->d < lim24 && x->h < lim24 && x->w < lim24 &&
                  last < ((int64_t)1 << 31) && (g_igemm_pipeline & 1)) ? 1 : 0;
   }
-  a.ovec = 0;       // set below once the epilogue operands are known
   Taps ht[8];
   a.ncls = g.classes ? 8 : 1;
   a.tiles_per_cls = g.tiles_per_n * x->n;
@@ -2055,6 +2275,13 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
       ci.oz = ci.oy = ci.ox = 0;
       ci.Dg = y->d; ci.Hg = y->h; ci.Wg = y->w;
     }
+  }
+  if (g.fused) {
+    MMTTA_CHECK(a.ovec && a.vec4, MMTTA_ERR_UNSUPPORTED,
+                "conv (class-fused stride-2 form): the epilogue operands must admit 16-byte accesses");
+    MMTTA_CHECK(a.in_bf == a.out_bf && (a.add == nullptr || a.add_bf == a.out_bf), MMTTA_ERR_UNSUPPORTED,
+                "conv: input, output and fused add must share one storage type (in %d out %d add %d)", a.in_bf, a.out_bf, a.add_bf);
+    return a.in_bf ? launch_cls8_t<16, true>(a, g.tiles, (hipStream_t)stream) : launch_cls8_t<16, false>(a, g.tiles, (hipStream_t)stream);
   }
   return launch_any(g.cfg, a, ht, g.tiles, (hipStream_t)stream);
 }

@@ -180,7 +180,7 @@ IGEMM_KERNELS = ["igemm_f32_kernel<1,4,8,8,8,8>", "igemm_f32_kernel<2,4,4,8,8,16
                  "direct_conv_kernel",
                  "igemm_kernel<1,4,8,8,8,16,bf16>", "igemm_kernel<2,4,4,8,8,32,bf16>", "igemm_kernel<4,4,4,4,8,32,bf16>",
                  "igemm_kernel<1,1,4,4,8,16,bf16>", "igemm_kernel<2,2,4,4,8,16,bf16>", "igemm_kernel<4,4,4,4,8,16,bf16>",
-                 "direct_chan_kernel", "igemm_kernel<1,2,4,8,8,16,bf16>"]
+                 "direct_chan_kernel", "igemm_kernel<1,2,4,8,8,16,bf16>", "igemm_cls8_kernel<16,bf16>"]
 
 
 WGRAD_KERNELS = ["wgrad_f32_kernel<4,4,8,7>", "wgrad_f32_kernel<2,2,8,7>", "wgrad_f32_kernel<4,4,8,1>", "wgrad_small_kernel",

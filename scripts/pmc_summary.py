@@ -22,6 +22,9 @@ def bench_name(k):
     m = re.match(r"igemm_kernel<(\d+,\d+,\d+,\d+,\d+,\d+),(true|false)(,\d+)?(,(true|false))?>$", k)
     if m:
         return f"igemm_kernel<{m.group(1)},bf16>" if m.group(2) == "true" else f"igemm_f32_kernel<{m.group(1)}>"
+    m = re.match(r"igemm_cls8_kernel<(\d+),(true|false)>$", k)
+    if m:
+        return f"igemm_cls8_kernel<{m.group(1)},bf16>"
     m = re.match(r"(wgrad_tr_kernel|wgrad_bf16v?_kernel)<(\d+,\d+,\d+)(,(true|false),(true|false))?>$", k)
     if m:
         return f"{m.group(1).replace('bf16v', 'bf16')}<{m.group(2)}>"

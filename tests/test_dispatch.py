@@ -84,3 +84,24 @@ def test_every_kernel_instantiation_is_reached_by_a_parity_case():
     assert seen_cfg == set(range(14)), f"conv configs without a parity case: {sorted(set(range(14)) - seen_cfg)}"
     assert seen_wg == set(range(9)), f"weight-gradient kernels without a parity case: {sorted(set(range(9)) - seen_wg)}"
     assert {2, 9} <= splitk_wide, "the 32-channel-stage igemm also needs a split-K parity case"
+
+
+def test_class_fused_kernel_is_planned_for_large_stride2_forms():
+    """config 15 (igemm_cls8_kernel): the stride-2 transposed forms of a bf16 layer take the class-fused kernel once one
+    workgroup per coarse 4x4x8 tile and 32 output channels makes >= MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS (128) workgroups,
+    and the per-class kernel below that; its parity cases force it on small shapes
+    (tests/test_hip_conv.py::test_class_fused_stride2_forms_match_the_per_class_kernel)."""
+    from multimodal_tta_amd import _lib
+    from multimodal_tta_amd._lib import BF16, CONV_DGRAD, CONVT_FWD, ConvDesc, ConvPlan
+
+    lib = _lib.load()
+    for (cin, cout, transposed, coarse, want) in ((128, 32, True, (32, 32, 32), 15), (32, 64, False, (32, 32, 32), 15),
+                                                  (128, 32, True, (8, 8, 8), 7), (768, 128, True, (8, 8, 8), 9)):
+        d, h, w = coarse
+        lo, hi = _cl(1, d, h, w, cin if transposed else cout), _cl(1, 2 * d, 2 * h, 2 * w, cout if transposed else cin)
+        op = CONVT_FWD if transposed else CONV_DGRAD          # both read the coarse tensor and write the fine one
+        dsc, plan = ConvDesc(op, 3, 2, cin, cout, BF16), ConvPlan()
+        assert lib.mmtta_conv_plan(C.byref(dsc), C.byref(_desc(lo)), C.byref(_desc(hi)), C.byref(plan)) == 0
+        assert int(plan.config) == want, (cin, cout, transposed, coarse, int(plan.config))
+        if want == 15:
+            assert plan.ksplit == 1 and plan.stats_rows == (d // 4) * (h // 4) * (w // 8)

@@ -482,3 +482,60 @@ def test_row_loader_matches_the_generic_loader(case, stored):
     assert torch.equal(outs[0][0], outs[1][0]), "forward differs"
     assert torch.equal(outs[0][1], outs[1][1]), "input gradient differs"
     assert torch.equal(outs[0][2], outs[1][2]), "statistics differ"
+
+
+@pytest.mark.parametrize("stored", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(64, 32, 3, 2, True, (1, 4, 4, 8)), (768, 128, 3, 2, True, (1, 8, 8, 8)),
+                                  (128, 32, 3, 2, True, (2, 5, 6, 7)), (32, 64, 3, 2, False, (1, 8, 8, 16)),
+                                  (64, 128, 3, 2, False, (1, 5, 6, 7)), (40, 72, 3, 2, True, (1, 3, 5, 9))])
+def test_class_fused_stride2_forms_match_the_per_class_kernel(case, stored):
+    """MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS: ConvTranspose3d forward and the input gradient of a stride-2 Conv3d with all
+    8 output parity classes produced by one workgroup per coarse tile (forced here with a threshold of 1) against the
+    per-class launches (threshold 0): same bf16 products, another fp32 summation order -> 1e-3 of max|ref| (bf16-stored
+    outputs: one more rounding, 1e-2), statistics sums equal to 1e-3, and both within the bf16 bound of torch fp32."""
+    from multimodal_tta_amd import ops
+
+    cin, cout, k, stride, transposed, shape = case
+    n, d, h, w = shape
+    torch.manual_seed(17)
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = (torch.randn(n, cin, d, h, w) * 1.5 + 0.3).to(torch.bfloat16).float()
+    mu = x.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    xin = F.relu((x - mu[:, :, None, None, None]) * rstd[:, :, None, None, None]).requires_grad_(True)
+    y_ref = mod(xin)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    outs = {}
+    for thr in (0, 1):
+        prev = ops.set_option(12, thr)
+        try:
+            op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+            op.pack(mod.weight.detach().cuda().contiguous())
+            bf = stored == "bf16" and transposed            # the forward of a transposed module may be bf16-stored
+            x_cl = cl_bf16(x) if bf else cl(x)
+            if bf:
+                y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda", ldc=ops.row_pad(cout, torch.bfloat16), dtype=torch.bfloat16)
+            else:
+                y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda")
+            rows = op.stats_rows(x_cl, y_cl)
+            stats = torch.zeros((rows, 2, cout), device="cuda")
+            op.forward(x_cl, nl, mod.bias.detach().cuda(), y_cl, stats=stats)
+            dx_cl = ops.new_cl(n, d, h, w, cin, "cuda")
+            op.dgrad(cl(gy), dx_cl)
+            torch.cuda.synchronize()
+            outs[thr] = (y_cl.float().clone(), dx_cl.clone(), stats.view(n, rows // n, 2, cout).double().sum(1).cpu())
+        finally:
+            ops.set_option(12, prev)
+    ys, gs = y_ref.abs().max().item(), xin.grad.abs().max().item()
+    ytol = 1e-2 if (stored == "bf16" and transposed) else 1e-3
+    assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= ytol * ys, "forward differs from the per-class kernel"
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-3 * gs, "input gradient differs from the per-class kernel"
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-3, atol=1e-3 * max(1.0, outs[0][2].abs().max().item()))
+    got_y = outs[1][0].permute(0, 4, 1, 2, 3).cpu()
+    assert (got_y - y_ref.detach()).abs().max().item() <= 1.5e-2 * ys + 1e-5
+    # dgrad here is the gradient w.r.t. the module input AFTER norm-on-load (the transform's backward is another kernel)
+    got_dx = outs[1][1].permute(0, 4, 1, 2, 3).cpu()
+    assert (got_dx - xin.grad).abs().max().item() <= 1.5e-2 * gs + 1e-5
