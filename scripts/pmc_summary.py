@@ -25,7 +25,7 @@ def bench_name(k):
     m = re.match(r"igemm_cls8_kernel<(\d+),(true|false)>$", k)
     if m:
         return f"igemm_cls8_kernel<{m.group(1)},bf16>"
-    m = re.match(r"(wgrad_tr_kernel|wgrad_bf16v?_kernel)<(\d+,\d+,\d+)(,(true|false),(true|false))?>$", k)
+    m = re.match(r"(wgrad_tr_kernel|wgrad_bf16v?_kernel)<(\d+,\d+,\d+)((,(true|false)){2,3})?>$", k)
     if m:
         return f"{m.group(1).replace('bf16v', 'bf16')}<{m.group(2)}>"
     m = re.match(r"wgrad_f32_kernel<(\d+,\d+,\d+,\d+)(,(true|false),(true|false))?>$", k)
