@@ -152,6 +152,8 @@ def load() -> C.CDLL:
         lib.mmtta_set_option(9, 0)
     if "MMTTA_WGVEC" in os.environ:                      # A/B aid: MMTTA_OPT_WGRAD_VECTOR_STAGING
         lib.mmtta_set_option(11, int(os.environ["MMTTA_WGVEC"]))
+    if "MMTTA_THINMFMA" in os.environ:                   # A/B aid: MMTTA_OPT_THIN_MFMA
+        lib.mmtta_set_option(13, int(os.environ["MMTTA_THINMFMA"]))
     if "MMTTA_CLSFUSE" in os.environ:                    # A/B aid: MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS
         lib.mmtta_set_option(12, int(os.environ["MMTTA_CLSFUSE"]))
     if "MMTTA_LEAN" in os.environ:                       # A/B aid: MMTTA_OPT_IGEMM_LEAN

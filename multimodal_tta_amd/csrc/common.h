@@ -295,6 +295,7 @@ extern int g_ws_workgroups;         // api.hip: MMTTA_OPT_IGEMM_WS_WORKGROUPS
 extern int g_wgrad_vec;             // api.hip: MMTTA_OPT_WGRAD_VECTOR_STAGING
 extern int g_igemm_lean;            // api.hip: MMTTA_OPT_IGEMM_LEAN
 extern int g_cls_fused_min;         // api.hip: MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS
+extern int g_thin_mfma;             // api.hip: MMTTA_OPT_THIN_MFMA
 extern int g_epilogue_vec;          // api.hip: MMTTA_OPT_EPILOGUE_VEC16
 extern void* g_ws_debug;            // api.hip: mmtta_debug_set_buffer (phase stamps of the producer/consumer kernel)
 extern int g_tune[4];               // api.hip: launch-geometry knobs (MMTTA_OPT_SPLITK_BELOW ... MMTTA_OPT_WGRAD_THIN_SLABS)

@@ -459,6 +459,160 @@ __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
   direct_stats<NO>(a, n, ssum, ssq, red);
 }
 
+// ------------------------------------------------------------------ the same R -> R convolution on the 4x4x4 matrix tiles
+// `bf16` precision mode.  direct_row_kernel spends 27 * KI * NO fp32 FMAs per voxel on the vector ALU (243 for 3 -> 3: at
+// 128^3 the two launches of a step cost as much vector-ALU time as a 64^3 32 -> 32 implicit GEMM, for 0.05 % of its MACs)
+// and with several volumes in flight vector-ALU issue is what the chip runs out of.  v_mfma_f32_4x4x4_16B_bf16 computes 16
+// independent [4 x 4] += [4 x 4][4 x 4] products per instruction: block = 4 voxels (rows), k = the 4 padded input
+// channels, columns = the 4 padded output channels - one instruction per tap and 64 voxels, no padding of N to 32.
+// Lane maps (checked on the device with integer data): A: lane l holds row l & 3 of block l >> 2 (its 4 k values = ONE
+// 8-byte LDS read of a bf16 voxel); B: lane l holds column l & 3 (4 k values, the same for all blocks: 27 taps x 2
+// registers per lane, built once from the fp32 image); D: lane l holds rows 0..3 of column l & 3 of block l >> 2.
+// Row r of block b is voxel x = 16 r + b of the wave's 64-voxel row, so the store of accumulator register r is 16 voxels
+// x 4 channels = 256 contiguous bytes.  The input tile (2 x 8 x 64 voxels + halo) is staged once as bf16 [voxel][4].
+// Measured (r02e, 3 -> 3 at 128^3): 46.5 us against 47.7 us for direct_row_kernel and no change with four volumes in
+// flight - the layer is bound by something other than its FMAs, so this stays an option (MMTTA_OPT_THIN_MFMA, off) and
+// the exact fp32 form the default.
+typedef short cs4 __attribute__((ext_vector_type(4)));
+typedef float cf4v __attribute__((ext_vector_type(4)));
+
+template <bool HAS_T>
+__global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
+  constexpr int TZ = 2, TY = 8, TX = 64, BZ = TZ + 2, BY = TY + 2, BX = TX + 2, NBOX = BZ * BY * BX;
+  __shared__ uint2 box[NBOX];
+  __shared__ float red[32];
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int txn = (a.out.w + TX - 1) / TX, tyn = (a.out.h + TY - 1) / TY;
+  int t = blockIdx.x;
+  const int txi = t % txn; t /= txn;
+  const int tyi = t % tyn;
+  const int tzi = t / tyn;
+  const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
+  {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill / pack
+    constexpr int NIT = (NBOX + 255) / 256;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_T) nl_coeff_vec<4>(a.tin, n, a.K, 0, sc, sh);          // channels >= K: scale = shift = 0
+    const float* inb = a.in.p + (long long)n * a.in.sn;
+    float4 raw[NIT];
+    unsigned okm = 0u;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int v = min(tid + 256 * j, NBOX - 1);
+      const int bz = v / (BY * BX), rem = v - bz * (BY * BX), by = rem / BX, bx = rem - by * BX;
+      const int iz = oz0 - 1 + bz, iy = oy0 - 1 + by, ix = ox0 - 1 + bx;
+      const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
+      okm |= (ok ? 1u : 0u) << j;
+      raw[j] = *reinterpret_cast<const float4*>(inb + (long long)min(max(iz, 0), a.in.d - 1) * a.in.sd +
+                                                (long long)min(max(iy, 0), a.in.h - 1) * a.in.sh +
+                                                (long long)min(max(ix, 0), a.in.w - 1) * a.in.sw);
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const float xs[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+      float v4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = HAS_T ? nl_apply(xs[k], sc[k], sh[k], a.tin.relu) : xs[k];
+        v4[k] = k < a.K ? v : 0.f;                                  // pad lanes of the voxel row may hold anything
+      }
+      const unsigned m = ((okm >> j) & 1u) ? 0xffffffffu : 0u;
+      uint2 pk;
+      pk.x = f32x2_to_bf16x2(v4[0], v4[1]) & m; pk.y = f32x2_to_bf16x2(v4[2], v4[3]) & m;
+      if (tid + 256 * j < NBOX) box[tid + 256 * j] = pk;
+    }
+  }
+  // ---- B operand: column j = lane & 3 of every tap, k = input channel (fp32 image [tap][K][4], mirrored for the gradient)
+  const int jc = lane & 3, blk = lane >> 2;
+  cs4 wb[27];
+#pragma unroll
+  for (int tp = 0; tp < 27; ++tp) {
+    const float* wt = a.w + (a.transposed ? 26 - tp : tp) * a.K * 4;
+    float wk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wk[k] = (k < a.K && jc < a.N) ? wt[k * 4 + jc] : 0.f;
+    const unsigned lo = f32x2_to_bf16x2(wk[0], wk[1]), hi = f32x2_to_bf16x2(wk[2], wk[3]);
+    wb[tp] = __builtin_bit_cast(cs4, make_uint2(lo, hi));
+  }
+  float bias = 0.f, asc = 1.f, ash = 0.f;
+  if (jc < a.N) {
+    if (a.bias) bias = a.bias[jc];
+    if (a.add) nl_coeff(a.tadd, n, a.N, jc, asc, ash);
+  }
+  __syncthreads();
+  float ssum = 0.f, ssq = 0.f;
+  const int arow = lane & 3;                    // A: this lane supplies row `arow` of block `blk`: voxel x = 16 arow + blk
+#pragma unroll 1
+  for (int rp = 0; rp < TZ * TY / 8; ++rp) {    // two rows of the tile per wave and trip (independent accumulator chains)
+    const int r0 = rp * 8 + wave * 2;
+    cf4v acc[2];
+    const uint2* ab[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int zl = (r0 + q) / TY, yl = (r0 + q) % TY;
+      ab[q] = box + (zl * BY + yl) * BX + 16 * arow + blk;
+      acc[q] = cf4v{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) {
+      const int toff = ((tp / 9) * BY + (tp / 3) % 3) * BX + tp % 3;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint2 av = ab[q][toff];
+        acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(cs4, av), wb[tp], acc[q], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: register r of lane (blk, jc) = output voxel x = 16 r + blk, channel jc
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int oz = oz0 + (r0 + q) / TY, oy = oy0 + (r0 + q) % TY;
+      const bool rowok = oz < a.out.d && oy < a.out.h;
+      float* orow = a.out.p + (long long)n * a.out.sn + (long long)min(oz, a.out.d - 1) * a.out.sd + (long long)min(oy, a.out.h - 1) * a.out.sh;
+      const float* arow_p = a.add ? a.add + (long long)n * a.asn + (long long)min(oz, a.out.d - 1) * a.asd + (long long)min(oy, a.out.h - 1) * a.ash
+                                  : nullptr;
+      float addv[4] = {0.f, 0.f, 0.f, 0.f}, oldv[4] = {0.f, 0.f, 0.f, 0.f};
+      const int jl = min(jc, a.N - 1);
+      if (a.add) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) addv[r] = arow_p[(long long)min(ox0 + 16 * r + blk, a.out.w - 1) * a.asw + jl];
+      }
+      if (a.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oldv[r] = orow[(long long)min(ox0 + 16 * r + blk, a.out.w - 1) * a.out.sw + jl];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ox = ox0 + 16 * r + blk;
+        float v = acc[q][r] + bias;
+        if (a.add) v += nl_apply(addv[r], asc, ash, a.tadd.relu);
+        if (a.accumulate) v += oldv[r];
+        if (rowok && ox < a.out.w) {
+          if (jc < a.N) {
+            orow[(long long)ox * a.out.sw + jc] = v;
+            ssum += v; ssq += v * v;
+          } else if (a.out_vec4) {
+            orow[(long long)ox * a.out.sw + jc] = 0.f;          // the view owns its pad lanes: keep them zero
+          }
+        }
+      }
+    }
+  }
+  if (a.stats != nullptr) {   // lanes with the same l & 3 hold the same channel
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) { ssum += __shfl_xor(ssum, o, 64); ssq += __shfl_xor(ssq, o, 64); }
+    if (lane < 4) { red[(0 * 4 + wave) * 4 + lane] = ssum; red[(1 * 4 + wave) * 4 + lane] = ssq; }
+    __syncthreads();
+    if (tid < a.N) {
+      const float s2 = red[0 * 4 + tid] + red[1 * 4 + tid] + red[2 * 4 + tid] + red[3 * 4 + tid];
+      const float q2 = red[16 + 0 * 4 + tid] + red[16 + 1 * 4 + tid] + red[16 + 2 * 4 + tid] + red[16 + 3 * 4 + tid];
+      const long long rrow = (long long)n * a.blocks_per_n + blockIdx.x;
+      a.stats[(rrow * 2 + 0) * a.N + tid] = s2;
+      a.stats[(rrow * 2 + 1) * a.N + tid] = q2;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ stride-2 up-convolution to <= 4 channels
 // ConvTranspose3d K -> R (k3, s2, p1, output_padding 1) with K = 32 / 64: the full-resolution last layer of the U-Net.
 // out[2i+p] needs in[i] (p = 0: tap 1; p = 1: tap 2) and, for p = 1, in[i+1] (tap 0), per axis.  A workgroup stages
@@ -1022,14 +1176,15 @@ int pointwise_small_run(const mmtta_tensor* x, const void* packed, int Kp, int N
 }
 
 // 0: thread per voxel (any shape); 1: lanes along K (K = 32 or 64); 2: row kernel (K <= 4, k3 s1);
-// 3: LDS-staged stride-2 up-convolution (ConvTranspose3d forward, K = 32 or 64)
+// 3: LDS-staged stride-2 up-convolution (ConvTranspose3d forward, K = 32 or 64); 4: variant 2's shapes on the 4x4x4
+// matrix tiles (bf16 precision, MMTTA_OPT_THIN_MFMA)
 static int direct_variant(const mmtta_conv_desc* d, const mmtta_tensor* x) {
   int K, N;
   direct_dims(d, K, N);
   if (!aligned16(x) || (long long)x->w * x->sw * 4 >= (1LL << 31)) return 0;
   if ((K == 32 || K == 64) && d->op == MMTTA_CONVT_FWD && d->ksize == 3 && d->stride == 2) return 3;
   if (K == 32 || K == 64) return 1;
-  if (K <= 4 && d->stride == 1 && d->ksize == 3) return 2;
+  if (K <= 4 && d->stride == 1 && d->ksize == 3) return (d->dtype == MMTTA_BF16 && g_thin_mfma && N <= 4) ? 4 : 2;
   return 0;
 }
 
@@ -1049,6 +1204,7 @@ int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const m
     return (int)((dhw + 255) / 256);
   }
   if (v == 3) return x->d * x->h * ((x->w + 63) / 64);       // one workgroup per (input row pair, 64-voxel chunk)
+  if (v == 4) return ((y->d + 1) / 2) * ((y->h + 7) / 8) * ((y->w + 63) / 64);     // one workgroup per 2 x 8 x 64 tile
   // grid-stride kernels: enough workgroups to fill the chip a few times over, never more than the work
   const long long want = (direct_units(d, v, y) + 3) / 4;
   const long long cap = v == 1 ? 1024 : 2048;
@@ -1319,6 +1475,12 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   if (variant == 2) {
     if (has_t) launch_row<true>(a, y->n, stream); else launch_row<false>(a, y->n, stream);
     return launch_status("direct conv (row)");
+  }
+  if (variant == 4) {
+    const dim3 grid(a.blocks_per_n, y->n), block(256);
+    if (has_t) hipLaunchKernelGGL(conv3_mfma4_kernel<true>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(conv3_mfma4_kernel<false>, grid, block, 0, stream, a);
+    return launch_status("direct conv (4x4x4 matrix tiles)");
   }
   if (variant == 3) {
     const bool bf = d->dtype == MMTTA_BF16;

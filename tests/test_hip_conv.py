@@ -217,6 +217,11 @@ BF16_CASES = [
     (16, 32, 3, 2, False, (1, 8, 8, 8)),
     (256, 256, 3, 1, False, (1, 16, 16, 16)),
     (64, 3, 3, 2, True, (1, 3, 5, 70)),
+    # <= 4 channels on both sides (direct_row_kernel; the 4x4x4 matrix-tile form has its own test below)
+    (3, 3, 3, 1, False, (1, 5, 7, 70)),
+    (4, 2, 3, 1, False, (2, 5, 6, 70)),
+    (1, 1, 3, 1, False, (1, 6, 5, 9)),
+    (2, 4, 3, 1, False, (1, 3, 9, 130)),
 ]
 
 
@@ -539,3 +544,52 @@ def test_class_fused_stride2_forms_match_the_per_class_kernel(case, stored):
     # dgrad here is the gradient w.r.t. the module input AFTER norm-on-load (the transform's backward is another kernel)
     got_dx = outs[1][1].permute(0, 4, 1, 2, 3).cpu()
     assert (got_dx - xin.grad).abs().max().item() <= 1.5e-2 * gs + 1e-5
+
+
+@pytest.mark.parametrize("case", [(3, 3, (1, 5, 7, 70)), (4, 2, (2, 4, 9, 66)), (2, 4, (1, 3, 8, 128)), (1, 3, (1, 2, 3, 5))])
+def test_thin_conv_on_matrix_tiles_matches_the_vector_kernel(case):
+    """MMTTA_OPT_THIN_MFMA: the <= 4 -> <= 4 channel 3x3x3 convolution on the 4x4x4 matrix tiles (bf16 operands) against
+    the fp32 vector-ALU kernel, with everything the epilogue can do: norm-on-load + ReLU of the input, bias, fused
+    residual add with its own norm-on-load, accumulate, statistics.  Bound 1e-2 of max|ref| (operand rounding 2^-9)."""
+    from multimodal_tta_amd import ops
+
+    cin, cout, shape = case
+    n, d, h, w = shape
+    torch.manual_seed(23)
+    mod = ref_module(cin, cout, 3, 1, False)
+    x = torch.randn(n, cin, d, h, w) * 2 + 0.5
+    r = torch.randn(n, cout, d, h, w)
+
+    def stats_of(t):
+        mu = t.mean(dim=(2, 3, 4))
+        var = t.var(dim=(2, 3, 4), unbiased=False)
+        return mu.reshape(-1).cuda().contiguous(), (1.0 / torch.sqrt(var + 1e-5)).reshape(-1).cuda().contiguous()
+
+    mx, rx = stats_of(x)
+    mr, rr = stats_of(r)
+    gy = torch.randn(n, cout, d, h, w)
+    outs = {}
+    for mode in (0, 1):
+        prev = ops.set_option(13, mode)
+        try:
+            op = ops.ConvOp(cin, cout, 3, 1, False, "cuda", dtype=ops.BF16)
+            op.pack(mod.weight.detach().cuda().contiguous())
+            x_cl, r_cl = cl(x), cl(r)
+            y_cl = ops.new_cl(n, d, h, w, cout, "cuda")
+            rows = op.stats_rows(x_cl, y_cl)
+            stats = torch.zeros((rows, 2, cout), device="cuda")
+            op.forward(x_cl, ops.NL(mx, rx, relu=True), mod.bias.detach().cuda(), y_cl, stats=stats, add=r_cl,
+                       add_nl=ops.NL(mr, rr, relu=True))
+            dx_cl = ops.new_cl(n, d, h, w, cin, "cuda")
+            dx_cl.fill_(0.25)
+            op.dgrad(cl(gy), dx_cl, accumulate=True)
+            torch.cuda.synchronize()
+            outs[mode] = (ncdhw(y_cl).clone(), ncdhw(dx_cl).clone(), stats.view(n, rows // n, 2, cout).double().sum(1).cpu())
+        finally:
+            ops.set_option(13, prev)
+    ys, gs = outs[0][0].abs().max().item(), outs[0][1].abs().max().item()
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-2 * ys, "forward differs from the vector kernel"
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-2 * gs, "input gradient differs from the vector kernel"
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=2e-2, atol=2e-2 * max(1.0, outs[0][2].abs().max().item()))
+    y_ref = mod(F.relu(F.instance_norm(x))) + F.relu(F.instance_norm(r))
+    assert (outs[1][0] - y_ref.detach()).abs().max().item() <= 1.5e-2 * y_ref.abs().max().item()
