@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
 // registers per lane, built once from the fp32 image); D: lane l holds rows 0..3 of column l & 3 of block l >> 2.
 // Row r of block b is voxel x = 16 r + b of the wave's 64-voxel row, so the store of accumulator register r is 16 voxels
 // x 4 channels = 256 contiguous bytes.  The input tile (2 x 8 x 64 voxels + halo) is staged once as bf16 [voxel][4].
-// Measured (r02e, 3 -> 3 at 128^3): 46.5 us against 47.7 us for direct_row_kernel and no change with four volumes in
+// Measured (r02e, 3 -> 3 at 128^3): 45.6 us (46.5 with a 2 x 8 x 64 tile) against 47.7 us for direct_row_kernel and no change with four volumes in
 // flight - the layer is bound by something other than its FMAs, so this stays an option (MMTTA_OPT_THIN_MFMA, off) and
 // the exact fp32 form the default.
 typedef short cs4 __attribute__((ext_vector_type(4)));
@@ -478,7 +478,8 @@ typedef float cf4v __attribute__((ext_vector_type(4)));
 
 template <bool HAS_T>
 __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
-  constexpr int TZ = 2, TY = 8, TX = 64, BZ = TZ + 2, BY = TY + 2, BX = TX + 2, NBOX = BZ * BY * BX;
+  // 8 x 8 x 64 tile: the halo box is 1.6x the tile (2 x 8 x 64: 2.6x - the launch is bound by that re-read, not by FMAs)
+  constexpr int TZ = 8, TY = 8, TX = 64, BZ = TZ + 2, BY = TY + 2, BX = TX + 2, NBOX = BZ * BY * BX;
   __shared__ uint2 box[NBOX];
   __shared__ float red[32];
   const int n = blockIdx.y;
@@ -491,36 +492,39 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
   const int tzi = t / tyn;
   const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
   {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill / pack
-    constexpr int NIT = (NBOX + 255) / 256;
+    constexpr int NIT = (NBOX + 255) / 256, RND = 13;              // items per thread, in rounds of RND loads in flight
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (HAS_T) nl_coeff_vec<4>(a.tin, n, a.K, 0, sc, sh);          // channels >= K: scale = shift = 0
     const float* inb = a.in.p + (long long)n * a.in.sn;
-    float4 raw[NIT];
-    unsigned okm = 0u;
+#pragma unroll 1
+    for (int j0 = 0; j0 < NIT; j0 += RND) {
+      float4 raw[RND];
+      unsigned okm = 0u;
 #pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      const int v = min(tid + 256 * j, NBOX - 1);
-      const int bz = v / (BY * BX), rem = v - bz * (BY * BX), by = rem / BX, bx = rem - by * BX;
-      const int iz = oz0 - 1 + bz, iy = oy0 - 1 + by, ix = ox0 - 1 + bx;
-      const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
-      okm |= (ok ? 1u : 0u) << j;
-      raw[j] = *reinterpret_cast<const float4*>(inb + (long long)min(max(iz, 0), a.in.d - 1) * a.in.sd +
-                                                (long long)min(max(iy, 0), a.in.h - 1) * a.in.sh +
-                                                (long long)min(max(ix, 0), a.in.w - 1) * a.in.sw);
-    }
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      const float xs[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
-      float v4[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float v = HAS_T ? nl_apply(xs[k], sc[k], sh[k], a.tin.relu) : xs[k];
-        v4[k] = k < a.K ? v : 0.f;                                  // pad lanes of the voxel row may hold anything
+      for (int j = 0; j < RND; ++j) {
+        const int v = min(tid + 256 * (j0 + j), NBOX - 1);
+        const int bz = v / (BY * BX), rem = v - bz * (BY * BX), by = rem / BX, bx = rem - by * BX;
+        const int iz = oz0 - 1 + bz, iy = oy0 - 1 + by, ix = ox0 - 1 + bx;
+        const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
+        okm |= (ok ? 1u : 0u) << j;
+        raw[j] = *reinterpret_cast<const float4*>(inb + (long long)min(max(iz, 0), a.in.d - 1) * a.in.sd +
+                                                  (long long)min(max(iy, 0), a.in.h - 1) * a.in.sh +
+                                                  (long long)min(max(ix, 0), a.in.w - 1) * a.in.sw);
       }
-      const unsigned m = ((okm >> j) & 1u) ? 0xffffffffu : 0u;
-      uint2 pk;
-      pk.x = f32x2_to_bf16x2(v4[0], v4[1]) & m; pk.y = f32x2_to_bf16x2(v4[2], v4[3]) & m;
-      if (tid + 256 * j < NBOX) box[tid + 256 * j] = pk;
+#pragma unroll
+      for (int j = 0; j < RND; ++j) {
+        const float xs[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+        float v4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v = HAS_T ? nl_apply(xs[k], sc[k], sh[k], a.tin.relu) : xs[k];
+          v4[k] = k < a.K ? v : 0.f;                                // pad lanes of the voxel row may hold anything
+        }
+        const unsigned m = ((okm >> j) & 1u) ? 0xffffffffu : 0u;
+        uint2 pk;
+        pk.x = f32x2_to_bf16x2(v4[0], v4[1]) & m; pk.y = f32x2_to_bf16x2(v4[2], v4[3]) & m;
+        if (tid + 256 * (j0 + j) < NBOX) box[tid + 256 * (j0 + j)] = pk;
+      }
     }
   }
   // ---- B operand: column j = lane & 3 of every tap, k = input channel (fp32 image [tap][K][4], mirrored for the gradient)
@@ -1204,7 +1208,7 @@ int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const m
     return (int)((dhw + 255) / 256);
   }
   if (v == 3) return x->d * x->h * ((x->w + 63) / 64);       // one workgroup per (input row pair, 64-voxel chunk)
-  if (v == 4) return ((y->d + 1) / 2) * ((y->h + 7) / 8) * ((y->w + 63) / 64);     // one workgroup per 2 x 8 x 64 tile
+  if (v == 4) return ((y->d + 7) / 8) * ((y->h + 7) / 8) * ((y->w + 63) / 64);     // one workgroup per 8 x 8 x 64 tile
   // grid-stride kernels: enough workgroups to fill the chip a few times over, never more than the work
   const long long want = (direct_units(d, v, y) + 3) / 4;
   const long long cap = v == 1 ? 1024 : 2048;
