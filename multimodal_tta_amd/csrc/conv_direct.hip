@@ -470,17 +470,20 @@ __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
 // registers per lane, built once from the fp32 image); D: lane l holds rows 0..3 of column l & 3 of block l >> 2.
 // Row r of block b is voxel x = 16 r + b of the wave's 64-voxel row, so the store of accumulator register r is 16 voxels
 // x 4 channels = 256 contiguous bytes.  The input tile (2 x 8 x 64 voxels + halo) is staged once as bf16 [voxel][4].
-// Measured (r02e, 3 -> 3 at 128^3): 45.6 us (46.5 with a 2 x 8 x 64 tile) against 47.7 us for direct_row_kernel and no change with four volumes in
-// flight - the layer is bound by something other than its FMAs, so this stays an option (MMTTA_OPT_THIN_MFMA, off) and
-// the exact fp32 form the default.
+// Measured (r02e, 3 -> 3 at 128^3, scripts/experiments/thin_phases.py): 33 us against 43 us for direct_row_kernel (the first
+// version, one voxel per staging item and 108 scalar weight loads per lane, took 44: 26 of them index arithmetic), 58.7
+// against 58.6 volumes/s with four volumes in flight - the exact fp32 form stays the default (MMTTA_OPT_THIN_MFMA, off).
 typedef short cs4 __attribute__((ext_vector_type(4)));
 typedef float cf4v __attribute__((ext_vector_type(4)));
 
 template <bool HAS_T>
 __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
-  // 8 x 8 x 64 tile: the halo box is 1.6x the tile (2 x 8 x 64: 2.6x - the launch is bound by that re-read, not by FMAs)
-  constexpr int TZ = 8, TY = 8, TX = 64, BZ = TZ + 2, BY = TY + 2, BX = TX + 2, NBOX = BZ * BY * BX;
-  __shared__ uint2 box[NBOX];
+  // 8 x 8 x 64 tile: the halo box is 1.6x the tile.  The box rows are padded to 68 voxels so that a staging item is a run
+  // of 4 voxels along x (one decode, one row address, four 16-byte loads): phase timing of the first version showed 26 of
+  // its 44 us in per-voxel index / address arithmetic and in 108 scalar weight loads per lane, not in loads or MFMAs.
+  constexpr int TZ = 8, TY = 8, TX = 64, BZ = TZ + 2, BY = TY + 2, BX = 68, RUNS = BX / 4, NRUN = BZ * BY * RUNS;
+  __shared__ uint2 box[BZ * BY * BX];
+  __shared__ uint2 wtab[27 * 4];                // [tap][column] x 4 k values (bf16)
   __shared__ float red[32];
   const int n = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -491,62 +494,85 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
   const int tyi = t % tyn;
   const int tzi = t / tyn;
   const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
-  {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill / pack
-    constexpr int NIT = (NBOX + 255) / 256, RND = 13;              // items per thread, in rounds of RND loads in flight
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (HAS_T) nl_coeff_vec<4>(a.tin, n, a.K, 0, sc, sh);          // channels >= K: scale = shift = 0
-    const float* inb = a.in.p + (long long)n * a.in.sn;
-#pragma unroll 1
-    for (int j0 = 0; j0 < NIT; j0 += RND) {
-      float4 raw[RND];
-      unsigned okm = 0u;
-#pragma unroll
-      for (int j = 0; j < RND; ++j) {
-        const int v = min(tid + 256 * (j0 + j), NBOX - 1);
-        const int bz = v / (BY * BX), rem = v - bz * (BY * BX), by = rem / BX, bx = rem - by * BX;
-        const int iz = oz0 - 1 + bz, iy = oy0 - 1 + by, ix = ox0 - 1 + bx;
-        const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
-        okm |= (ok ? 1u : 0u) << j;
-        raw[j] = *reinterpret_cast<const float4*>(inb + (long long)min(max(iz, 0), a.in.d - 1) * a.in.sd +
-                                                  (long long)min(max(iy, 0), a.in.h - 1) * a.in.sh +
-                                                  (long long)min(max(ix, 0), a.in.w - 1) * a.in.sw);
-      }
-#pragma unroll
-      for (int j = 0; j < RND; ++j) {
-        const float xs[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
-        float v4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float v = HAS_T ? nl_apply(xs[k], sc[k], sh[k], a.tin.relu) : xs[k];
-          v4[k] = k < a.K ? v : 0.f;                                // pad lanes of the voxel row may hold anything
-        }
-        const unsigned m = ((okm >> j) & 1u) ? 0xffffffffu : 0u;
-        uint2 pk;
-        pk.x = f32x2_to_bf16x2(v4[0], v4[1]) & m; pk.y = f32x2_to_bf16x2(v4[2], v4[3]) & m;
-        if (tid + 256 * (j0 + j) < NBOX) box[tid + 256 * (j0 + j)] = pk;
-      }
-    }
-  }
-  // ---- B operand: column j = lane & 3 of every tap, k = input channel (fp32 image [tap][K][4], mirrored for the gradient)
-  const int jc = lane & 3, blk = lane >> 2;
-  cs4 wb[27];
-#pragma unroll
-  for (int tp = 0; tp < 27; ++tp) {
+  // ---- B operand table: column j of tap tp = the 4 k values w[tp][k][j] (fp32 image [tap][K][4], mirrored for the gradient)
+  if (tid < 27 * 4) {
+    const int tp = tid >> 2, j = tid & 3;
     const float* wt = a.w + (a.transposed ? 26 - tp : tp) * a.K * 4;
     float wk[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wk[k] = (k < a.K && jc < a.N) ? wt[k * 4 + jc] : 0.f;
-    const unsigned lo = f32x2_to_bf16x2(wk[0], wk[1]), hi = f32x2_to_bf16x2(wk[2], wk[3]);
-    wb[tp] = __builtin_bit_cast(cs4, make_uint2(lo, hi));
+    for (int k = 0; k < 4; ++k) wk[k] = (k < a.K && j < a.N) ? wt[k * 4 + j] : 0.f;
+    wtab[tid] = make_uint2(f32x2_to_bf16x2(wk[0], wk[1]), f32x2_to_bf16x2(wk[2], wk[3]));
   }
+  {  // ---- stage the halo box: runs of 4 voxels, two runs (8 loads) in flight per thread
+    constexpr int NIT = (NRUN + 255) / 256, RND = 2;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_T) nl_coeff_vec<4>(a.tin, n, a.K, 0, sc, sh);          // channels >= K: scale = shift = 0
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k >= a.K) { sc[k] = 0.f; sh[k] = 0.f; }                   // pad lanes of the voxel row may hold anything
+    const float relu_lo = (HAS_T && a.tin.relu) ? 0.f : -__builtin_inff();
+    const float* inb = a.in.p + (long long)n * a.in.sn;
+    const unsigned isw = (unsigned)a.in.sw;
+#pragma unroll 1
+    for (int j0 = 0; j0 < NIT; j0 += RND) {
+      float4 raw[RND][4];
+      unsigned okm = 0u;
+#pragma unroll
+      for (int j = 0; j < RND; ++j) {
+        const int v = min(tid + 256 * (j0 + j), NRUN - 1);
+        const int bz = v / (BY * RUNS), rem = v - bz * (BY * RUNS), by = rem / RUNS, run = rem - by * RUNS;
+        const int iz = oz0 - 1 + bz, iy = oy0 - 1 + by, ix = ox0 - 1 + 4 * run;
+        const bool rok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h;
+        const float* row = inb + (long long)min(max(iz, 0), a.in.d - 1) * a.in.sd + (long long)min(max(iy, 0), a.in.h - 1) * a.in.sh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          okm |= ((rok && (unsigned)(ix + q) < (unsigned)a.in.w) ? 1u : 0u) << (4 * j + q);
+          raw[j][q] = *reinterpret_cast<const float4*>(row + (unsigned)min(max(ix + q, 0), a.in.w - 1) * isw);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RND; ++j) {
+        uint2 pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float xs[4] = {raw[j][q].x, raw[j][q].y, raw[j][q].z, raw[j][q].w};
+          float v4[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v4[k] = fmaxf(fmaf(xs[k], sc[k], sh[k]), relu_lo);
+          const unsigned m = ((okm >> (4 * j + q)) & 1u) ? 0xffffffffu : 0u;
+          pk[q].x = f32x2_to_bf16x2(v4[0], v4[1]) & m; pk[q].y = f32x2_to_bf16x2(v4[2], v4[3]) & m;
+        }
+        if (tid + 256 * (j0 + j) < NRUN) {
+          uint4* dst = reinterpret_cast<uint4*>(box + 4 * (tid + 256 * (j0 + j)));      // run v = voxels 4 v .. 4 v + 3 of the image
+          dst[0] = make_uint4(pk[0].x, pk[0].y, pk[1].x, pk[1].y);
+          dst[1] = make_uint4(pk[2].x, pk[2].y, pk[3].x, pk[3].y);
+        }
+      }
+    }
+  }
+  const int jc = lane & 3, blk = lane >> 2;
   float bias = 0.f, asc = 1.f, ash = 0.f;
   if (jc < a.N) {
     if (a.bias) bias = a.bias[jc];
     if (a.add) nl_coeff(a.tadd, n, a.N, jc, asc, ash);
   }
   __syncthreads();
+  cs4 wb[27];
+#pragma unroll
+  for (int tp = 0; tp < 27; ++tp) wb[tp] = __builtin_bit_cast(cs4, wtab[tp * 4 + jc]);
   float ssum = 0.f, ssq = 0.f;
   const int arow = lane & 3;                    // A: this lane supplies row `arow` of block `blk`: voxel x = 16 arow + blk
+  const int jl = min(jc, a.N - 1);
+  // element offsets of this lane's four output voxels inside a row (x = ox0 + 16 r + blk), and whether they exist
+  unsigned xoff_o[4], xoff_a[4];
+  unsigned xok = 0u;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ox = ox0 + 16 * r + blk;
+    xok |= (ox < a.out.w ? 1u : 0u) << r;
+    xoff_o[r] = (unsigned)min(ox, a.out.w - 1) * (unsigned)a.out.sw;
+    xoff_a[r] = (unsigned)min(ox, a.out.w - 1) * (unsigned)a.asw;
+  }
 #pragma unroll 1
   for (int rp = 0; rp < TZ * TY / 8; ++rp) {    // two rows of the tile per wave and trip (independent accumulator chains)
     const int r0 = rp * 8 + wave * 2;
@@ -576,27 +602,25 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
       const float* arow_p = a.add ? a.add + (long long)n * a.asn + (long long)min(oz, a.out.d - 1) * a.asd + (long long)min(oy, a.out.h - 1) * a.ash
                                   : nullptr;
       float addv[4] = {0.f, 0.f, 0.f, 0.f}, oldv[4] = {0.f, 0.f, 0.f, 0.f};
-      const int jl = min(jc, a.N - 1);
       if (a.add) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) addv[r] = arow_p[(long long)min(ox0 + 16 * r + blk, a.out.w - 1) * a.asw + jl];
+        for (int r = 0; r < 4; ++r) addv[r] = arow_p[xoff_a[r] + jl];
       }
       if (a.accumulate) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) oldv[r] = orow[(long long)min(ox0 + 16 * r + blk, a.out.w - 1) * a.out.sw + jl];
+        for (int r = 0; r < 4; ++r) oldv[r] = orow[xoff_o[r] + jl];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ox = ox0 + 16 * r + blk;
         float v = acc[q][r] + bias;
         if (a.add) v += nl_apply(addv[r], asc, ash, a.tadd.relu);
         if (a.accumulate) v += oldv[r];
-        if (rowok && ox < a.out.w) {
+        if (rowok && ((xok >> r) & 1u)) {
           if (jc < a.N) {
-            orow[(long long)ox * a.out.sw + jc] = v;
+            orow[xoff_o[r] + jc] = v;
             ssum += v; ssq += v * v;
           } else if (a.out_vec4) {
-            orow[(long long)ox * a.out.sw + jc] = 0.f;          // the view owns its pad lanes: keep them zero
+            orow[xoff_o[r] + jc] = 0.f;          // the view owns its pad lanes: keep them zero
           }
         }
       }
