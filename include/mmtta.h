@@ -115,13 +115,14 @@ int mmtta_abi_version(void);
 #define MMTTA_OPT_EPILOGUE_VEC16 9
 /* 1: the 32-output-channel stride-1 layers (64^3 level) use the lean 4x8x8 tile at four workgroups per CU. */
 #define MMTTA_OPT_IGEMM_LEAN 10
-/* Loader of the bf16-operand 27-tap weight gradient (csrc/conv_wgrad.hip):
+/* Kernel of the bf16-operand 27-tap weight gradient (csrc/conv_wgrad.hip):
+ *   1  (default; 3 is a synonym) the transposed-read kernel for every operand pair that admits its 16-byte items
+ *      (16-byte-aligned rows, strides < 2^24, < 2^31 elements; else as 0): operands stay [voxel][channel] in LDS as in
+ *      HBM and ds_read_b64_tr_b16 transposes them on the way into the MFMA;
  *   0  element loads, one channel per thread, operands transposed to [channel][voxel] while staging (round 1);
- *   1  (default) the transposed-read kernel when an operand is bf16-stored, else as 0;
- *   2  as 0 with 16-byte (bf16 storage: 8-byte) four-channel loads - bit-identical to 0;
- *   3  the transposed-read kernel for every 16-byte-aligned operand pair: operands stay [voxel][channel] in LDS as in
- *      HBM and ds_read_b64_tr_b16 transposes them on the way into the MFMA (another voxel order in the fp32
- *      accumulation: equal to 0 within 2e-3 of max|dw|, tests/test_hip_conv.py::test_transposed_read_wgrad). */
+ *   2  as 0 with 16-byte (bf16 storage: 8-byte) four-channel loads - bit-identical to 0.
+ * 1 sums the voxels in another order than 0 / 2: equal within 2e-3 of max|dw|
+ * (tests/test_hip_conv.py::test_transposed_read_wgrad). */
 #define MMTTA_OPT_WGRAD_VECTOR_STAGING 11
 #define MMTTA_OPT_IGEMM_WS_WORKGROUPS 8
 /* Stride-2 transposed forms (ConvTranspose3d forward, input gradient of a stride-2 Conv3d) in bf16 mode: when one

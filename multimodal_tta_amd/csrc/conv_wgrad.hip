@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
   const int t1 = min(a.tiles, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
   constexpr int GP = G::GP, DP = G::DP;
-  constexpr int PREF = 40;                                             // registers the cross-loop prefetch may hold
+  constexpr int PREF = (GBF || DBF) ? 40 : 32;                         // registers the cross-loop prefetch may hold
   constexpr int PGmax = (PREF - DP * (DBF ? 4 : 8)) / (GBF ? 4 : 8);
   constexpr int PG = PGmax < 0 ? 0 : (PGmax < GP ? PGmax : GP);        // box passes prefetched across the MFMA loop
   Oct8<GBF> gv[GP];
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
     const int n = pn;
     // what the prefetch had no registers for comes in rounds of RB passes (all loads of a round in flight together);
     // the first round is requested before the prefetched part is committed
-    constexpr int RB = GBF ? 12 : 6;
+    constexpr int RB = GBF ? 12 : 4;
     constexpr int R1 = PG + RB < GP ? PG + RB : GP;
     const float* gbase = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.g) + (long long)n * a.gsn * (GBF ? 2 : 4));
     const int iz0 = poz0 * SI - 1, iy0 = poy0 * SI - 1;
@@ -1588,7 +1588,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   }
   w.bf16 = d->dtype == MMTTA_BF16 && w.ntaps == 27;
   w.tr = w.bf16 && wtr_ok(w.g) && wtr_ok(w.dn) && !(w.convt && is_bf16(w.g)) && !(!w.convt && is_bf16(w.dn)) &&
-         (g_wgrad_vec == 3 || (g_wgrad_vec == 1 && (is_bf16(w.g) || is_bf16(w.dn))));
+         (g_wgrad_vec == 1 || g_wgrad_vec == 3);
   if (w.tr && w.si == 1) { w.TZ = 4; w.TY = 8; w.TX = 8; }
   else if (w.si == 1) { w.TZ = 4; w.TY = 4; w.TX = 8; }
   else if (w.bf16) { w.TZ = 2; w.TY = 4; w.TX = 8; }

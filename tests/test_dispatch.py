@@ -4,7 +4,7 @@ parity cases (tests/test_hip_conv.py::CASES / BF16_CASES) - asserted through the
 
 config ids: csrc/conv_igemm.hip::config_id (0-5 fp32 igemm, 6 direct, 7-12 bf16 igemm, 13 channel kernel);
 weight-gradient ids: mmtta_conv_wgrad_kernel (0 f32 s1, 1 f32 s2, 2 1x1, 3 small-channel, 4 bf16 s1, 5 bf16 s2, 6 tiny,
-7 / 8 transposed-read bf16 s1 / s2: the default for a bf16-STORED module input, parity cases test_transposed_read_wgrad).
+7 / 8 transposed-read bf16 s1 / s2: the default of bf16 precision, parity cases test_transposed_read_wgrad; 4 / 5 under option 11 = 0).
 VERDICT r1 P1: ids 2 and 9 (igemm <4,4,4,4,8,32>) used to be reachable only by the full-size bench."""
 import ctypes as C
 
@@ -14,14 +14,14 @@ from test_hip_conv import BF16_CASES, CASES, TR_CASES
 
 # (case, (fwd, dgrad) config in fp32 mode, the same in bf16 mode, weight-gradient kernel (fp32 mode, bf16 mode))
 DISPATCH = [
-    ((32, 32, 3, 1, False, (1, 16, 16, 16)), (0, 0), (7, 7), (0, 4)),
-    ((64, 64, 3, 1, False, (1, 8, 8, 8)), (1, 1), (8, 8), (0, 4)),
-    ((128, 128, 3, 1, False, (1, 32, 32, 32)), (2, 2), (9, 9), (0, 4)),
-    ((16, 32, 3, 2, False, (1, 8, 8, 8)), (3, 0), (10, 7), (1, 5)),
-    ((32, 64, 3, 2, False, (1, 8, 8, 16)), (4, 0), (11, 7), (1, 5)),
-    ((64, 128, 3, 2, False, (1, 5, 6, 7)), (5, 1), (12, 8), (1, 5)),
-    ((128, 136, 3, 1, False, (2, 4, 6, 8)), (5, 5), (12, 12), (0, 4)),
-    ((768, 128, 3, 2, True, (1, 8, 8, 8)), (2, 5), (9, 12), (1, 5)),
+    ((32, 32, 3, 1, False, (1, 16, 16, 16)), (0, 0), (7, 7), (0, 7)),
+    ((64, 64, 3, 1, False, (1, 8, 8, 8)), (1, 1), (8, 8), (0, 7)),
+    ((128, 128, 3, 1, False, (1, 32, 32, 32)), (2, 2), (9, 9), (0, 7)),
+    ((16, 32, 3, 2, False, (1, 8, 8, 8)), (3, 0), (10, 7), (1, 8)),
+    ((32, 64, 3, 2, False, (1, 8, 8, 16)), (4, 0), (11, 7), (1, 8)),
+    ((64, 128, 3, 2, False, (1, 5, 6, 7)), (5, 1), (12, 8), (1, 8)),
+    ((128, 136, 3, 1, False, (2, 4, 6, 8)), (5, 5), (12, 12), (0, 7)),
+    ((768, 128, 3, 2, True, (1, 8, 8, 8)), (2, 5), (9, 12), (1, 8)),
     ((256, 512, 1, 1, False, (1, 4, 4, 4)), (5, 5), (12, 12), (2, 2)),
     ((64, 3, 3, 2, True, (1, 3, 5, 70)), (6, 4), (6, 13), (3, 3)),
     ((4, 32, 3, 2, False, (1, 16, 16, 16)), (13, 6), (13, 6), (3, 3)),
@@ -74,13 +74,19 @@ def test_every_kernel_instantiation_is_reached_by_a_parity_case():
             assert kid == wg, f"{case} dtype {dtype}: weight-gradient kernel {kid}, expected {wg}"
             seen_cfg.update(got)
             seen_wg.add(kid)
-            if dtype == BF16 and wg in (4, 5):
-                # the same layer with its module input bf16-stored (method.storage: bf16): the transposed-read kernel
-                sx, sy = _desc(x, BF16), ty
-                kid = int(lib.mmtta_conv_wgrad_kernel(C.byref(dsc), C.byref(sx), C.byref(sy)))
-                assert kid == wg + 3, f"{case} bf16-stored: weight-gradient kernel {kid}, expected {wg + 3}"
+            if dtype == BF16 and wg in (7, 8):
                 assert case in TR_CASES, f"{case}: transposed-read instantiation without a parity case"
-                seen_wg.add(kid)
+                # the same layer with its module input bf16-stored (method.storage: bf16): the same kernel
+                kid = int(lib.mmtta_conv_wgrad_kernel(C.byref(dsc), C.byref(_desc(x, BF16)), C.byref(ty)))
+                assert kid == wg, f"{case} bf16-stored: weight-gradient kernel {kid}, expected {wg}"
+                # the staging-transposed kernels (ids 4 / 5) stay reachable through MMTTA_OPT_WGRAD_VECTOR_STAGING = 0
+                prev = lib.mmtta_set_option(11, 0)
+                try:
+                    kid0 = int(lib.mmtta_conv_wgrad_kernel(C.byref(dsc), C.byref(tx), C.byref(ty)))
+                finally:
+                    lib.mmtta_set_option(11, prev)
+                assert kid0 == wg - 3, f"{case} option 0: weight-gradient kernel {kid0}, expected {wg - 3}"
+                seen_wg.add(kid0)
     assert seen_cfg == set(range(14)), f"conv configs without a parity case: {sorted(set(range(14)) - seen_cfg)}"
     assert seen_wg == set(range(9)), f"weight-gradient kernels without a parity case: {sorted(set(range(9)) - seen_wg)}"
     assert {2, 9} <= splitk_wide, "the 32-channel-stage igemm also needs a split-K parity case"
