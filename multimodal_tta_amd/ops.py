@@ -185,7 +185,7 @@ IGEMM_KERNELS = ["igemm_f32_kernel<1,4,8,8,8,8>", "igemm_f32_kernel<2,4,4,8,8,16
 
 WGRAD_KERNELS = ["wgrad_f32_kernel<4,4,8,7>", "wgrad_f32_kernel<2,2,8,7>", "wgrad_f32_kernel<4,4,8,1>", "wgrad_small_kernel",
                  "wgrad_bf16_kernel<4,4,1>", "wgrad_bf16_kernel<2,4,2>", "wgrad_tiny_kernel",
-                 "wgrad_tr_kernel<4,8,1>", "wgrad_tr_kernel<2,4,2>"]
+                 "wgrad_tr_kernel<4,8,1>", "wgrad_tr_kernel<2,4,2>", "wgrad_tr1_kernel"]
 
 
 class KernelProfiler:

@@ -28,9 +28,13 @@ def bench_name(k):
     m = re.match(r"(wgrad_tr_kernel|wgrad_bf16v?_kernel)<(\d+,\d+,\d+)((,(true|false)){2,3})?>$", k)
     if m:
         return f"{m.group(1).replace('bf16v', 'bf16')}<{m.group(2)}>"
+    if k.startswith("wgrad_tr1_kernel"):
+        return "wgrad_tr1_kernel"
     m = re.match(r"wgrad_f32_kernel<(\d+,\d+,\d+,\d+)(,(true|false),(true|false))?>$", k)
     if m:
         return f"wgrad_f32_kernel<{m.group(1)}>"
+    if k.startswith("wgrad_tr1_kernel"):
+        return "wgrad_tr1_kernel"
     m = re.match(r"wgrad_f32_kernel<(\d+),(\d+),(\d+),(\d+)>$", k)
     if m:
         return k

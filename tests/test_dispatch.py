@@ -4,7 +4,8 @@ parity cases (tests/test_hip_conv.py::CASES / BF16_CASES) - asserted through the
 
 config ids: csrc/conv_igemm.hip::config_id (0-5 fp32 igemm, 6 direct, 7-12 bf16 igemm, 13 channel kernel);
 weight-gradient ids: mmtta_conv_wgrad_kernel (0 f32 s1, 1 f32 s2, 2 1x1, 3 small-channel, 4 bf16 s1, 5 bf16 s2, 6 tiny,
-7 / 8 transposed-read bf16 s1 / s2: the default of bf16 precision, parity cases test_transposed_read_wgrad; 4 / 5 under option 11 = 0).
+7 / 8 transposed-read bf16 s1 / s2: the default of bf16 precision, parity cases test_transposed_read_wgrad; 4 / 5 under option 11 = 0;
+9 the 1x1x1 streaming kernel of bf16 precision, parity cases test_pointwise_conv_weight_gradient_on_transposed_reads).
 VERDICT r1 P1: ids 2 and 9 (igemm <4,4,4,4,8,32>) used to be reachable only by the full-size bench."""
 import ctypes as C
 
@@ -22,7 +23,7 @@ DISPATCH = [
     ((64, 128, 3, 2, False, (1, 5, 6, 7)), (5, 1), (12, 8), (1, 8)),
     ((128, 136, 3, 1, False, (2, 4, 6, 8)), (5, 5), (12, 12), (0, 7)),
     ((768, 128, 3, 2, True, (1, 8, 8, 8)), (2, 5), (9, 12), (1, 8)),
-    ((256, 512, 1, 1, False, (1, 4, 4, 4)), (5, 5), (12, 12), (2, 2)),
+    ((256, 512, 1, 1, False, (1, 4, 4, 4)), (5, 5), (12, 12), (2, 9)),
     ((64, 3, 3, 2, True, (1, 3, 5, 70)), (6, 4), (6, 13), (3, 3)),
     ((4, 32, 3, 2, False, (1, 16, 16, 16)), (13, 6), (13, 6), (3, 3)),
     ((3, 3, 3, 1, False, (1, 8, 8, 8)), (6, 6), (6, 6), (6, 6)),
@@ -88,7 +89,7 @@ def test_every_kernel_instantiation_is_reached_by_a_parity_case():
                 assert kid0 == wg - 3, f"{case} option 0: weight-gradient kernel {kid0}, expected {wg - 3}"
                 seen_wg.add(kid0)
     assert seen_cfg == set(range(14)), f"conv configs without a parity case: {sorted(set(range(14)) - seen_cfg)}"
-    assert seen_wg == set(range(9)), f"weight-gradient kernels without a parity case: {sorted(set(range(9)) - seen_wg)}"
+    assert seen_wg == set(range(10)), f"weight-gradient kernels without a parity case: {sorted(set(range(10)) - seen_wg)}"
     assert {2, 9} <= splitk_wide, "the 32-channel-stage igemm also needs a split-K parity case"
 
 

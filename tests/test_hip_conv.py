@@ -593,3 +593,48 @@ def test_thin_conv_on_matrix_tiles_matches_the_vector_kernel(case):
     assert torch.allclose(outs[0][2], outs[1][2], rtol=2e-2, atol=2e-2 * max(1.0, outs[0][2].abs().max().item()))
     y_ref = mod(F.relu(F.instance_norm(x))) + F.relu(F.instance_norm(r))
     assert (outs[1][0] - y_ref.detach()).abs().max().item() <= 1.5e-2 * y_ref.abs().max().item()
+
+
+@pytest.mark.parametrize("stored", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(33, 32, (1, 5, 9, 11)), (96, 64, (2, 8, 8, 8)), (256, 512, (1, 4, 4, 4)), (40, 72, (1, 4, 16, 24)),
+                                  (32, 3, (1, 6, 10, 70)), (64, 2, (2, 4, 8, 8))])      # heads: N <= 4 padded to one 32-column block
+def test_pointwise_conv_weight_gradient_on_transposed_reads(case, stored):
+    """1x1x1 weight gradient of bf16 precision (wgrad_tr1_kernel: a streaming kernel, both operands [voxel][channel] bf16 in
+    LDS, one slab per wave) against torch fp32 - operands rounded to bf16: 1.5e-2 of max|ref| - and against the fp32-MFMA
+    kernel it replaces (option 11 = 0): 1e-2; bias gradient fp32-exact; norm-on-load of the input, accumulate."""
+    from multimodal_tta_amd import ops
+
+    cin, cout, shape = case
+    n, d, h, w = shape
+    torch.manual_seed(41 + cin)
+    mod = ref_module(cin, cout, 1, 1, False)
+    x = (torch.randn(n, cin, d, h, w) * 1.5 + 0.25).to(torch.bfloat16).float()
+    mu = x.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    xin = F.relu((x - mu[:, :, None, None, None]) * rstd[:, :, None, None, None])
+    y_ref = mod(xin)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    wt = mod.weight.detach().cuda().contiguous()
+    x_cl = cl_bf16(x) if stored == "bf16" else cl(x)
+    gy_cl = cl(gy)
+    out = {}
+    for mode in (0, 1):
+        prev = ops.set_option(11, mode)
+        try:
+            op = ops.ConvOp(cin, cout, 1, 1, False, "cuda", dtype=ops.BF16)
+            op.pack(wt)
+            dw = torch.empty_like(wt)
+            db = torch.empty(cout, device="cuda")
+            op.wgrad(x_cl, nl, gy_cl, dw, db)
+            op.wgrad(x_cl, nl, gy_cl, dw, db, accumulate=True)
+            torch.cuda.synchronize()
+            out[mode] = (dw.cpu() / 2, db.cpu() / 2)
+        finally:
+            ops.set_option(11, prev)
+    ref = mod.weight.grad
+    scale = ref.abs().max().item()
+    assert (out[1][0] - ref).abs().max().item() <= 1.5e-2 * scale + 1e-5
+    assert (out[1][0] - out[0][0]).abs().max().item() <= 1e-2 * scale + 1e-6, "differs from the fp32-MFMA kernel"
+    close("bias gradient", out[1][1], mod.bias.grad)
