@@ -67,7 +67,7 @@ def main():
         tot["us"] += d["tus"]
     cyc = lambda us: us * 1e-6 * GHZ * 1e9 * SIMDS
     print("# SQ counters of the adaptation path (unet 4x128^3, bf16 operands, kernels serialised by the PMC passes)\n")
-    print(f"source: `{path}` (scripts/pmc_layers.sh: one counter group per pass, kernel trace only); {SIMDS} SIMDs, {GHZ} GHz assumed.\n")
+    print(f"source: `{path}` (scripts/pmc_bench.sh or scripts/pmc_layers.sh: one counter group per pass, kernel trace only); {SIMDS} SIMDs, {GHZ} GHz assumed.\n")
     print("| kernel family | share of VALU-busy cycles | kernel time (us) | VALU busy | MFMA busy | SALU busy |")
     print("|---|---:|---:|---:|---:|---:|")
     for name, f in sorted(fams.items(), key=lambda kv: -kv[1]["valu"]):
