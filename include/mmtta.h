@@ -372,6 +372,26 @@ typedef struct mmtta_optim_desc {
 int mmtta_optim_step(const mmtta_optim_desc* desc, float* p, const float* g, float* m, float* v, int64_t n,
                      int64_t n_decay, int32_t* step, void* stream);
 
+/* Weight gradient with the optimizer update fused into its reduction: the same launches as mmtta_conv_wgrad, but the
+ * reduce kernels, which are the first place the complete gradient of an element exists, apply mmtta_optim_step's arithmetic
+ * to `param` / `exp_avg` / `exp_avg_sq` (the layout of dw: torch's weight layout) instead of writing dw - bit-identical
+ * parameters, 8 of the optimizer's 28 bytes per parameter never move and the rest moves inside the backward pass.  `step`
+ * is read, not advanced (advance it once per optimizer step, after every layer: mmtta_optim_step on the remaining
+ * parameters does).  The bias gradient still goes to `db` (NULL: none).  Only layers whose weight gradient goes through the
+ * slab reduction (mmtta_conv_wgrad_fusable() == 1: more than 4 channels on both sides) and no accumulation; the
+ * reference's loss.backward(); optimizer.step() (src/core/trainers/seg_trainer.py:142-143) is the unfused pair.
+ * Measured round 2: 2.5 % SLOWER than the separate pass on the U-Net (the reduction owns one (cd, cg) pair's 27 taps per
+ * thread group: parameter and moments move in 108-byte runs, the arena pass streams) - `method.fuse_optimizer` is off by
+ * default; kept because the result is bit-identical and a reduction over wider (cg) groups would turn the sign. */
+int mmtta_optim_step_partial(const mmtta_optim_desc* desc, float* p, const float* g, float* m, float* v, int64_t n,
+                             int64_t n_decay, int32_t* step, void* stream);     /* mmtta_optim_step without advancing `step` */
+int mmtta_optim_advance(int32_t* step, void* stream);                            /* step += 1 */
+int mmtta_conv_wgrad_fusable(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_tensor* dy);
+int mmtta_conv_wgrad_optim(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                           const mmtta_tensor* dy, float* db, void* workspace, int64_t workspace_bytes,
+                           const mmtta_optim_desc* opt, float* param, float* exp_avg, float* exp_avg_sq,
+                           const int32_t* step, int decay, void* stream);
+
 /* ------------------------------------------------------------------ evaluation tail ------ */
 /* sigmoid -> (>= threshold) -> uint8 mask; GT (> 0.5); per (n,r) integer counts
  * inter = sum p&g, psum = sum p, gsum = sum g.  Replaces reference

@@ -283,6 +283,50 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// ------------------------------------------------------------------ optimizer arithmetic (one element)
+struct OptimArgs {
+  float lr, beta1, beta2, eps, wd, momentum, dampening;
+  int nesterov;
+};
+
+// Every product-sum below is an EXPLICIT fused multiply-add and implicit contraction is switched off: the function is
+// inlined into several kernels (the arena optimizer, the fused weight-gradient reductions) and hipcc's contraction choices
+// differ with the surrounding code - left to itself the two gave moments one ulp apart from the second step on.
+template <int KIND>
+__device__ __forceinline__ void optim_update(float& pi, float gi, float& mi, float& vi, bool decay, const OptimArgs& a,
+                                             float step_size, float bc2_sqrt, bool first) {
+#pragma clang fp contract(off)
+  if (KIND == 0) {
+    if (decay) gi = fmaf(a.wd, pi, gi);
+    mi = fmaf(1.f - a.beta1, gi - mi, mi);
+    vi = fmaf((1.f - a.beta2) * gi, gi, vi * a.beta2);
+    const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+    pi = fmaf(-step_size, mi / denom, pi);
+  } else if (KIND == 1) {
+    if (decay) pi = pi * (1.f - a.lr * a.wd);
+    mi = fmaf(1.f - a.beta1, gi - mi, mi);
+    vi = fmaf((1.f - a.beta2) * gi, gi, vi * a.beta2);
+    const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+    pi = fmaf(-step_size, mi / denom, pi);
+  } else {
+    if (decay) gi = fmaf(a.wd, pi, gi);
+    if (a.momentum != 0.f) {
+      mi = first ? gi : fmaf(a.momentum, mi, (1.f - a.dampening) * gi);
+      gi = a.nesterov ? fmaf(a.momentum, mi, gi) : mi;
+    }
+    pi = fmaf(-a.lr, gi, pi);
+  }
+}
+
+// bias-corrected step size and sqrt(1 - beta2^t) of optimizer step t0 + 1 (double arithmetic, as torch does on the host)
+__device__ __forceinline__ void optim_scalars(int kind, const OptimArgs& a, int t0, float& step_size, float& bc2_sqrt) {
+  const double t = (double)(t0 + 1);
+  const double bc1 = 1.0 - pow((double)a.beta1, t);
+  const double bc2 = 1.0 - pow((double)a.beta2, t);
+  step_size = kind == 2 ? a.lr : (float)((double)a.lr / bc1);
+  bc2_sqrt = kind == 2 ? 1.f : (float)sqrt(bc2);
+}
+
 // shared between translation units (defined in pointwise.hip)
 int channel_partial_rows(const mmtta_tensor* t);                        // partial rows per batch item
 int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s);  // part: [N*rows][2][C] (sum, sumsq)

@@ -235,11 +235,43 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
 // dw[cd][cg][tap] (+)= sum_sl slab[sl][tap][cg][cd]   (torch weight layout out of the [tap][cg][cd] slabs)
 // The transpose goes through LDS so that both sides stay coalesced: reads run along cd, writes are runs of
 // `ntaps` consecutive floats per (cd, cg).  27 taps: one block = one cg x 64 cd;  1 tap: 32 cg x 32 cd.
+// Optimizer fused into the reduction (mmtta_conv_wgrad_optim): the reduce kernels are the first place the COMPLETE weight
+// gradient exists, so they apply the parameter update there instead of writing dw for a later pass over the arena to read
+// back - the arithmetic of optim_kernel on the same fp32 value, element by element (bit-identical parameters), 8 of the
+// optimizer's 28 bytes per parameter never move, and the remaining 24 move inside small launches that overlap the
+// backward pass instead of in one chip-filling stream at the end of the step.  p == nullptr: plain reduction.
+struct FusedOpt {
+  float* p; float* m; float* v;      // parameter, first / second moment: the layout of dw
+  const int* step;
+  OptimArgs a;
+  int kind, decay;
+};
+
+__device__ __forceinline__ void fused_update(const FusedOpt& fo, long long idx, float g, float step_size, float bc2_sqrt, bool first) {
+  float pi = fo.p[idx], mi = 0.f, vi = 0.f;
+  const bool decay = fo.decay && fo.a.wd != 0.f;
+  if (fo.kind == 0) {
+    mi = fo.m[idx]; vi = fo.v[idx];
+    optim_update<0>(pi, g, mi, vi, decay, fo.a, step_size, bc2_sqrt, first);
+    fo.m[idx] = mi; fo.v[idx] = vi;
+  } else if (fo.kind == 1) {
+    mi = fo.m[idx]; vi = fo.v[idx];
+    optim_update<1>(pi, g, mi, vi, decay, fo.a, step_size, bc2_sqrt, first);
+    fo.m[idx] = mi; fo.v[idx] = vi;
+  } else {
+    if (fo.a.momentum != 0.f) mi = fo.m[idx];
+    optim_update<2>(pi, g, mi, vi, decay, fo.a, step_size, bc2_sqrt, first);
+    if (fo.a.momentum != 0.f) fo.m[idx] = mi;
+  }
+  fo.p[idx] = pi;
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                              int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate,
                                                              const float* __restrict__ dbpart, float* __restrict__ db,
-                                                             int db_nsl) {
+                                                             int db_nsl, FusedOpt fo) {
   __shared__ float tile[32][28];
+  __shared__ float s_opt[2];
   const int cd0 = blockIdx.y * 32;
   if ((int)blockIdx.x == Cg) {
     // bias gradient rows ride in the same launch: db[cd] (+)= sum_sl dbpart[sl][cd]; 8 threads per channel
@@ -296,21 +328,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __rest
     const int i = threadIdx.x + 256 * it;
     if (i < 27 * 32) tile[i & 31][i >> 5] = live[it] ? acc[it] : 0.f;
   }
+  int t0 = 0;
+  if (fo.p != nullptr) {
+    t0 = *fo.step;
+    if (threadIdx.x == 0) optim_scalars(fo.kind, fo.a, t0, s_opt[0], s_opt[1]);
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < 27 * 32; i += 256) {
     const int cdl = i / 27, tap = i % 27;
     const int cd = cd0 + cdl;
     if (cd < Cd) {
-      float* o = dw + ((long long)cd * Cg + cg) * 27 + tap;
+      const long long idx = ((long long)cd * Cg + cg) * 27 + tap;
       const float v = tile[cdl][tap];
-      *o = accumulate ? (*o + v) : v;
+      if (fo.p != nullptr) fused_update(fo, idx, v, s_opt[0], s_opt[1], t0 == 0);
+      else dw[idx] = accumulate ? (dw[idx] + v) : v;
     }
   }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                            int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate) {
+                                                            int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate, FusedOpt fo) {
   __shared__ float tile[32][33];
+  __shared__ float s_opt[2];
   const int cg0 = blockIdx.x * 32, cd0 = blockIdx.y * 32;
   for (int i = threadIdx.x; i < 32 * 32; i += 256) {
     const int cdl = i & 31, cgl = i >> 5;
@@ -319,13 +358,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restr
       for (int sl = 0; sl < nsl; ++sl) s += slab[((long long)sl * CGp + cg0 + cgl) * CDp + cd0 + cdl];
     tile[cdl][cgl] = s;
   }
+  int t0 = 0;
+  if (fo.p != nullptr) {
+    t0 = *fo.step;
+    if (threadIdx.x == 0) optim_scalars(fo.kind, fo.a, t0, s_opt[0], s_opt[1]);
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < 32 * 32; i += 256) {
     const int cgl = i & 31, cdl = i >> 5;
     if (cg0 + cgl < Cg && cd0 + cdl < Cd) {
-      float* o = dw + (long long)(cd0 + cdl) * Cg + cg0 + cgl;
+      const long long idx = (long long)(cd0 + cdl) * Cg + cg0 + cgl;
       const float v = tile[cdl][cgl];
-      *o = accumulate ? (*o + v) : v;
+      if (fo.p != nullptr) fused_update(fo, idx, v, s_opt[0], s_opt[1], t0 == 0);
+      else dw[idx] = accumulate ? (dw[idx] + v) : v;
     }
   }
 }
@@ -1848,13 +1893,15 @@ extern "C" int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* d, const mmtta_ten
   return w.si == 1 ? 0 : 1;
 }
 
-extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
-                                const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
-                                int64_t workspace_bytes, void* stream) {
+static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                           const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
+                           int64_t workspace_bytes, void* stream, const FusedOpt& fo) {
   WGeo w;
   int st = wgeometry(d, x, dy, w);
   if (st) return st;
-  MMTTA_CHECK(dw != nullptr, MMTTA_ERR_INVALID, "wgrad: null dw");
+  MMTTA_CHECK(dw != nullptr || fo.p != nullptr, MMTTA_ERR_INVALID, "wgrad: null dw");
+  MMTTA_CHECK(fo.p == nullptr || (!w.tiny && !w.small && !accumulate), MMTTA_ERR_UNSUPPORTED,
+              "wgrad + optimizer: only the slab-reduced layers (more than 4 channels on both sides), without accumulate");
   const int64_t need = (w.slab_floats + w.db_floats + w.pre_floats) * 4;
   MMTTA_CHECK(workspace != nullptr && workspace_bytes >= need, MMTTA_ERR_WORKSPACE, "wgrad: workspace %lld bytes, need %lld",
               (long long)workspace_bytes, (long long)need);
@@ -1972,10 +2019,10 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
   const bool db_here = db != nullptr && !w.convt;      // bias partials written by the main kernel: [nsl][CDp]
   if (w.ntaps == 27)
     hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3(a.Cg + (db_here ? 1 : 0), (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
-                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, dbws, db, w.nsl);
+                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, dbws, db, w.nsl, fo);
   else
     hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((a.Cg + 31) / 32, (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
-                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate);
+                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, fo);
   st = launch_status("wgrad reduce");
   if (st) return st;
   if (db != nullptr) {
@@ -1992,4 +2039,37 @@ extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x,
     st = launch_status("bias reduce");
   }
   return st;
+}
+
+extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                                const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+  FusedOpt fo;
+  fo.p = fo.m = fo.v = nullptr; fo.step = nullptr; fo.kind = 0; fo.decay = 0;
+  fo.a = OptimArgs{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+  return conv_wgrad_impl(d, x, x_norm, dy, dw, db, accumulate, workspace, workspace_bytes, stream, fo);
+}
+
+// 1 when mmtta_conv_wgrad_optim can take this layer (its weight gradient goes through the slab reduce kernels), else 0
+extern "C" int mmtta_conv_wgrad_fusable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* dy) {
+  WGeo w;
+  const int st = wgeometry(d, x, dy, w);
+  if (st) return st < 0 ? st : -st;
+  return (!w.tiny && !w.small) ? 1 : 0;
+}
+
+extern "C" int mmtta_conv_wgrad_optim(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                                      const mmtta_tensor* dy, float* db, void* workspace, int64_t workspace_bytes,
+                                      const mmtta_optim_desc* opt, float* param, float* exp_avg, float* exp_avg_sq,
+                                      const int32_t* step, int decay, void* stream) {
+  MMTTA_CHECK(opt != nullptr && param != nullptr && step != nullptr, MMTTA_ERR_INVALID, "wgrad + optimizer: null argument");
+  MMTTA_CHECK(opt->kind == MMTTA_OPTIM_SGD ? (opt->momentum == 0.f || exp_avg != nullptr) : (exp_avg != nullptr && exp_avg_sq != nullptr),
+              MMTTA_ERR_INVALID, "wgrad + optimizer: missing optimizer state buffers");
+  if (opt->kind == MMTTA_OPTIM_SGD)
+    MMTTA_CHECK(!(opt->nesterov && (opt->momentum <= 0.f || opt->dampening != 0.f)), MMTTA_ERR_INVALID,
+                "optimizer: nesterov needs momentum > 0 and zero dampening (torch.optim.SGD raises the same)");
+  FusedOpt fo;
+  fo.p = param; fo.m = exp_avg; fo.v = exp_avg_sq; fo.step = step; fo.kind = opt->kind; fo.decay = decay ? 1 : 0;
+  fo.a = OptimArgs{opt->lr, opt->beta1, opt->beta2, opt->eps, opt->weight_decay, opt->momentum, opt->dampening, opt->nesterov};
+  return conv_wgrad_impl(d, x, x_norm, dy, nullptr, db, 0, workspace, workspace_bytes, stream, fo);
 }
