@@ -217,7 +217,7 @@ BF16_CASES = [
     (16, 32, 3, 2, False, (1, 8, 8, 8)),
     (256, 256, 3, 1, False, (1, 16, 16, 16)),
     (64, 3, 3, 2, True, (1, 3, 5, 70)),
-    # <= 4 channels on both sides (direct_row_kernel; the 4x4x4 matrix-tile form has its own test below)
+    # <= 4 channels on both sides: v_mfma_f32_4x4x4_16B_bf16 (conv3_mfma4_kernel), ragged rows longer than one 64-voxel run
     (3, 3, 3, 1, False, (1, 5, 7, 70)),
     (4, 2, 3, 1, False, (2, 5, 6, 70)),
     (1, 1, 3, 1, False, (1, 6, 5, 9)),
