@@ -10,7 +10,7 @@ reproduces the measured milliseconds per volume and says which kernels the throu
 import re
 import sys
 
-FAT = ("igemm", "wgrad_tr", "wgrad_bf16", "wgrad_small", "wgrad_f32", "upconv", "chan_mfma")
+FAT = ("igemm", "wgrad_tr", "wgrad_bf16", "wgrad_small", "wgrad_f32", "upconv", "chan_mfma", "conv3_mfma4")
 
 
 def family(k):
