@@ -56,8 +56,8 @@ def mfma_peak(kernel_name: str) -> float:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8, help="timed adapted volumes per rank")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24, help="timed adapted volumes per rank")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="unet", choices=["unet", "unet_multimodal_deepfusion"])
     ap.add_argument("--task", default="brats", choices=["brats", "hecktor21"])
     ap.add_argument("--tta-steps", type=int, default=10)
