@@ -380,9 +380,10 @@ int mmtta_optim_step(const mmtta_optim_desc* desc, float* p, const float* g, flo
  * parameters does).  The bias gradient still goes to `db` (NULL: none).  Only layers whose weight gradient goes through the
  * slab reduction (mmtta_conv_wgrad_fusable() == 1: more than 4 channels on both sides) and no accumulation; the
  * reference's loss.backward(); optimizer.step() (src/core/trainers/seg_trainer.py:142-143) is the unfused pair.
- * Measured round 2: 3 % SLOWER than the separate pass on the U-Net (57.4 against 59.3 volumes/s), with 108-byte and with
- * 864-byte runs of dw per reduce workgroup alike: the update turns a write-only reduction into three reads and three
- * writes per element inside small launches, and the arena pass it replaces streams at 6.4 TB/s.  `method.fuse_optimizer`
+ * Measured round 2: 3 % SLOWER than the separate pass on the U-Net (57.4 against 59.3 volumes/s), with 108-byte runs of dw
+ * per reduce workgroup and with 864-byte runs (a reduce kernel of 8 cg per workgroup, itself 7 -> 12.5 us per launch and
+ * dropped again) alike: the update turns a write-only reduction into three reads and three writes per element inside
+ * small launches, and the arena pass it replaces streams at 6.4 TB/s.  `method.fuse_optimizer`
  * is off by default; kept because the result is bit-identical. */
 int mmtta_optim_step_partial(const mmtta_optim_desc* desc, float* p, const float* g, float* m, float* v, int64_t n,
                              int64_t n_decay, int32_t* step, void* stream);     /* mmtta_optim_step without advancing `step` */

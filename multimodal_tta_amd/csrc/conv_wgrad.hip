@@ -270,10 +270,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __rest
                                                              int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate,
                                                              const float* __restrict__ dbpart, float* __restrict__ db,
                                                              int db_nsl, FusedOpt fo) {
-  __shared__ float tile2[32][217];
+  __shared__ float tile[32][28];
   __shared__ float s_opt[2];
   const int cd0 = blockIdx.y * 32;
-  if ((int)blockIdx.x == (Cg + 7) / 8) {
+  if ((int)blockIdx.x == Cg) {
     // bias gradient rows ride in the same launch: db[cd] (+)= sum_sl dbpart[sl][cd]; 8 threads per channel
     const int cdl = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int cd = min(cd0 + cdl, Cd - 1);
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __rest
         s4[u] += q < db_nsl ? v : 0.f;
       }
     }
-    float* red = &tile2[0][0];
+    float* red = &tile[0][0];
     red[threadIdx.x] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     __syncthreads();
     if (threadIdx.x < 32 && cd0 + (int)threadIdx.x < Cd) {
@@ -298,43 +298,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __rest
     }
     return;
   }
-  // one block = 8 cg x 32 cd x 27 taps = 6912 sums: a thread owns one (cg, cd) pair and walks its 27 taps, every load a
-  // 128-byte row of cd; the sums go through LDS and leave as runs of 8 cg x 27 taps = 216 consecutive floats of dw per cd
-  // (864 bytes; one cg per block gave 108-byte runs, which is what made the fused optimizer below lose to the arena pass)
-  const int cg0 = blockIdx.x * 8;
-  const int cdl = threadIdx.x & 31, cgl = threadIdx.x >> 5;
-  const bool live = cg0 + cgl < Cg && cd0 + cdl < Cd;
+  // one block = one cg x 32 cd x 27 taps = 864 sums: up to 4 per thread, all advancing together through the slabs
+  // (4 slabs x 4 items = 16 independent loads per trip, unconditional from clamped addresses)
+  const int cg = blockIdx.x;
   const long long st = (long long)27 * CGp * CDp;
-  const float* base = slab + (long long)min(cg0 + cgl, CGp - 1) * CDp + min(cd0 + cdl, CDp - 1);
-  const long long tstep = (long long)CGp * CDp;
-  float acc[27];
+  const float* pit[4];
+  bool live[4];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
-  for (int sl = 0; sl < nsl; ++sl) {
-    const float* ps = base + (long long)sl * st;
-    float v[27];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) v[t] = ps[t * tstep];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] += v[t];
+  for (int it = 0; it < 4; ++it) {
+    const int i = threadIdx.x + 256 * it;
+    const int cdl = i & 31, tap = min(i >> 5, 26);
+    live[it] = i < 27 * 32 && cd0 + cdl < Cd;
+    pit[it] = slab + ((long long)tap * CGp + cg) * CDp + min(cd0 + cdl, CDp - 1);
   }
-  float* tile = &tile2[0][0];                   // [32 cd][217]: row = 8 cg x 27 taps (+1 pad)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < nsl; sl += 4) {
+    float v[4][4];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) tile[cdl * 217 + cgl * 27 + t] = live ? acc[t] : 0.f;
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) v[it][u] = pit[it][(long long)min(sl + u, nsl - 1) * st];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) acc[it] += sl + u < nsl ? v[it][u] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = threadIdx.x + 256 * it;
+    if (i < 27 * 32) tile[i & 31][i >> 5] = live[it] ? acc[it] : 0.f;
+  }
   int t0 = 0;
   if (fo.p != nullptr) {
     t0 = *fo.step;
     if (threadIdx.x == 0) optim_scalars(fo.kind, fo.a, t0, s_opt[0], s_opt[1]);
   }
   __syncthreads();
-  const int ncg = min(8, Cg - cg0);             // cg columns of this block that exist
-  const int run = ncg * 27;
-  for (int i = threadIdx.x; i < 32 * 216; i += 256) {
-    const int c = i / 216, j = i - c * 216;
-    const int cd = cd0 + c;
-    if (cd < Cd && j < run) {
-      const long long idx = ((long long)cd * Cg + cg0) * 27 + j;
-      const float v = tile[c * 217 + j];
+  for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+    const int cdl = i / 27, tap = i % 27;
+    const int cd = cd0 + cdl;
+    if (cd < Cd) {
+      const long long idx = ((long long)cd * Cg + cg) * 27 + tap;
+      const float v = tile[cdl][tap];
       if (fo.p != nullptr) fused_update(fo, idx, v, s_opt[0], s_opt[1], t0 == 0);
       else dw[idx] = accumulate ? (dw[idx] + v) : v;
     }
@@ -2013,7 +2018,7 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
   }
   const bool db_here = db != nullptr && !w.convt;      // bias partials written by the main kernel: [nsl][CDp]
   if (w.ntaps == 27)
-    hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3((a.Cg + 7) / 8 + (db_here ? 1 : 0), (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
+    hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3(a.Cg + (db_here ? 1 : 0), (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
                        a.Cg, a.Cd, w.CGp, w.CDp, accumulate, dbws, db, w.nsl, fo);
   else
     hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((a.Cg + 31) / 32, (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
