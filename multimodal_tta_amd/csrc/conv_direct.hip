@@ -774,6 +774,7 @@ struct CArgs {
   int accumulate;
   float* stats; int tiles_per_n;
   int tz, ty, tx;
+  int koff;                       // KI == 1: the channel sits at float `koff` of the 16-byte group `in.p` points at
 };
 
 template <int S, int KI, int NLN, bool HAS_T>
@@ -813,7 +814,8 @@ __global__ __launch_bounds__(256) void direct_chan_kernel(CArgs a) {
         const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
         const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
         const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
-        const float r4[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+        float r4[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+        if (KI == 1) r4[0] = a.koff == 0 ? raw[q].x : a.koff == 1 ? raw[q].y : a.koff == 2 ? raw[q].z : raw[q].w;
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -923,7 +925,8 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
         const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
         const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
         const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
-        const float r4[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+        float r4[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
+        if (KI == 1) r4[0] = a.koff == 0 ? raw[q].x : a.koff == 1 ? raw[q].y : a.koff == 2 ? raw[q].z : raw[q].w;
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1053,7 +1056,11 @@ bool chan_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   // N = 64 (one voxel per pass) measured slower than the fp32 implicit GEMM (109 vs 80 us on the 64->3 up-convolution's
   // input gradient: 27 LDS reads per voxel and wave); kept for N = 32, two voxels per pass
   // N = 64 only on the matrix cores (bf16 mode): the input gradient of the 64->R up-convolution
-  return K <= 4 && (N == 32 || (N == 64 && d->dtype == MMTTA_BF16)) && aligned16(x) && x->sw >= 4;
+  // a one-channel slice of a wider tensor (modality m of the network input) need not start on a 16-byte group: the kernels
+  // load the group it sits in and pick its float (CArgs::koff)
+  const bool slice1 = K == 1 && x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0 &&
+                      ((uintptr_t)x->ptr) % 4 == 0;
+  return K <= 4 && (N == 32 || (N == 64 && d->dtype == MMTTA_BF16)) && (aligned16(x) || slice1) && x->sw >= 4;
 }
 
 int chan_tiles_per_n(const mmtta_tensor* y) { return ((y->d + 3) / 4) * ((y->h + 3) / 4) * ((y->w + 7) / 8); }
@@ -1095,6 +1102,9 @@ int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_n
                   hipStream_t stream) {
   CArgs a;
   a.in = tv(x); a.tin = nl(x_norm); a.out = tv(y);
+  a.koff = (int)((((uintptr_t)x->ptr) % 16) / 4);
+  MMTTA_CHECK(a.koff == 0 || x->c == 1, MMTTA_ERR_UNSUPPORTED, "thin-K conv: only a one-channel slice may start inside a 16-byte group");
+  a.in.p -= a.koff;
   a.w = (const float*)packed; a.Kp = Kp; a.Np = Np; a.bias = bias;
   a.add = nullptr; a.asn = a.asd = a.ash = a.asw = 0; a.tadd = nl(nullptr); a.add_bf = 0;
   if (epi && epi->add) {

@@ -1702,22 +1702,39 @@ __device__ __forceinline__ void pack_tile(const PackEntry& e, int lb, float* til
   const int k0 = (lb / tiles_n) * PK, n0 = (lb % tiles_n) * PN;
   const int K = e.kn_is_ba ? e.B : e.A, N = e.kn_is_ba ? e.A : e.B;
   constexpr int RS = PK * T + 1;                 // row stride of the [n][k*T+tap] staging (odd: no bank conflicts)
+  // PN*PK*T is a multiple of 256 (6912 = 27 * 256, 256): U loads are issued before the first one is stored (one load per
+  // trip left the workgroup waiting 27 memory latencies in a row)
+  constexpr int IT = PN * PK * T / 256, U = IT % 9 == 0 ? 9 : 1;
+  static_assert(PN * PK * T % 256 == 0, "pack tile: whole trips");
   if (e.kn_is_ba) {                              // a = n, b = k: per n a run of PK*T contiguous floats
-    for (int idx = threadIdx.x; idx < PN * PK * T; idx += 256) {
-      const int nn = idx / (PK * T), r = idx % (PK * T);
-      const int kk = r / T;
-      // unconditional load from a clamped address, masked afterwards (a load behind a branch is waited for at once)
-      const bool ok = n0 + nn < N && k0 + kk < K;
-      const float v = e.w[((long long)min(n0 + nn, N - 1) * e.B + min(k0 + kk, K - 1)) * T + (r - kk * T)];
-      tile[nn * RS + r] = ok ? v : 0.f;
+    for (int it = 0; it < IT; it += U) {
+      float v[U]; int dst[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = (it + u) * 256 + threadIdx.x;
+        const int nn = idx / (PK * T), r = idx % (PK * T);
+        const int kk = r / T;
+        // unconditional load from a clamped address, masked afterwards (a load behind a branch is waited for at once)
+        ok[u] = n0 + nn < N && k0 + kk < K;
+        v[u] = e.w[((long long)min(n0 + nn, N - 1) * e.B + min(k0 + kk, K - 1)) * T + (r - kk * T)];
+        dst[u] = nn * RS + r;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) tile[dst[u]] = ok[u] ? v[u] : 0.f;
     }
   } else {                                       // a = k, b = n: per k a run of PN*T contiguous floats
-    for (int idx = threadIdx.x; idx < PK * PN * T; idx += 256) {
-      const int kk = idx / (PN * T), r = idx % (PN * T);
-      const int nn = r / T;
-      const bool ok = k0 + kk < K && n0 + nn < N;
-      const float v = e.w[((long long)min(k0 + kk, K - 1) * e.B + min(n0 + nn, N - 1)) * T + (r - nn * T)];
-      tile[kk * (PN * T) + r] = ok ? v : 0.f;
+    for (int it = 0; it < IT; it += U) {
+      float v[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = (it + u) * 256 + threadIdx.x;
+        const int kk = idx / (PN * T), r = idx % (PN * T);
+        const int nn = r / T;
+        ok[u] = k0 + kk < K && n0 + nn < N;
+        v[u] = e.w[((long long)min(k0 + kk, K - 1) * e.B + min(n0 + nn, N - 1)) * T + (r - nn * T)];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) tile[(it + u) * 256 + threadIdx.x] = ok[u] ? v[u] : 0.f;
     }
   }
   __syncthreads();

@@ -357,6 +357,78 @@ __global__ __launch_bounds__(256) void elementwise_kernel(EwArgs e) {
   }
 }
 
+// ------------------------------------------------------------------ norm backward apply, 8 channels per thread
+// The same arithmetic as elementwise_kernel<1, ...> for voxel-dense tensors with C a power of two >= 8: a thread keeps ONE
+// channel octet (its 48 coefficients are loaded once, as 16-byte loads) and walks IT voxels whose loads are all issued before
+// the first use; 32-bit element offsets from the batch item's base, no division per element.
+struct Nb8Args {
+  const float* dout; const float* y; float* o;
+  long long dsn, ysn, osn;
+  unsigned dsw, ysw, osw;
+  int C, relu;
+  unsigned dhw;
+  const float* mean; const float* rstd; const float* gamma; const float* beta; const float* m1; const float* m2;
+};
+
+template <bool YBF, int IT>
+__global__ __launch_bounds__(256) void norm_bwd_apply8_kernel(Nb8Args a) {
+  const int n = blockIdx.y;
+  const unsigned CG = (unsigned)a.C >> 3, nvl = 256u / CG;
+  const unsigned cg = threadIdx.x & (CG - 1), vl = threadIdx.x / CG;   // CG is a power of two
+  const unsigned c0 = cg * 8;
+  const float* dp = a.dout + (long long)n * a.dsn;
+  const float* yp = YBF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.y) + (long long)n * a.ysn)
+                        : a.y + (long long)n * a.ysn;
+  float* op = a.o + (long long)n * a.osn;
+  const unsigned v0 = blockIdx.x * (nvl * IT) + vl;
+  Oct8<YBF> yr[IT];
+  float4 d0[IT], d1[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const unsigned v = min(v0 + i * nvl, a.dhw - 1);                   // clamped address, masked store
+    yr[i] = oct8_ld<YBF>(yp, v * a.ysw + c0, v * a.ysw + c0 + 4);
+    d0[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0);
+    d1[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0 + 4);
+  }
+  float mu[8], rs[8], g[8], bt[8], m1[8], m2[8];
+  {
+    const unsigned pc = (unsigned)n * a.C + c0;
+    auto ld8 = [](const float* p, unsigned off, float (&r)[8]) {
+      const float4 lo = *reinterpret_cast<const float4*>(p + off), hi = *reinterpret_cast<const float4*>(p + off + 4);
+      r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = hi.w;
+    };
+    ld8(a.mean, pc, mu); ld8(a.rstd, pc, rs); ld8(a.m1, pc, m1); ld8(a.m2, pc, m2);
+    if (a.gamma) ld8(a.gamma, c0, g);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = 1.f;
+    }
+    if (a.beta) ld8(a.beta, c0, bt);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bt[j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    float yv[8], ov[8];
+    oct8_f8(yr[i], yv);
+    const float dv[8] = {d0[i].x, d0[i].y, d0[i].z, d0[i].w, d1[i].x, d1[i].y, d1[i].z, d1[i].w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xhat = (yv[j] - mu[j]) * rs[j];
+      float dz = dv[j];
+      if (a.relu && !(fmaf(g[j], xhat, bt[j]) > 0.f)) dz = 0.f;
+      ov[j] = rs[j] * (g[j] * dz - m1[j] - xhat * m2[j]);
+    }
+    const unsigned v = v0 + i * nvl;
+    if (v < a.dhw) {
+      *reinterpret_cast<float4*>(op + v * a.osw + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      *reinterpret_cast<float4*>(op + v * a.osw + c0 + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ linear combination
 struct LinArgs {
   TV in[8];
@@ -719,6 +791,40 @@ extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor
   const long long total = (long long)y->n * y->d * y->h * y->w * (v4 ? (y->c + 3) / 4 : y->c);
   const dim3 grid(grid_for(total));
   hipStream_t s = (hipStream_t)stream;
+  {
+    // octet form: C a power of two in [8, 2048], voxel-dense tensors, 16-byte aligned octets, 32-bit offsets inside an item
+    const int C = y->c;
+    const long long dhw = (long long)y->d * y->h * y->w;
+    auto dense = [](const mmtta_tensor* t) { return t->sh == (int64_t)t->w * t->sw && t->sd == (int64_t)t->h * t->sh; };
+    auto al = [](const mmtta_tensor* t, int per) {
+      return ((uintptr_t)t->ptr) % 16 == 0 && t->sw % per == 0 && t->sn % per == 0;
+    };
+    const bool pow2 = C >= 8 && C <= 2048 && (C & (C - 1)) == 0;
+    const bool ok8 = v4 && pow2 && dense(dout) && dense(y) && dense(dy) && al(dout, 4) && al(dy, 4) && al(y, is_bf16(y) ? 8 : 4) &&
+                     ((uintptr_t)t->mean % 16 == 0) && ((uintptr_t)t->rstd % 16 == 0) && ((uintptr_t)m1 % 16 == 0) &&
+                     ((uintptr_t)m2 % 16 == 0) && (!t->gamma || (uintptr_t)t->gamma % 16 == 0) &&
+                     (!t->beta || (uintptr_t)t->beta % 16 == 0) && dhw * std::max(std::max(dout->sw, y->sw), dy->sw) < (1LL << 31);
+    if (ok8) {
+      Nb8Args q;
+      q.dout = (const float*)dout->ptr; q.y = (const float*)y->ptr; q.o = (float*)dy->ptr;
+      q.dsn = dout->sn; q.ysn = y->sn; q.osn = dy->sn;
+      q.dsw = (unsigned)dout->sw; q.ysw = (unsigned)y->sw; q.osw = (unsigned)dy->sw;
+      q.C = C; q.relu = t->relu; q.dhw = (unsigned)dhw;
+      q.mean = t->mean; q.rstd = t->rstd; q.gamma = t->gamma; q.beta = t->beta; q.m1 = m1; q.m2 = m2;
+      const long long nvl = 256 / (C / 8);
+      const bool four = dhw / (nvl * 4) >= 1024;
+      const long long per = nvl * (four ? 4 : 2);
+      const dim3 g8((unsigned)((dhw + per - 1) / per), (unsigned)y->n);
+      if (is_bf16(y)) {
+        if (four) hipLaunchKernelGGL((norm_bwd_apply8_kernel<true, 4>), g8, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((norm_bwd_apply8_kernel<true, 2>), g8, dim3(256), 0, s, q);
+      } else {
+        if (four) hipLaunchKernelGGL((norm_bwd_apply8_kernel<false, 4>), g8, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((norm_bwd_apply8_kernel<false, 2>), g8, dim3(256), 0, s, q);
+      }
+      return launch_status("norm bwd apply");
+    }
+  }
   if (is_bf16(y)) {
     if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4, false, true, false>), grid, dim3(256), 0, s, e);
     else hipLaunchKernelGGL((elementwise_kernel<1, 1, false, true, false>), grid, dim3(256), 0, s, e);

@@ -193,6 +193,30 @@ def test_conv_channel_slices():
     assert out[..., :32].abs().max().item() == 0 and out[..., 64:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_one_channel_slices_of_the_input_take_the_thin_kernel(precision):
+    """The single-modality stems of the deep-fusion net (Conv3d 1->32 k3 s2 on channel m of the 4-channel input): a slice
+    that starts inside a 16-byte group (m = 1..3) runs on the same thin-K kernel as m = 0 (plan config 13; it fell back
+    to the padded fp32 implicit GEMM before) and matches torch."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(23)
+    n, d, h, w = 1, 12, 10, 16
+    x = torch.randn(n, 4, d, h, w)
+    x_cl = cl(x)
+    for m in range(4):
+        mod = torch.nn.Conv3d(1, 32, 3, stride=2, padding=1)
+        y_ref = mod(x[:, m:m + 1])
+        op = ops.ConvOp(1, 32, 3, 2, False, "cuda", dtype=ops.BF16 if precision == "bf16" else ops.F32)
+        op.pack(mod.weight.detach().cuda().contiguous())
+        xs = x_cl[..., m:m + 1]
+        y = torch.empty(n, (d + 1) // 2, (h + 1) // 2, (w + 1) // 2, 32, device="cuda")
+        assert int(op.plan(op.d_fwd, xs, y).config) == 13, f"modality {m}: not the thin-K kernel"
+        op.forward(xs, None, mod.bias.detach().cuda(), y)
+        torch.cuda.synchronize()
+        close(f"modality {m} stem", ncdhw(y), y_ref)
+
+
 BF16_CASES = [
     (32, 32, 3, 1, False, (1, 16, 16, 16)),
     (33, 32, 3, 1, False, (1, 8, 8, 16)),        # 16-channel tail step
