@@ -1387,7 +1387,91 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
   const int t0 = (int)xcd_contiguous_id(blockIdx.x, gridDim.x) * a.tiles_per_split;   // one part of the volume per XCD
   const int t1 = min(a.tiles, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
+  // Both operands 16-byte addressable (every layer of the shipped networks): the NEXT tile's global loads are issued
+  // before this tile's MFMAs and land while they run (a workgroup walked load -> barrier -> MFMA -> barrier with one
+  // workgroup per CU: every tile paid a full memory latency).  Otherwise the loads sit in the staging step itself.
+  constexpr int NQ = 6;                           // ceil(9*9*17 / 256): the stride-2 box is the largest
+  const bool piped = a.qvec4 && a.pvec4;
+  float4 raw[NQ], praw[MT / 32];
+  float qsc[4], qsh[4], psc[4], psh[4];
+  const int pcv = tid & 7, pc = cb0 + pcv * 4;
+  const int pcl4 = min(pc, (a.Cb - 1) & ~3);      // clamped channel group (16-byte aligned)
+  int n_coef = -1;
+  auto decode = [&](int tile, int& n, int& oz0, int& oy0, int& ox0) {
+    n = tile / tpn;
+    int t = tile % tpn;
+    const int txi = t % a.tx; t /= a.tx;
+    const int tyi = t % a.ty;
+    const int tzi = t / a.ty;
+    oz0 = tzi * TZ; oy0 = tyi * TY; ox0 = txi * TX;
+  };
+  auto issue = [&](int tile) {
+    int n, oz0, oy0, ox0;
+    decode(tile, n, oz0, oy0, ox0);
+    const int iz0 = oz0 * a.si + dmin, iy0 = oy0 * a.si + dmin, ix0 = ox0 * a.si + dmin;
+    const float* qb = a.q + (long long)n * a.qsn;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int bv = min(tid + 256 * q, boxvox - 1);
+      const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+      const int iz = min(max(iz0 + bz, 0), a.Dq - 1), iy = min(max(iy0 + by, 0), a.Hq - 1), ix = min(max(ix0 + bx, 0), a.Wq - 1);
+      raw[q] = *reinterpret_cast<const float4*>(qb + iz * a.qsd + iy * a.qsh + ix * a.qsw);
+    }
+    const long long pbo = (long long)n * a.psn;
+#pragma unroll
+    for (int q = 0; q < MT / 32; ++q) {
+      const int v = (tid >> 3) + 32 * q;
+      const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+      const int oz = min(oz0 + zl, a.Dp - 1), oy = min(oy0 + yl, a.Hp - 1), ox = min(ox0 + xl, a.Wp - 1);
+      praw[q] = ld4_t<PBF>(a.p, pbo + (long long)oz * a.psd + (long long)oy * a.psh + (long long)ox * a.psw + pcl4);
+    }
+    if (n != n_coef) {
+      nl_coeff_vec<4>(a.tq, n, a.Cs, 0, qsc, qsh);
+      nl_coeff_vec<4>(a.tp, n, a.Cb, pc, psc, psh);
+      n_coef = n;
+    }
+  };
+  auto commit = [&](int tile) {
+    int n, oz0, oy0, ox0;
+    decode(tile, n, oz0, oy0, ox0);
+    const int iz0 = oz0 * a.si + dmin, iy0 = oy0 * a.si + dmin, ix0 = ox0 * a.si + dmin;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int bv = tid + 256 * q;
+      if (bv < boxvox) {
+        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
+        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iz < (unsigned)a.Dq && (unsigned)iy < (unsigned)a.Hq && (unsigned)ix < (unsigned)a.Wq) {
+          v.x = nl_apply(raw[q].x, qsc[0], qsh[0], a.tq.relu);
+          v.y = a.Cs > 1 ? nl_apply(raw[q].y, qsc[1], qsh[1], a.tq.relu) : 0.f;
+          v.z = a.Cs > 2 ? nl_apply(raw[q].z, qsc[2], qsh[2], a.tq.relu) : 0.f;
+          v.w = a.Cs > 3 ? nl_apply(raw[q].w, qsc[3], qsh[3], a.tq.relu) : 0.f;
+        }
+        *reinterpret_cast<float4*>(ql + bv * 4) = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < MT / 32; ++q) {
+      const int v = (tid >> 3) + 32 * q;
+      const int xl = v % TX, yl = (v / TX) % TY, zl = v / (TX * TY);
+      const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oz < a.Dp && oy < a.Hp && ox < a.Wp && pc < a.Cb) {
+        const float4 x4 = praw[q];
+        o.x = nl_apply(x4.x, psc[0], psh[0], a.tp.relu);
+        o.y = (pc + 1 < a.Cb) ? nl_apply(x4.y, psc[1], psh[1], a.tp.relu) : 0.f;
+        o.z = (pc + 2 < a.Cb) ? nl_apply(x4.z, psc[2], psh[2], a.tp.relu) : 0.f;
+        o.w = (pc + 3 < a.Cb) ? nl_apply(x4.w, psc[3], psh[3], a.tp.relu) : 0.f;
+      }
+      *reinterpret_cast<float4*>(pl + v * 32 + pcv * 4) = o;
+    }
+  };
+  if (piped && t0 < t1) issue(t0);
   for (int tile = t0; tile < t1; ++tile) {
+    if (piped) {
+      commit(tile);
+    } else {
     const int n = tile / tpn;
     int t = tile % tpn;
     const int txi = t % a.tx; t /= a.tx;
@@ -1400,8 +1484,6 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
       float sc[4], sh[4];
       nl_coeff_vec<4>(a.tq, n, a.Cs, 0, sc, sh);
       // all of the thread's box voxels are loaded (from clamped addresses) before the first is used
-      constexpr int NQ = 6;                       // ceil(9*9*17 / 256): the stride-2 box is the largest
-      float4 raw[NQ];
       if (a.qvec4) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -1445,7 +1527,6 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
         const int cv = tid & 7, c = cb0 + cv * 4;
         float sc[4], sh[4];
         nl_coeff_vec<4>(a.tp, n, a.Cb, c, sc, sh);
-        float4 praw[MT / 32];
         const int cl4 = min(c, (a.Cb - 1) & ~3);           // clamped channel group (16-byte aligned)
 #pragma unroll
         for (int q = 0; q < MT / 32; ++q) {
@@ -1483,7 +1564,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
         }
       }
     }
+    }
     __syncthreads();
+    if (piped && tile + 1 < t1) issue(tile + 1);
     // voxel v = 2*kk + h: the pair shares (zl, yl) and differs by one x step, so the box offset is a wave-uniform
     // (scalar) term per kk plus a lane term that does not change inside the tile loop
     if (a.bf) {
