@@ -905,26 +905,35 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
   const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
   const int iz0 = oz0 * S - 1, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int N = a.out.c;
-  {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill / round to bf16
-    constexpr int NQ = (BOX + 255) / 256;
+  {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill / round to bf16.
+     // A thread keeps one box column bx and walks box rows (bz, by): the x clamp and mask are computed once, a row costs one
+     // small decode, offsets are 32-bit elements from the batch item (host-checked), validity travels as a bit mask.
+    constexpr int RPP = 256 / BX, NROW = BZ * BY, NQ = (NROW + RPP - 1) / RPP;
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (HAS_T) nl_coeff_vec<4>(a.tin, n, KI, 0, sc, sh);
     const float* inb = a.in.p + (long long)n * a.in.sn;
+    const int bx = tid % BX, r0 = tid / BX;
+    const int ix = ix0 + bx;
+    const bool xok = (unsigned)ix < (unsigned)a.in.w && r0 < RPP;
+    const unsigned xoff = (unsigned)min(max(ix, 0), a.in.w - 1) * (unsigned)a.in.sw;
+    const unsigned sd = (unsigned)a.in.sd, shh = (unsigned)a.in.sh;
     float4 raw[NQ];
+    unsigned okm = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int bv = min(tid + 256 * q, BOX - 1);
-      const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
-      const int iz = min(max(iz0 + bz, 0), a.in.d - 1), iy = min(max(iy0 + by, 0), a.in.h - 1), ix = min(max(ix0 + bx, 0), a.in.w - 1);
-      raw[q] = *reinterpret_cast<const float4*>(inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw);
+      const int row = min(r0 + q * RPP, NROW - 1);
+      const int by = row % BY, bz = row / BY;
+      const int iz = iz0 + bz, iy = iy0 + by;
+      const bool ok = xok && (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h;
+      okm |= (ok ? 1u : 0u) << q;
+      raw[q] = *reinterpret_cast<const float4*>(inb + ((unsigned)min(max(iz, 0), a.in.d - 1) * sd +
+                                                       (unsigned)min(max(iy, 0), a.in.h - 1) * shh + xoff));
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int bv = tid + 256 * q;
-      if (bv < BOX) {
-        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
-        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
-        const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
+      const int row = r0 + q * RPP;
+      if (r0 < RPP && row < NROW) {
+        const bool ok = (okm >> q) & 1u;
         float r4[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
         if (KI == 1) r4[0] = a.koff == 0 ? raw[q].x : a.koff == 1 ? raw[q].y : a.koff == 2 ? raw[q].z : raw[q].w;
         float v[4];
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
         uint2 pk;
         pk.x = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){v[0], v[1]}, bf16x2_t));
         pk.y = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){v[2], v[3]}, bf16x2_t));
-        box[bv] = pk;
+        box[row * BX + bx] = pk;
       }
     }
   }
@@ -1002,32 +1011,49 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
   float ssum[NB], ssq[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) { ssum[nb] = 0.f; ssq[nb] = 0.f; }
+  // voxel m of accumulator i: row oy0 + (i >> 2), column ox0 + (i & 3) + 4 * h; the z-slice (wave) is uniform.  Offsets are
+  // 32-bit elements from the slice (host-checked): four row terms plus four column terms, one add per store.
+  const int oz = oz0 + wave;
+  const bool zok = oz < a.out.d;
+  unsigned oyo[4], oxo[4], ayo[4], axo[4];
+  unsigned okrow = 0, okcol = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = oy0 + j, ox = ox0 + j + 4 * h;
+    okrow |= (zok && oy < a.out.h ? 1u : 0u) << j;
+    okcol |= (ox < a.out.w ? 1u : 0u) << j;
+    oyo[j] = (unsigned)oy * (unsigned)a.out.sh; oxo[j] = (unsigned)ox * (unsigned)a.out.sw;
+    ayo[j] = (unsigned)oy * (unsigned)a.ash; axo[j] = (unsigned)ox * (unsigned)a.asw;
+  }
+  const long long obase = (long long)n * a.out.sn + (long long)oz * a.out.sd;
+  const long long abase = (long long)n * a.asn + (long long)oz * a.asd;
   MMTTA_BF_DISPATCH(a.out.bf, OBF, {
+    float* const outp = OBF ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(a.out.p) + obase) : a.out.p + obase;
+    const float* const addp = a.add == nullptr ? nullptr
+                              : (OBF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.add) + abase) : a.add + abase);
 _Pragma("unroll")
     for (int i = 0; i < 16; ++i) {
-      const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
-      const int oz = oz0 + wave, oy = oy0 + m / TX, ox = ox0 + m % TX;
-      const bool vok = oz < a.out.d && oy < a.out.h && ox < a.out.w;
-      const long long ooff = (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh + (long long)ox * a.out.sw;
-      const long long aoff = (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash + (long long)ox * a.asw;
+      const bool vok = ((okrow >> (i >> 2)) & (okcol >> (i & 3)) & 1u) != 0;
+      const unsigned ooff = oyo[i >> 2] + oxo[i & 3];
+      const unsigned aoff = ayo[i >> 2] + axo[i & 3];
 _Pragma("unroll")
       for (int nb = 0; nb < NB; ++nb) {
         const int col = nb * 32 + r;
         const bool live = vok && col < N;
         float val = acc[nb][i] + bias[nb];
         // fused add / accumulate operands share the output's storage type (host-checked)
-        if (a.add) val += nl_apply(live ? ld1_t<OBF>(a.add, aoff + col) : 0.f, asc[nb], ash[nb], a.tadd.relu);
-        if (a.accumulate && live) val += ld1_t<OBF>(a.out.p, ooff + col);
+        if (a.add) val += nl_apply(live ? ld1_t<OBF>(addp, aoff + col) : 0.f, asc[nb], ash[nb], a.tadd.relu);
+        if (a.accumulate && live) val += ld1_t<OBF>(outp, ooff + col);
         if constexpr (OBF) {
           // bf16 rows: neighbouring channel lanes pair up, the even one stores both as one dword (a 2-byte store per
           // lane is a partial-dword write: ~12x the time per byte of a full store)
           const float other = __shfl_xor(val, 1, 64);
           if (live && !(r & 1)) {
-            if (col + 1 < N) reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned short*>(a.out.p) + ooff + col)[0] = f32x2_to_bf16x2(val, other);
-            else st1_t<true>(a.out.p, ooff + col, val);
+            if (col + 1 < N) reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned short*>(outp) + ooff + col)[0] = f32x2_to_bf16x2(val, other);
+            else st1_t<true>(outp, ooff + col, val);
           }
         } else {
-          if (live) a.out.p[ooff + col] = val;
+          if (live) outp[ooff + col] = val;
         }
         if (live) { ssum[nb] += val; ssq[nb] += val * val; }
       }
@@ -1060,7 +1086,9 @@ bool chan_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   // load the group it sits in and pick its float (CArgs::koff)
   const bool slice1 = K == 1 && x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0 &&
                       ((uintptr_t)x->ptr) % 4 == 0;
-  return K <= 4 && (N == 32 || (N == 64 && d->dtype == MMTTA_BF16)) && (aligned16(x) || slice1) && x->sw >= 4;
+  // the kernels address with 32-bit element offsets inside a batch item (input) / a z-slice (output)
+  const bool small = (long long)x->d * x->sd < (1LL << 31) && (long long)(y->h + 4) * y->sh < (1LL << 31);
+  return K <= 4 && (N == 32 || (N == 64 && d->dtype == MMTTA_BF16)) && (aligned16(x) || slice1) && x->sw >= 4 && small;
 }
 
 int chan_tiles_per_n(const mmtta_tensor* y) { return ((y->d + 3) / 4) * ((y->h + 3) / 4) * ((y->w + 7) / 8); }
@@ -1114,6 +1142,7 @@ int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_n
     a.add = (const float*)ad->ptr; a.asn = ad->sn; a.asd = ad->sd; a.ash = ad->sh; a.asw = ad->sw;
     a.tadd = nl(&epi->add_norm);
     a.add_bf = is_bf16(ad) ? 1 : 0;
+    MMTTA_CHECK((long long)(ad->h + 4) * ad->sh < (1LL << 31), MMTTA_ERR_UNSUPPORTED, "thin-K conv: epilogue `add` slice beyond 2^31 elements");
   }
   // the <= 4-channel gathered tensor is always fp32 (network input, gradient); the 32 / 64-channel result may be
   // bf16-stored, on the matrix-core path only
