@@ -794,33 +794,41 @@ __global__ __launch_bounds__(256) void direct_chan_kernel(CArgs a) {
   const int n = t / a.tz;
   const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
   const int iz0 = oz0 * S - 1, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-  {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill
-    constexpr int NQ = (BOX + 255) / 256;
+  {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill.  A thread keeps one box column and
+     // walks box rows (see chan_mfma_kernel): one x clamp, 32-bit offsets, validity as a bit mask.
+    constexpr int RPP = 256 / BX, NROW = BZ * BY, NQ = (NROW + RPP - 1) / RPP;
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (HAS_T) nl_coeff_vec<4>(a.tin, n, KI, 0, sc, sh);
     const float* inb = a.in.p + (long long)n * a.in.sn;
+    const int bx = tid % BX, r0 = tid / BX;
+    const int ix = ix0 + bx;
+    const bool xok = (unsigned)ix < (unsigned)a.in.w && r0 < RPP;
+    const unsigned xoff = (unsigned)min(max(ix, 0), a.in.w - 1) * (unsigned)a.in.sw;
+    const unsigned sd = (unsigned)a.in.sd, shh = (unsigned)a.in.sh;
     float4 raw[NQ];
+    unsigned okm = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int bv = min(tid + 256 * q, BOX - 1);
-      const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
-      const int iz = min(max(iz0 + bz, 0), a.in.d - 1), iy = min(max(iy0 + by, 0), a.in.h - 1), ix = min(max(ix0 + bx, 0), a.in.w - 1);
-      raw[q] = *reinterpret_cast<const float4*>(inb + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw);
+      const int row = min(r0 + q * RPP, NROW - 1);
+      const int by = row % BY, bz = row / BY;
+      const int iz = iz0 + bz, iy = iy0 + by;
+      const bool ok = xok && (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h;
+      okm |= (ok ? 1u : 0u) << q;
+      raw[q] = *reinterpret_cast<const float4*>(inb + ((unsigned)min(max(iz, 0), a.in.d - 1) * sd +
+                                                       (unsigned)min(max(iy, 0), a.in.h - 1) * shh + xoff));
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int bv = tid + 256 * q;
-      if (bv < BOX) {
-        const int bx = bv % BX, by = (bv / BX) % BY, bz = bv / (BX * BY);
-        const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
-        const bool ok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h && (unsigned)ix < (unsigned)a.in.w;
+      const int row = r0 + q * RPP;
+      if (r0 < RPP && row < NROW) {
+        const bool ok = (okm >> q) & 1u;
         float r4[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
         if (KI == 1) r4[0] = a.koff == 0 ? raw[q].x : a.koff == 1 ? raw[q].y : a.koff == 2 ? raw[q].z : raw[q].w;
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           v[k] = (ok && k < KI) ? (HAS_T ? nl_apply(r4[k], sc[k], sh[k], a.tin.relu) : r4[k]) : 0.f;
-        box[bv] = make_float4(v[0], v[1], v[2], v[3]);
+        box[row * BX + bx] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }
@@ -841,10 +849,14 @@ __global__ __launch_bounds__(256) void direct_chan_kernel(CArgs a) {
   if (a.add) nl_coeff(a.tadd, n, N, min(nl, N - 1), asc, ash);
   __syncthreads();
   float ssum = 0.f, ssq = 0.f;
+  // a wave owns the z-slice oz0 + wave (32 voxels = TY x TX): 32-bit element offsets inside it (host-checked)
+  const int oz = oz0 + wave;
+  float* const outp = a.out.p + (long long)n * a.out.sn + (long long)oz * a.out.sd + nl;
+  const float* const addp = a.add ? a.add + (long long)n * a.asn + (long long)oz * a.asd + nl : nullptr;
 #pragma unroll 2
   for (int p = 0; p < NPASS; ++p) {
-    const int vloc = wave * 32 + p * VP + vslot;
-    const int xl = vloc % TX, yl = (vloc / TX) % TY, zl = vloc / (TX * TY);
+    const int q = p * VP + vslot;
+    const int xl = q % TX, yl = q / TX, zl = wave;
     const float4* bp = box + ((zl * S) * BY + yl * S) * BX + xl * S;
     float acc = 0.f;
 #pragma unroll
@@ -858,11 +870,11 @@ __global__ __launch_bounds__(256) void direct_chan_kernel(CArgs a) {
 #pragma unroll
           for (int k = 0; k < KI; ++k) acc = fmaf(xs[k], w[(dz * 3 + dy) * 3 + dx][k], acc);
         }
-    const int oz = oz0 + zl, oy = oy0 + yl, ox = ox0 + xl;
+    const int oy = oy0 + yl, ox = ox0 + xl;
     if (nok && oz < a.out.d && oy < a.out.h && ox < a.out.w) {
       float val = acc + bias;
-      if (a.add) val += nl_apply(a.add[(long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash + (long long)ox * a.asw + nl], asc, ash, a.tadd.relu);
-      float* op = a.out.p + (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh + (long long)ox * a.out.sw + nl;
+      if (a.add) val += nl_apply(addp[(unsigned)oy * (unsigned)a.ash + (unsigned)ox * (unsigned)a.asw], asc, ash, a.tadd.relu);
+      float* op = outp + ((unsigned)oy * (unsigned)a.out.sh + (unsigned)ox * (unsigned)a.out.sw);
       if (a.accumulate) val += *op;
       *op = val;
       ssum += val; ssq += val * val;
@@ -892,6 +904,7 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
   constexpr int TZ = 4, TY = 4, TX = 8;
   constexpr int BZ = (TZ - 1) * S + 3, BY = (TY - 1) * S + 3, BX = (TX - 1) * S + 3, BOX = BZ * BY * BX;
   __shared__ uint2 box[BOX];                       // 4 bf16 channels per voxel
+  __shared__ uint4 wlds[7 * NB * 64];              // the B fragments, [s2 * NB + nb][lane]
   __shared__ float red[2][4][32 * NB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -947,28 +960,33 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
       }
     }
   }
-  // ---- B fragments: k = s*16 + h*8 + e  <->  tap = s*4 + h*2 + (e >> 2), channel = e & 3; column = nb*32 + r
-  uint4 wfrag[7][NB];
+  // ---- B fragments: k = s*16 + h*8 + e  <->  tap = s*4 + h*2 + (e >> 2), channel = e & 3; column = nb*32 + r.
+  // The 7 x NB x 64 fragments are the same for the four waves: the workgroup builds each ONCE into LDS (<= 8 scalar loads per
+  // entry, two to four entries per thread instead of 56 / 112 loads per lane) and every lane reads its own 16 bytes back.
+  {
+    constexpr int NE = (7 * NB * 64 + 255) / 256;
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int col = nb * 32 + r;
-    const float* wp = a.w + min(col, a.Np - 1);
+    for (int q = 0; q < NE; ++q) {
+      const int fr = (tid >> 6) + 4 * q;                      // fragment s2 * NB + nb (wave-uniform)
+      if (fr < 7 * NB) {
+        const int s2 = fr / NB, nb = fr % NB;
+        const int col = nb * 32 + r;
+        const float* wp = a.w + min(col, a.Np - 1);
+        float wv[8];
 #pragma unroll
-    for (int s2 = 0; s2 < 7; ++s2) {
-      float wv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int tap = s2 * 4 + h * 2 + (e >> 2), c = e & 3;
-        const int tapc = tap < 27 ? tap : 26;
-        const float raw = c < KI ? wp[((long long)tapc * a.Kp + c) * a.Np] : 0.f;
-        wv[e] = (tap < 27 && c < KI && col < N) ? raw : 0.f;
+        for (int e = 0; e < 8; ++e) {
+          const int tap = s2 * 4 + h * 2 + (e >> 2), c = e & 3;
+          const int tapc = tap < 27 ? tap : 26;
+          const float raw = c < KI ? wp[(unsigned)(tapc * a.Kp + c) * (unsigned)a.Np] : 0.f;
+          wv[e] = (tap < 27 && c < KI && col < N) ? raw : 0.f;
+        }
+        uint4 pk;
+        pk.x = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[0], wv[1]}, bf16x2_t));
+        pk.y = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[2], wv[3]}, bf16x2_t));
+        pk.z = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[4], wv[5]}, bf16x2_t));
+        pk.w = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[6], wv[7]}, bf16x2_t));
+        wlds[fr * 64 + lane] = pk;
       }
-      uint4 pk;
-      pk.x = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[0], wv[1]}, bf16x2_t));
-      pk.y = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[2], wv[3]}, bf16x2_t));
-      pk.z = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[4], wv[5]}, bf16x2_t));
-      pk.w = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[6], wv[7]}, bf16x2_t));
-      wfrag[s2][nb] = pk;
     }
   }
   float bias[NB], asc[NB], ash[NB];
@@ -980,6 +998,11 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
     if (a.add) nl_coeff(a.tadd, n, N, col, asc[nb], ash[nb]);
   }
   __syncthreads();
+  uint4 wfrag[7][NB];
+#pragma unroll
+  for (int s2 = 0; s2 < 7; ++s2)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) wfrag[s2][nb] = wlds[(s2 * NB + nb) * 64 + lane];
   // ---- A fragments: MFMA row m = r  <->  voxel (zl = wave, yl = m / 8, xl = m % 8)
   ufloat16 acc[NB];
 #pragma unroll
