@@ -1273,7 +1273,8 @@ static int direct_variant(const mmtta_conv_desc* d, const mmtta_tensor* x) {
   int K, N;
   direct_dims(d, K, N);
   if (!aligned16(x) || (long long)x->w * x->sw * 4 >= (1LL << 31)) return 0;
-  if ((K == 32 || K == 64) && d->op == MMTTA_CONVT_FWD && d->ksize == 3 && d->stride == 2) return 3;
+  if ((K == 32 || K == 64) && d->op == MMTTA_CONVT_FWD && d->ksize == 3 && d->stride == 2 &&
+      (long long)x->d * x->sd < (1LL << 31)) return 3;       // 32-bit offsets inside a batch item
   if (K == 32 || K == 64) return 1;
   if (K <= 4 && d->stride == 1 && d->ksize == 3) return (d->dtype == MMTTA_BF16 && g_thin_mfma && N <= 4) ? 4 : 2;
   return 0;
@@ -1356,23 +1357,35 @@ __global__ __launch_bounds__(256) void upconv_mfma_kernel(DArgs a) {
     const int cg = tid % CG;
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (HAS_T) nl_coeff_vec<4>(a.tin, n, K, cg * 4, sc, sh);
+    // the four rows' offsets and validity are workgroup-uniform (scalar); a staged voxel adds its clamped x offset: 32-bit
+    // elements from the batch item (host-checked), no 64-bit vector arithmetic
     const long long inbo = (long long)n * a.in.sn + cg * 4;      // element offset (the input may be bf16-stored)
+    unsigned rowoff[4], rowok = 0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      const int iz = iz0 + (row >> 1), iy = iy0 + (row & 1);
+      rowoff[row] = (unsigned)min(iz, a.in.d - 1) * (unsigned)a.in.sd + (unsigned)min(iy, a.in.h - 1) * (unsigned)a.in.sh;
+      rowok |= (iz < a.in.d && iy < a.in.h ? 1u : 0u) << row;
+    }
+    const unsigned sw = (unsigned)a.in.sw;
     float4 raw[NIT];
+    unsigned okm = 0;
     MMTTA_BF_DISPATCH(a.in.bf, INBF, {
+      const float* inb = INBF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.in.p) + inbo) : a.in.p + inbo;
 _Pragma("unroll")
       for (int q = 0; q < NIT; ++q) {
         const int vs = min(tid / CG + q * (256 / CG), 4 * XV - 1);
         const int row = vs / XV, xl = vs % XV;
-        const int iz = min(iz0 + (row >> 1), a.in.d - 1), iy = min(iy0 + (row & 1), a.in.h - 1), ix = min(ix0 + xl, a.in.w - 1);
-        raw[q] = ld4_t<INBF>(a.in.p, inbo + (long long)iz * a.in.sd + (long long)iy * a.in.sh + (long long)ix * a.in.sw);
+        const unsigned ro = row == 0 ? rowoff[0] : row == 1 ? rowoff[1] : row == 2 ? rowoff[2] : rowoff[3];
+        okm |= (((rowok >> row) & 1u) != 0 && ix0 + xl < a.in.w ? 1u : 0u) << q;
+        raw[q] = ld4_t<INBF>(inb, (long long)(ro + (unsigned)min(ix0 + xl, a.in.w - 1) * sw));
       }
     });
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
       const int vs = tid / CG + q * (256 / CG);
       if (vs < 4 * XV) {
-        const int row = vs / XV, xl = vs % XV;
-        const bool ok = iz0 + (row >> 1) < a.in.d && iy0 + (row & 1) < a.in.h && ix0 + xl < a.in.w;
+        const bool ok = (okm >> q) & 1u;
         float4 v;
         v.x = ok ? (HAS_T ? nl_apply(raw[q].x, sc[0], sh[0], a.tin.relu) : raw[q].x) : 0.f;
         v.y = ok ? (HAS_T ? nl_apply(raw[q].y, sc[1], sh[1], a.tin.relu) : raw[q].y) : 0.f;

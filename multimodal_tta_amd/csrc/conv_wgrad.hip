@@ -1359,26 +1359,29 @@ struct W2Args {
   int bf;          // bf16 precision mode: operands rounded to bf16, 16 voxels per v_mfma_f32_32x32x16_bf16
 };
 
-template <bool PBF>
+// SI (gather stride) and T27 (27 taps / 1 tap) are template parameters: the box extents divide every staged voxel's index,
+// and a run-time divisor is a ~30-instruction division (36 of them per tile and thread before)
+template <bool PBF, int SI, bool T27>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
   extern __shared__ float lds[];
   constexpr int TZ = 4, TY = 4, TX = 8, MT = 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
-  const int ext = a.ntaps == 1 ? 0 : 2;
-  const int BZ = (TZ - 1) * a.si + ext + 1, BY = (TY - 1) * a.si + ext + 1, BX = (TX - 1) * a.si + ext + 1;
-  const int boxvox = BZ * BY * BX;
-  const int dmin = a.ntaps == 1 ? 0 : -1;
+  constexpr int NT = T27 ? 27 : 1;
+  constexpr int ext = T27 ? 2 : 0;
+  constexpr int BZ = (TZ - 1) * SI + ext + 1, BY = (TY - 1) * SI + ext + 1, BX = (TX - 1) * SI + ext + 1;
+  constexpr int boxvox = BZ * BY * BX;
+  constexpr int dmin = T27 ? -1 : 0;
   float* ql = lds;                  // [boxvox][4]
   float* pl = lds + boxvox * 4;     // [MT][32]
   const int cb0 = blockIdx.y * 32;
-  const int nrows = a.ntaps * a.Cs;
+  const int nrows = NT * a.Cs;
   const int rowid = wave * 32 + r;
   int toffl = 0;
   if (rowid < nrows) {
     const int tap = rowid / a.Cs, cs = rowid % a.Cs;
-    toffl = (a.ntaps == 1 ? 0 : (((tap / 9) * BY + ((tap / 3) % 3)) * BX + (tap % 3))) * 4 + cs;
+    toffl = (!T27 ? 0 : (((tap / 9) * BY + ((tap / 3) % 3)) * BX + (tap % 3))) * 4 + cs;
   }
   f32x16 acc;
 #pragma unroll
@@ -1390,7 +1393,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
   // Both operands 16-byte addressable (every layer of the shipped networks): the NEXT tile's global loads are issued
   // before this tile's MFMAs and land while they run (a workgroup walked load -> barrier -> MFMA -> barrier with one
   // workgroup per CU: every tile paid a full memory latency).  Otherwise the loads sit in the staging step itself.
-  constexpr int NQ = 6;                           // ceil(9*9*17 / 256): the stride-2 box is the largest
+  constexpr int NQ = (boxvox + 255) / 256;          // 6 for the stride-2 box (9 x 9 x 17)
   const bool piped = a.qvec4 && a.pvec4;
   float4 raw[NQ], praw[MT / 32];
   float qsc[4], qsh[4], psc[4], psh[4];
@@ -1408,7 +1411,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
   auto issue = [&](int tile) {
     int n, oz0, oy0, ox0;
     decode(tile, n, oz0, oy0, ox0);
-    const int iz0 = oz0 * a.si + dmin, iy0 = oy0 * a.si + dmin, ix0 = ox0 * a.si + dmin;
+    const int iz0 = oz0 * SI + dmin, iy0 = oy0 * SI + dmin, ix0 = ox0 * SI + dmin;
     const float* qb = a.q + (long long)n * a.qsn;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -1434,7 +1437,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
   auto commit = [&](int tile) {
     int n, oz0, oy0, ox0;
     decode(tile, n, oz0, oy0, ox0);
-    const int iz0 = oz0 * a.si + dmin, iy0 = oy0 * a.si + dmin, ix0 = ox0 * a.si + dmin;
+    const int iz0 = oz0 * SI + dmin, iy0 = oy0 * SI + dmin, ix0 = ox0 * SI + dmin;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int bv = tid + 256 * q;
@@ -1478,7 +1481,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
     const int tyi = t % a.ty;
     const int tzi = t / a.ty;
     const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
-    const int iz0 = oz0 * a.si + dmin, iy0 = oy0 * a.si + dmin, ix0 = ox0 * a.si + dmin;
+    const int iz0 = oz0 * SI + dmin, iy0 = oy0 * SI + dmin, ix0 = ox0 * SI + dmin;
     {  // Q box: up to 4 channels per voxel
       const float* qb = a.q + (long long)n * a.qsn;
       float sc[4], sh[4];
@@ -1572,12 +1575,12 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
     if (a.bf) {
       // k = h*8 + e of MFMA step kk is voxel 16*kk + 8*h + e: with TX = 8 that is the x-row e = 0..7 at
       // (yl, zl) = ((2*kk + h) % TY, (2*kk + h) / TY): 8 gathered values per operand, packed to bf16
-      const int xs = a.si * 4;
+      const int xs = SI * 4;
 #pragma unroll 2
       for (int kk = 0; kk < MT / 16; ++kk) {
         const int rowi = 2 * kk + h;
         const int yl = rowi % TY, zl = rowi / TY;
-        const float* qp = ql + (((zl * a.si) * BY + yl * a.si) * BX) * 4 + toffl;
+        const float* qp = ql + (((zl * SI) * BY + yl * SI) * BX) * 4 + toffl;
         const float* pp = pl + (rowi * 8) * 32 + r;
         float av[8], bv[8];
 #pragma unroll
@@ -1588,12 +1591,12 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
       }
     } else {
-    const float* qlane = ql + toffl + h * a.si * 4;
+    const float* qlane = ql + toffl + h * SI * 4;
     const float* plane = pl + h * 32 + r;
 #pragma unroll 8
     for (int kk = 0; kk < MT / 2; ++kk) {
       const int xl0 = (2 * kk) % TX, yl = ((2 * kk) / TX) % TY, zl = (2 * kk) / (TX * TY);
-      const int gaddr = (((zl * a.si) * BY + yl * a.si) * BX + xl0 * a.si) * 4;
+      const int gaddr = (((zl * SI) * BY + yl * SI) * BX + xl0 * SI) * 4;
       const float av = qlane[gaddr];
       const float b = plane[kk * 64];
       dbacc += b;
@@ -1671,12 +1674,24 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
   for (int i = 0; i < CS; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
   long long ufirst, ulast;
   unit_range(units, xcd_contiguous_id(blockIdx.x, gridDim.x), gridDim.x, ufirst, ulast);
-  for (long long u0 = ufirst + wave; u0 < ulast; u0 += 4) {
-    long long u = u0;
-    const int chunk = (int)(u % chunks); u /= chunks;
-    const int oy0 = 2 * (int)(u % hp); u /= hp;
-    const int oz = (int)(u % a.dy.d);
-    const int n = (int)(u / a.dy.d);
+  // the unit index is decoded ONCE (three 64-bit divisions) and then advanced by carries: all of it wave-uniform
+  int chunk, oyp, oz, n;
+  {
+    long long u = ufirst + wave;
+    chunk = (int)(u % chunks); u /= chunks;
+    oyp = (int)(u % hp); u /= hp;
+    oz = (int)(u % a.dy.d);
+    n = (int)(u / a.dy.d);
+  }
+  auto advance = [&]() {
+    chunk += 4;
+    while (chunk >= chunks) {
+      chunk -= chunks;
+      if (++oyp == hp) { oyp = 0; if (++oz == a.dy.d) { oz = 0; ++n; } }
+    }
+  };
+  for (long long u0 = ufirst + wave; u0 < ulast; u0 += 4, advance()) {
+    const int oy0 = 2 * oyp;
     const int iz = oz + kz - 1;
     if ((unsigned)iz >= (unsigned)a.x.d) continue;
     if (HAS_T && n != n_cached) {
@@ -2029,8 +2044,19 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
     const int ext = w.ntaps == 1 ? 0 : 2;
     const int BZ = 3 * w.si + ext + 1, BY = 3 * w.si + ext + 1, BX = 7 * w.si + ext + 1;
     const size_t lds = ((size_t)BZ * BY * BX * 4 + 128 * 32) * sizeof(float);
-    if (b.p_bf) hipLaunchKernelGGL(wgrad_small_kernel<true>, dim3(w.S, w.CDp / 32), dim3(256), lds, s, b);
-    else hipLaunchKernelGGL(wgrad_small_kernel<false>, dim3(w.S, w.CDp / 32), dim3(256), lds, s, b);
+    MMTTA_CHECK((w.ntaps == 27 && (w.si == 1 || w.si == 2)) || (w.ntaps == 1 && w.si == 1), MMTTA_ERR_UNSUPPORTED,
+                "wgrad (thin layer): %d taps with stride %d", w.ntaps, w.si);
+    const dim3 sg(w.S, w.CDp / 32);
+    if (w.ntaps == 1) {
+      if (b.p_bf) hipLaunchKernelGGL((wgrad_small_kernel<true, 1, false>), sg, dim3(256), lds, s, b);
+      else hipLaunchKernelGGL((wgrad_small_kernel<false, 1, false>), sg, dim3(256), lds, s, b);
+    } else if (w.si == 1) {
+      if (b.p_bf) hipLaunchKernelGGL((wgrad_small_kernel<true, 1, true>), sg, dim3(256), lds, s, b);
+      else hipLaunchKernelGGL((wgrad_small_kernel<false, 1, true>), sg, dim3(256), lds, s, b);
+    } else {
+      if (b.p_bf) hipLaunchKernelGGL((wgrad_small_kernel<true, 2, true>), sg, dim3(256), lds, s, b);
+      else hipLaunchKernelGGL((wgrad_small_kernel<false, 2, true>), sg, dim3(256), lds, s, b);
+    }
     st = launch_status("wgrad small");
     if (st || g_profile_main_only) return st;
     const int total = w.ntaps * b.Cs * b.Cb;
