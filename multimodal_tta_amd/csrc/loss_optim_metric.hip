@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void entropy_bernoulli_vec_kernel(TV z, TV dz,
   double acc = 0.0;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const long long n = i / dhw, v = i - n * dhw;
+    // one volume per launch in the adaptation loop: no 64-bit division per voxel then (uniform branch)
+    const long long n = z.n == 1 ? 0 : i / dhw, v = i - n * dhw;
     const float4 t4 = *reinterpret_cast<const float4*>(z.p + n * z.sn + v * 4);
     const float ts[4] = {t4.x, t4.y, t4.z, t4.w};
     float g[4] = {0.f, 0.f, 0.f, 0.f};

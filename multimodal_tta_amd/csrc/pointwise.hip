@@ -429,6 +429,77 @@ __global__ __launch_bounds__(256) void norm_bwd_apply8_kernel(Nb8Args a) {
   }
 }
 
+// ------------------------------------------------------------------ combine, 8 channels per thread
+// out = Ta(a) + Tb(b) for voxel-dense tensors of one storage type with C a power of two >= 8: the same arithmetic as
+// elementwise_kernel<0, ...>, a thread's 16 coefficient pairs computed once, IT voxels' loads issued before the first use.
+struct Cb8Args {
+  const float* a; const float* b; float* o;
+  long long asn, bsn, osn;
+  unsigned asw, bsw, osw;
+  int C;
+  unsigned dhw;
+  NL ta, tb;
+};
+
+template <bool BF, bool HASB, int IT>
+__global__ __launch_bounds__(256) void combine8_kernel(Cb8Args e) {
+  const int n = blockIdx.y;
+  const unsigned CG = (unsigned)e.C >> 3, nvl = 256u / CG;
+  const unsigned cg = threadIdx.x & (CG - 1), vl = threadIdx.x / CG;   // CG is a power of two
+  const unsigned c0 = cg * 8;
+  auto item = [&](const float* p, long long sn) {
+    return BF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p) + (long long)n * sn) : p + (long long)n * sn;
+  };
+  const float* ap = item(e.a, e.asn);
+  const float* bp = HASB ? item(e.b, e.bsn) : ap;
+  float* op = const_cast<float*>(item(e.o, e.osn));
+  const unsigned v0 = blockIdx.x * (nvl * IT) + vl;
+  Oct8<BF> ar[IT], br[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const unsigned v = min(v0 + i * nvl, e.dhw - 1);                   // clamped address, masked store
+    ar[i] = oct8_ld<BF>(ap, v * e.asw + c0, v * e.asw + c0 + 4);
+    if (HASB) br[i] = oct8_ld<BF>(bp, v * e.bsw + c0, v * e.bsw + c0 + 4);
+  }
+  float sa[8], ha[8], sb[8], hb[8];
+  nl_coeff_vec<8>(e.ta, n, e.C, (int)c0, sa, ha);
+  if (HASB) nl_coeff_vec<8>(e.tb, n, e.C, (int)c0, sb, hb);
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    float av[8], bv[8], ov[8];
+    oct8_f8(ar[i], av);
+    if (HASB) oct8_f8(br[i], bv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float r = nl_apply(av[j], sa[j], ha[j], e.ta.relu);
+      if (HASB) r += nl_apply(bv[j], sb[j], hb[j], e.tb.relu);
+      ov[j] = r;
+    }
+    const unsigned v = v0 + i * nvl;
+    if (v < e.dhw) {
+      if constexpr (BF) {
+        uint4 q;
+        q.x = f32x2_to_bf16x2(ov[0], ov[1]); q.y = f32x2_to_bf16x2(ov[2], ov[3]);
+        q.z = f32x2_to_bf16x2(ov[4], ov[5]); q.w = f32x2_to_bf16x2(ov[6], ov[7]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(op) + v * e.osw + c0) = q;
+      } else {
+        *reinterpret_cast<float4*>(op + v * e.osw + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        *reinterpret_cast<float4*>(op + v * e.osw + c0 + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+      }
+    }
+  }
+}
+
+template <bool BF, bool HASB>
+static void launch_combine8(const Cb8Args& q, int n, hipStream_t s) {
+  const long long nvl = 256 / (q.C / 8);
+  const bool four = q.dhw / (nvl * 4) >= 1024;
+  const long long per = nvl * (four ? 4 : 2);
+  const dim3 g8((unsigned)((q.dhw + per - 1) / per), (unsigned)n);
+  if (four) hipLaunchKernelGGL((combine8_kernel<BF, HASB, 4>), g8, dim3(256), 0, s, q);
+  else hipLaunchKernelGGL((combine8_kernel<BF, HASB, 2>), g8, dim3(256), 0, s, q);
+}
+
 // ------------------------------------------------------------------ linear combination
 struct LinArgs {
   TV in[8];
@@ -724,6 +795,27 @@ extern "C" int mmtta_combine(const mmtta_tensor* a, const mmtta_norm_on_load* ta
   MMTTA_CHECK((abf == bbf && bbf == obf), MMTTA_ERR_UNSUPPORTED, "combine: operands must share one storage type");
   const dim3 grid(grid_for(total));
   hipStream_t s = (hipStream_t)stream;
+  {
+    // octet form: C a power of two in [8, 2048], voxel-dense tensors, 16-byte aligned octets, 32-bit offsets inside an item
+    const int C = out->c;
+    const long long dhw = (long long)out->d * out->h * out->w;
+    auto dense = [](const mmtta_tensor* t) { return t->sh == (int64_t)t->w * t->sw && t->sd == (int64_t)t->h * t->sh; };
+    const int per = abf ? 8 : 4;
+    auto al = [per](const mmtta_tensor* t) { return ((uintptr_t)t->ptr) % 16 == 0 && t->sw % per == 0 && t->sn % per == 0; };
+    const bool pow2 = C >= 8 && C <= 2048 && (C & (C - 1)) == 0;
+    const bool ok8 = v4 && pow2 && dense(a) && dense(out) && al(a) && al(out) && (!b || (dense(b) && al(b))) &&
+                     dhw * std::max(std::max(a->sw, out->sw), b ? b->sw : (int64_t)0) < (1LL << 31);
+    if (ok8) {
+      Cb8Args q;
+      q.a = (const float*)a->ptr; q.b = b ? (const float*)b->ptr : nullptr; q.o = (float*)out->ptr;
+      q.asn = a->sn; q.bsn = b ? b->sn : 0; q.osn = out->sn;
+      q.asw = (unsigned)a->sw; q.bsw = b ? (unsigned)b->sw : 0u; q.osw = (unsigned)out->sw;
+      q.C = C; q.dhw = (unsigned)dhw; q.ta = e.ta; q.tb = e.tb;
+      if (abf) { if (b) launch_combine8<true, true>(q, out->n, s); else launch_combine8<true, false>(q, out->n, s); }
+      else { if (b) launch_combine8<false, true>(q, out->n, s); else launch_combine8<false, false>(q, out->n, s); }
+      return launch_status("combine");
+    }
+  }
   if (abf) {
     if (v4) hipLaunchKernelGGL((elementwise_kernel<0, 4, true, true, true>), grid, dim3(256), 0, s, e);
     else hipLaunchKernelGGL((elementwise_kernel<0, 1, true, true, true>), grid, dim3(256), 0, s, e);
