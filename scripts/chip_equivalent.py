@@ -26,7 +26,7 @@ def family(k):
         return "thin full-resolution layers"
     if k.startswith(("splitk", "instance", "channel_reduce", "stats", "db_reduce", "slab")):
         return "split-K finalize, statistics, reductions"
-    if k.startswith("elementwise"):
+    if k.startswith(("elementwise", "norm_bwd_apply8", "combine8")):
         return "norm backward / residual adds"
     return "optimizer, repack, loss, copies"
 

@@ -28,7 +28,7 @@ def fam(k):
         return "thin full-resolution layers (<= 4 channels on one side)"
     if k.startswith(("splitk", "instance_stats", "channel_reduce", "stats_", "bwd_finalize", "rows_reduce")):
         return "split-K finalize, statistics, reductions"
-    if k.startswith("elementwise"):
+    if k.startswith(("elementwise", "norm_bwd_apply8", "combine8")):
         return "norm backward / residual adds (elementwise)"
     return "optimizer, repack, loss, copies"
 
