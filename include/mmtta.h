@@ -132,11 +132,13 @@ int mmtta_abi_version(void);
  * class summed before the channel stages instead of after: equal to the per-class kernel within fp32 summation order.
  * Changes the statistics rows a convolution writes (mmtta_conv_plan reports them): set before planning. */
 #define MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS 12
-/* 1 (default): in bf16 precision the 3x3x3 stride-1 convolutions with <= 4 channels on both sides (forward and input
+/* 1 / 2 (default) / 3: in bf16 precision the 3x3x3 stride-1 convolutions with <= 4 channels on both sides (forward and input
  * gradient of the U-Net's last residual unit) run on v_mfma_f32_4x4x4_16B_bf16 (operands rounded to bf16 like every other
  * matrix-core layer of that mode, one instruction per tap and 64 voxels); 0: fp32 FMAs on the vector ALU
  * (direct_row_kernel), as in fp32 precision.  Measured round 2 (3 -> 3 at 128^3): 33 us against 43 us per launch, +0.5 to
  * +1 % volumes/s; full-size parity against the fp32 oracle unchanged (logits 1.496e-2 vs 1.494e-2 of max, Dice 6e-5).
+ * The value picks the workgroup tile: 1 = 8 x 8 x 64 voxels (two workgroups per CU), 2 = 4 x 8 x 64 (four per CU: another
+ * workgroup's MFMAs cover a workgroup's staging; same-box A/B 64.1 against 63.7 volumes/s), 3 = 2 x 8 x 64.
  * Changes the statistics rows such a convolution writes: set before planning. */
 #define MMTTA_OPT_THIN_MFMA 13
 int mmtta_set_option(int key, int value);

@@ -18,7 +18,7 @@ void* g_ws_debug = nullptr;
 int g_epilogue_vec = 1;
 int g_igemm_lean = 0;
 int g_cls_fused_min = 128;
-int g_thin_mfma = 1;
+int g_thin_mfma = 2;
 int g_wgrad_vec = 1;
 // split-K below / target, weight-gradient workgroups, thin-layer slabs.  Swept with the lanes bound to their own hardware
 // queues (profiles/r02_tuning_sweep.txt): four volumes in flight want half the splitting two did (96/128, 128 slabs)
@@ -49,7 +49,7 @@ extern "C" int mmtta_set_option(int key, int value) {
   }
   if (key == MMTTA_OPT_THIN_MFMA) {
     const int prev = mmtta::g_thin_mfma;
-    mmtta::g_thin_mfma = value ? 1 : 0;
+    mmtta::g_thin_mfma = value < 0 ? 0 : (value > 3 ? 3 : value);
     return prev;
   }
   if (key == MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS) {

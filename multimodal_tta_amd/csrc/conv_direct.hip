@@ -477,12 +477,12 @@ __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
 typedef short cs4 __attribute__((ext_vector_type(4)));
 typedef float cf4v __attribute__((ext_vector_type(4)));
 
-template <bool HAS_T>
+template <bool HAS_T, int TZ>
 __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
   // 8 x 8 x 64 tile: the halo box is 1.6x the tile.  The box rows are padded to 68 voxels so that a staging item is a run
   // of 4 voxels along x (one decode, one row address, four 16-byte loads): phase timing of the first version showed 26 of
   // its 44 us in per-voxel index / address arithmetic and in 108 scalar weight loads per lane, not in loads or MFMAs.
-  constexpr int TZ = 8, TY = 8, TX = 64, BZ = TZ + 2, BY = TY + 2, BX = 68, RUNS = BX / 4, NRUN = BZ * BY * RUNS;
+  constexpr int TY = 8, TX = 64, BZ = TZ + 2, BY = TY + 2, BX = 68, RUNS = BX / 4, NRUN = BZ * BY * RUNS;
   __shared__ uint2 box[BZ * BY * BX];
   __shared__ uint2 wtab[27 * 4];                // [tap][column] x 4 k values (bf16)
   __shared__ float red[32];
@@ -574,9 +574,38 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
     xoff_o[r] = (unsigned)min(ox, a.out.w - 1) * (unsigned)a.out.sw;
     xoff_a[r] = (unsigned)min(ox, a.out.w - 1) * (unsigned)a.asw;
   }
+  // the fused-add / accumulate operands of trip rp + 1 are requested before the MFMAs of trip rp: behind the MFMA loop
+  // every trip waited a full memory latency for them (both 3 -> 3 launches of a step carry the residual add)
+  float addn[2][4], oldn[2][4];
+  auto fetch = [&](int rp) {
+    const int r0 = rp * 8 + wave * 2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int oz = min(oz0 + (r0 + q) / TY, a.out.d - 1), oy = min(oy0 + (r0 + q) % TY, a.out.h - 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { addn[q][r] = 0.f; oldn[q][r] = 0.f; }
+      if (a.add) {
+        const float* ap = a.add + (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) addn[q][r] = ap[xoff_a[r] + jl];
+      }
+      if (a.accumulate) {
+        const float* op = a.out.p + (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oldn[q][r] = op[xoff_o[r] + jl];
+      }
+    }
+  };
+  fetch(0);
 #pragma unroll 1
   for (int rp = 0; rp < TZ * TY / 8; ++rp) {    // two rows of the tile per wave and trip (independent accumulator chains)
     const int r0 = rp * 8 + wave * 2;
+    float addc[2][4], oldc[2][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { addc[q][r] = addn[q][r]; oldc[q][r] = oldn[q][r]; }
+    if (rp + 1 < TZ * TY / 8) fetch(rp + 1);
     cf4v acc[2];
     const uint2* ab[2];
 #pragma unroll
@@ -600,22 +629,11 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
       const int oz = oz0 + (r0 + q) / TY, oy = oy0 + (r0 + q) % TY;
       const bool rowok = oz < a.out.d && oy < a.out.h;
       float* orow = a.out.p + (long long)n * a.out.sn + (long long)min(oz, a.out.d - 1) * a.out.sd + (long long)min(oy, a.out.h - 1) * a.out.sh;
-      const float* arow_p = a.add ? a.add + (long long)n * a.asn + (long long)min(oz, a.out.d - 1) * a.asd + (long long)min(oy, a.out.h - 1) * a.ash
-                                  : nullptr;
-      float addv[4] = {0.f, 0.f, 0.f, 0.f}, oldv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.add) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) addv[r] = arow_p[xoff_a[r] + jl];
-      }
-      if (a.accumulate) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oldv[r] = orow[xoff_o[r] + jl];
-      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[q][r] + bias;
-        if (a.add) v += nl_apply(addv[r], asc, ash, a.tadd.relu);
-        if (a.accumulate) v += oldv[r];
+        if (a.add) v += nl_apply(addc[q][r], asc, ash, a.tadd.relu);
+        if (a.accumulate) v += oldc[q][r];
         if (rowok && ((xok >> r) & 1u)) {
           if (jc < a.N) {
             orow[xoff_o[r] + jc] = v;
@@ -1296,7 +1314,10 @@ int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const m
     return (int)((dhw + 255) / 256);
   }
   if (v == 3) return x->d * x->h * ((x->w + 63) / 64);       // one workgroup per (input row pair, 64-voxel chunk)
-  if (v == 4) return ((y->d + 7) / 8) * ((y->h + 7) / 8) * ((y->w + 63) / 64);     // one workgroup per 8 x 8 x 64 tile
+  if (v == 4) {                                    // one workgroup per TZ x 8 x 64 tile (MMTTA_OPT_THIN_MFMA = 2: TZ = 4)
+    const int tz = g_thin_mfma == 3 ? 2 : g_thin_mfma == 2 ? 4 : 8;
+    return ((y->d + tz - 1) / tz) * ((y->h + 7) / 8) * ((y->w + 63) / 64);
+  }
   // grid-stride kernels: enough workgroups to fill the chip a few times over, never more than the work
   const long long want = (direct_units(d, v, y) + 3) / 4;
   const long long cap = v == 1 ? 1024 : 2048;
@@ -1582,8 +1603,16 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   }
   if (variant == 4) {
     const dim3 grid(a.blocks_per_n, y->n), block(256);
-    if (has_t) hipLaunchKernelGGL(conv3_mfma4_kernel<true>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(conv3_mfma4_kernel<false>, grid, block, 0, stream, a);
+    if (g_thin_mfma == 3) {
+      if (has_t) hipLaunchKernelGGL((conv3_mfma4_kernel<true, 2>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((conv3_mfma4_kernel<false, 2>), grid, block, 0, stream, a);
+    } else if (g_thin_mfma == 2) {
+      if (has_t) hipLaunchKernelGGL((conv3_mfma4_kernel<true, 4>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((conv3_mfma4_kernel<false, 4>), grid, block, 0, stream, a);
+    } else {
+      if (has_t) hipLaunchKernelGGL((conv3_mfma4_kernel<true, 8>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((conv3_mfma4_kernel<false, 8>), grid, block, 0, stream, a);
+    }
     return launch_status("direct conv (4x4x4 matrix tiles)");
   }
   if (variant == 3) {

@@ -80,10 +80,16 @@ def main():
     ap.add_argument("--volumes", type=int, default=8)
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--quick", action="store_true", help="the neighbourhood of the current defaults only")
+    ap.add_argument("--around", action="store_true", help="the current defaults and one knob moved at a time")
     a = ap.parse_args()
     if a.quick:
         SETTINGS[:] = [dict(splitk_below=b, splitk_target=t, wgrad_workgroups=w, wgrad_thin_slabs=th)
                        for (b, t) in ((96, 128), (192, 256)) for (w, th) in ((128, 256), (256, 256), (192, 256), (128, 128), (96, 256))]
+    if a.around:
+        base = dict(splitk_below=96, splitk_target=128, wgrad_workgroups=128, wgrad_thin_slabs=256)
+        SETTINGS[:] = [base] + [dict(base, **d) for d in (
+            dict(wgrad_thin_slabs=384), dict(wgrad_thin_slabs=512), dict(wgrad_workgroups=96), dict(wgrad_workgroups=160),
+            dict(splitk_below=64, splitk_target=96), dict(splitk_below=128, splitk_target=160))]
     for rep in range(a.repeat):
         for lanes in a.lanes:
             for s in SETTINGS:

@@ -593,7 +593,7 @@ def test_thin_conv_on_matrix_tiles_matches_the_vector_kernel(case):
     mr, rr = stats_of(r)
     gy = torch.randn(n, cout, d, h, w)
     outs = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2, 3):                     # vector kernel; 8 / 4 / 2 x 8 x 64 workgroup tiles of the matrix-tile kernel
         prev = ops.set_option(13, mode)
         try:
             op = ops.ConvOp(cin, cout, 3, 1, False, "cuda", dtype=ops.BF16)
@@ -615,6 +615,9 @@ def test_thin_conv_on_matrix_tiles_matches_the_vector_kernel(case):
     assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-2 * ys, "forward differs from the vector kernel"
     assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-2 * gs, "input gradient differs from the vector kernel"
     assert torch.allclose(outs[0][2], outs[1][2], rtol=2e-2, atol=2e-2 * max(1.0, outs[0][2].abs().max().item()))
+    for mode in (2, 3):                           # the tile height changes which workgroup computes a voxel, not its value
+        assert torch.equal(outs[mode][0], outs[1][0]) and torch.equal(outs[mode][1], outs[1][1]), f"tile mode {mode}"
+        assert torch.allclose(outs[mode][2], outs[1][2], rtol=1e-5, atol=1e-5 * max(1.0, outs[1][2].abs().max().item()))
     y_ref = mod(F.relu(F.instance_norm(x))) + F.relu(F.instance_norm(r))
     assert (outs[1][0] - y_ref.detach()).abs().max().item() <= 1.5e-2 * y_ref.abs().max().item()
 
