@@ -113,7 +113,12 @@ int mmtta_abi_version(void);
 /* 1 (default): implicit-GEMM epilogues store 16 bytes per lane through an LDS transposition (same values; the
  * statistics rows sum in a different order); 0: four-byte stores straight from the accumulators (round 1). */
 #define MMTTA_OPT_EPILOGUE_VEC16 9
-/* 1: the 32-output-channel stride-1 layers (64^3 level) use the lean 4x8x8 tile at four workgroups per CU. */
+/* 1 (default): the 32-output-channel stride-1 layers of bf16 precision (the 64^3 level of the U-Net) use the lean 4x8x8
+ * tile (two row blocks per wave: half the accumulator registers, twice the workgroups: 1024 at 64^3, three to four per CU,
+ * so that another workgroup's MFMAs cover a workgroup's staging); 0: the 8x8x8 tile (512 workgroups, two per CU).  Same
+ * products in the same order: outputs equal bit for bit, the statistics rows are per tile.  Measured: neutral when the
+ * implicit GEMM staged one item per trip (r02c), +1.2 % volumes/s with the row loaders (same-box A/B 65.2 against 64.4).
+ * Changes the statistics rows a convolution writes: set before planning. */
 #define MMTTA_OPT_IGEMM_LEAN 10
 /* Kernel of the bf16-operand 27-tap weight gradient (csrc/conv_wgrad.hip):
  *   1  (default; 3 is a synonym) the transposed-read kernel for every operand pair that admits its 16-byte items

@@ -16,7 +16,7 @@ int g_igemm_ws = 0;
 int g_ws_workgroups = 256;
 void* g_ws_debug = nullptr;
 int g_epilogue_vec = 1;
-int g_igemm_lean = 0;
+int g_igemm_lean = 1;
 int g_cls_fused_min = 128;
 int g_thin_mfma = 2;
 int g_wgrad_vec = 1;
@@ -59,7 +59,7 @@ extern "C" int mmtta_set_option(int key, int value) {
   }
   if (key == MMTTA_OPT_IGEMM_LEAN) {
     const int prev = mmtta::g_igemm_lean;
-    mmtta::g_igemm_lean = value ? 1 : 0;
+    mmtta::g_igemm_lean = value < 0 ? 0 : (value > 2 ? 2 : value);
     return prev;
   }
   if (key == MMTTA_OPT_EPILOGUE_VEC16) {

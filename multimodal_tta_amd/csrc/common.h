@@ -272,10 +272,21 @@ __device__ __forceinline__ void unit_range(long long units, unsigned lb, unsigne
   last = first + per < units ? first + per : units;
 }
 
+// Sum over the 64 lanes, returned to every lane.  Six DPP adds (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then
+// row_bcast 15 and 31 across rows: the total lands in lane 63) and one readlane, instead of six ds_bpermute round trips
+// through the LDS crossbar: the tiny weight gradient reduces 84 values per wave (a quarter of its vector instructions).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  auto step = [](float x, auto ctrl, auto rmask) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
+    return x + __builtin_bit_cast(float, moved);
+  };
+  v = step(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});   // row_shr:1
+  v = step(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});   // row_shr:2
+  v = step(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});   // row_shr:4
+  v = step(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8 -> lane 15 of a row = row total
+  v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1, 3
+  v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

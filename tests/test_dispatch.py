@@ -2,7 +2,9 @@
 parity cases (tests/test_hip_conv.py::CASES / BF16_CASES) - asserted through the planner the launches themselves use
 (``mmtta_conv_plan`` / ``mmtta_conv_wgrad_kernel`` are host-only, so this runs without a GPU too).
 
-config ids: csrc/conv_igemm.hip::config_id (0-5 fp32 igemm, 6 direct, 7-12 bf16 igemm, 13 channel kernel);
+config ids: csrc/conv_igemm.hip::config_id (0-5 fp32 igemm, 6 direct, 7-12 bf16 igemm, 13 channel kernel, 14 the lean 4x8x8 tile
+of the 32-output-channel bf16 layers: the default, id 7 = the 8x8x8 tile under MMTTA_OPT_IGEMM_LEAN = 0, parity case
+test_lean_tile_matches_the_wide_tile; 15 class-fused);
 weight-gradient ids: mmtta_conv_wgrad_kernel (0 f32 s1, 1 f32 s2, 2 1x1, 3 small-channel, 4 bf16 s1, 5 bf16 s2, 6 tiny,
 7 / 8 transposed-read bf16 s1 / s2: the default of bf16 precision, parity cases test_transposed_read_wgrad; 4 / 5 under option 11 = 0;
 9 the 1x1x1 streaming kernel of bf16 precision, parity cases test_pointwise_conv_weight_gradient_on_transposed_reads).
@@ -15,11 +17,11 @@ from test_hip_conv import BF16_CASES, CASES, TR_CASES
 
 # (case, (fwd, dgrad) config in fp32 mode, the same in bf16 mode, weight-gradient kernel (fp32 mode, bf16 mode))
 DISPATCH = [
-    ((32, 32, 3, 1, False, (1, 16, 16, 16)), (0, 0), (7, 7), (0, 7)),
+    ((32, 32, 3, 1, False, (1, 16, 16, 16)), (0, 0), (14, 14), (0, 7)),
     ((64, 64, 3, 1, False, (1, 8, 8, 8)), (1, 1), (8, 8), (0, 7)),
     ((128, 128, 3, 1, False, (1, 32, 32, 32)), (2, 2), (9, 9), (0, 7)),
-    ((16, 32, 3, 2, False, (1, 8, 8, 8)), (3, 0), (10, 7), (1, 8)),
-    ((32, 64, 3, 2, False, (1, 8, 8, 16)), (4, 0), (11, 7), (1, 8)),
+    ((16, 32, 3, 2, False, (1, 8, 8, 8)), (3, 0), (10, 14), (1, 8)),
+    ((32, 64, 3, 2, False, (1, 8, 8, 16)), (4, 0), (11, 14), (1, 8)),
     ((64, 128, 3, 2, False, (1, 5, 6, 7)), (5, 1), (12, 8), (1, 8)),
     ((128, 136, 3, 1, False, (2, 4, 6, 8)), (5, 5), (12, 12), (0, 7)),
     ((768, 128, 3, 2, True, (1, 8, 8, 8)), (2, 5), (9, 12), (1, 8)),
@@ -75,6 +77,16 @@ def test_every_kernel_instantiation_is_reached_by_a_parity_case():
             assert kid == wg, f"{case} dtype {dtype}: weight-gradient kernel {kid}, expected {wg}"
             seen_cfg.update(got)
             seen_wg.add(kid)
+            if dtype == BF16 and 14 in got:                # the 8x8x8 tile (id 7) stays reachable: MMTTA_OPT_IGEMM_LEAN = 0
+                prev = lib.mmtta_set_option(10, 0)
+                try:
+                    for op, a, b, g in ((fo, tx, ty, got[0]), (do, ty, tx, got[1])):
+                        dsc0, plan0 = ConvDesc(op, k, stride, cin, cout, dtype), ConvPlan()
+                        assert lib.mmtta_conv_plan(C.byref(dsc0), C.byref(a), C.byref(b), C.byref(plan0)) == 0
+                        assert int(plan0.config) == (7 if g == 14 else g), f"{case}: option 10 = 0 plans {int(plan0.config)}"
+                        seen_cfg.add(int(plan0.config))
+                finally:
+                    lib.mmtta_set_option(10, prev)
             if dtype == BF16 and wg in (7, 8):
                 assert case in TR_CASES, f"{case}: transposed-read instantiation without a parity case"
                 # the same layer with its module input bf16-stored (method.storage: bf16): the same kernel
@@ -88,7 +100,7 @@ def test_every_kernel_instantiation_is_reached_by_a_parity_case():
                     lib.mmtta_set_option(11, prev)
                 assert kid0 == wg - 3, f"{case} option 0: weight-gradient kernel {kid0}, expected {wg - 3}"
                 seen_wg.add(kid0)
-    assert seen_cfg == set(range(14)), f"conv configs without a parity case: {sorted(set(range(14)) - seen_cfg)}"
+    assert seen_cfg == set(range(15)), f"conv configs without a parity case: {sorted(set(range(15)) - seen_cfg)}"
     assert seen_wg == set(range(10)), f"weight-gradient kernels without a parity case: {sorted(set(range(10)) - seen_wg)}"
     assert {2, 9} <= splitk_wide, "the 32-channel-stage igemm also needs a split-K parity case"
 
@@ -103,7 +115,7 @@ def test_class_fused_kernel_is_planned_for_large_stride2_forms():
 
     lib = _lib.load()
     for (cin, cout, transposed, coarse, want) in ((128, 32, True, (32, 32, 32), 15), (32, 64, False, (32, 32, 32), 15),
-                                                  (128, 32, True, (8, 8, 8), 7), (768, 128, True, (8, 8, 8), 9)):
+                                                  (128, 32, True, (8, 8, 8), 14), (768, 128, True, (8, 8, 8), 9)):
         d, h, w = coarse
         lo, hi = _cl(1, d, h, w, cin if transposed else cout), _cl(1, 2 * d, 2 * h, 2 * w, cout if transposed else cin)
         op = CONVT_FWD if transposed else CONV_DGRAD          # both read the coarse tensor and write the fine one

@@ -514,6 +514,59 @@ def test_row_loader_matches_the_generic_loader(case, stored):
 
 
 @pytest.mark.parametrize("stored", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(32, 32, 3, 1, False, (1, 16, 16, 16)), (33, 32, 3, 1, False, (1, 8, 8, 16)),
+                                  (16, 32, 3, 2, False, (1, 8, 8, 8)), (32, 64, 3, 2, False, (1, 8, 8, 16)),
+                                  (128, 32, 3, 2, True, (1, 4, 4, 4)), (32, 32, 1, 1, False, (1, 9, 10, 11))])
+def test_lean_tile_matches_the_wide_tile(case, stored):
+    """MMTTA_OPT_IGEMM_LEAN: the 32-output-channel stride-1 forms of bf16 precision on the 4x8x8 tile (config 14, the
+    default) against the 8x8x8 tile (config 7, option 10 = 0): forward with norm-on-load + ReLU and input gradient (the
+    stride-2 layers reach it through their per-class input gradient / transposed forward) - the same products in the
+    same order (up to the split of the reduction on small grids); the statistics rows are per tile and are compared as sums."""
+    from multimodal_tta_amd import ops
+
+    cin, cout, k, stride, transposed, shape = case
+    n, d, h, w = shape
+    torch.manual_seed(13)
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = (torch.randn(n, cin, d, h, w) * 2 + 0.5).to(torch.bfloat16).float()
+    mu = x.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    outs, cfgs = {}, {}
+    for mode in (0, 1):
+        prev = ops.set_option(10, mode)
+        prev_cls = ops.set_option(12, 0)          # per-class launches of the stride-2 forms (the class-fused kernel has its own tile)
+        try:
+            op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+            op.pack(mod.weight.detach().cuda().contiguous())
+            x_cl = cl_bf16(x) if stored == "bf16" else cl(x)
+            if stored == "bf16":
+                y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda", ldc=ops.row_pad(cout, torch.bfloat16), dtype=torch.bfloat16)
+            else:
+                y_cl = ops.new_cl(*op.out_shape(x_cl)[:4], cout, "cuda")
+            rows = op.stats_rows(x_cl, y_cl)
+            stats = torch.zeros((rows, 2, cout), device="cuda")
+            op.forward(x_cl, nl, mod.bias.detach().cuda(), y_cl, stats=stats)
+            gy_cl = cl(torch.randn(n, cout, *y_cl.shape[1:4], generator=torch.Generator().manual_seed(5)))
+            dx_cl = ops.new_cl(n, d, h, w, cin, "cuda")
+            op.dgrad(gy_cl, dx_cl)
+            torch.cuda.synchronize()
+            cfgs[mode] = (int(op.plan(op.d_fwd, x_cl, y_cl).config), int(op.plan(op.d_dgrad, gy_cl, dx_cl).config))
+            outs[mode] = (y_cl.clone(), dx_cl.clone(), stats.double().sum(0).cpu())
+        finally:
+            ops.set_option(12, prev_cls)
+            ops.set_option(10, prev)
+    assert 14 in cfgs[1] and 14 not in cfgs[0] and 7 in cfgs[0], f"plans {cfgs}"
+    assert torch.isfinite(outs[1][0].float()).all()
+    # twice the tiles can mean another split of the reduction (split-K below 96 workgroups): fp32 summation order only
+    tol = 1e-2 if stored == "bf16" else 1e-4
+    for i, what in ((0, "forward"), (1, "input gradient")):
+        a, b = outs[0][i].float(), outs[1][i].float()
+        assert (a - b).abs().max().item() <= (tol if i == 0 else 1e-4) * a.abs().max().item(), f"{what} differs"
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-3, atol=1e-2), "statistics sums differ"
+
+
+@pytest.mark.parametrize("stored", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(64, 32, 3, 2, True, (1, 4, 4, 8)), (768, 128, 3, 2, True, (1, 8, 8, 8)),
                                   (128, 32, 3, 2, True, (2, 5, 6, 7)), (32, 64, 3, 2, False, (1, 8, 8, 16)),
                                   (64, 128, 3, 2, False, (1, 5, 6, 7)), (40, 72, 3, 2, True, (1, 3, 5, 9))])
