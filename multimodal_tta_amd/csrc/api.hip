@@ -59,7 +59,7 @@ extern "C" int mmtta_set_option(int key, int value) {
   }
   if (key == MMTTA_OPT_IGEMM_LEAN) {
     const int prev = mmtta::g_igemm_lean;
-    mmtta::g_igemm_lean = value < 0 ? 0 : (value > 2 ? 2 : value);
+    mmtta::g_igemm_lean = value ? 1 : 0;
     return prev;
   }
   if (key == MMTTA_OPT_EPILOGUE_VEC16) {
