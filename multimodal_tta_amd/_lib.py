@@ -107,6 +107,8 @@ _SIGNATURES = {
                                           C.c_int, C.c_void_p, C.c_void_p]),
     "mmtta_norm_bwd_apply": (C.c_int, [_P(Tensor), _P(Tensor), _P(NormOnLoad), C.c_void_p, C.c_void_p, _P(Tensor),
                                        C.c_void_p]),
+    "mmtta_norm_bwd_small_ok": (C.c_int, [_P(Tensor), _P(Tensor), _P(NormOnLoad), _P(Tensor)]),
+    "mmtta_norm_bwd_small": (C.c_int, [_P(Tensor), _P(Tensor), _P(NormOnLoad), C.c_int64, _P(Tensor), C.c_void_p]),
     "mmtta_upsample2x_fwd": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p]),
     "mmtta_upsample2x_bwd": (C.c_int, [_P(Tensor), _P(Tensor), C.c_int, C.c_void_p]),
     "mmtta_lincomb": (C.c_int, [C.c_int, _P(_P(Tensor)), _P(C.c_float), _P(Tensor), C.c_int, C.c_void_p]),

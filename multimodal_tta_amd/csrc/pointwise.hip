@@ -429,6 +429,127 @@ __global__ __launch_bounds__(256) void norm_bwd_apply8_kernel(Nb8Args a) {
   }
 }
 
+// ------------------------------------------------------------------ whole instance-norm backward of a small tensor
+// The deep levels (<= 16^3 voxels) ran reduce -> finalize -> apply as three launches of a few microseconds each, all of
+// them launch latency.  Here one workgroup owns 32 channels of one batch item: pass 1 sums dz and dz * xhat over all
+// voxels (a thread keeps one channel octet, 64 voxel lanes), the 64 partials of a channel are added in a fixed order
+// in fp64 (like instance_bwd_kernel), pass 2 re-reads the two tensors (L2 hits) and writes dy.  No affine gradients.
+struct NbsArgs {
+  const float* dout; const float* y; float* o;
+  long long dsn, ysn, osn;
+  unsigned dsw, ysw, osw;
+  int C, relu;
+  unsigned dhw;
+  double count;
+  const float* mean; const float* rstd; const float* gamma; const float* beta;
+};
+
+template <bool YBF>
+__global__ __launch_bounds__(256) void norm_bwd_small_kernel(NbsArgs a) {
+  __shared__ float part[2][8][256];
+  __shared__ float mm[2][32];
+  const int n = blockIdx.y;
+  const unsigned cg = threadIdx.x & 3, vl = threadIdx.x >> 2;
+  const unsigned c0 = blockIdx.x * 32 + cg * 8;
+  const float* dp = a.dout + (long long)n * a.dsn;
+  const float* yp = YBF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.y) + (long long)n * a.ysn)
+                        : a.y + (long long)n * a.ysn;
+  float* op = a.o + (long long)n * a.osn;
+  float mu[8], rs[8], g[8], bt[8];
+  {
+    const unsigned pc = (unsigned)n * a.C + c0;
+    auto ld8 = [](const float* p, unsigned off, float (&r)[8]) {
+      const float4 lo = *reinterpret_cast<const float4*>(p + off), hi = *reinterpret_cast<const float4*>(p + off + 4);
+      r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = hi.w;
+    };
+    ld8(a.mean, pc, mu); ld8(a.rstd, pc, rs);
+    if (a.gamma) ld8(a.gamma, c0, g);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = 1.f;
+    }
+    if (a.beta) ld8(a.beta, c0, bt);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bt[j] = 0.f;
+    }
+  }
+  constexpr int IT = 2;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+  for (unsigned vb = vl; vb < a.dhw; vb += 64 * IT) {
+    Oct8<YBF> yr[IT];
+    float4 d0[IT], d1[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const unsigned v = min(vb + 64 * i, a.dhw - 1);
+      yr[i] = oct8_ld<YBF>(yp, v * a.ysw + c0, v * a.ysw + c0 + 4);
+      d0[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0);
+      d1[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0 + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      float yv[8];
+      oct8_f8(yr[i], yv);
+      const float dv[8] = {d0[i].x, d0[i].y, d0[i].z, d0[i].w, d1[i].x, d1[i].y, d1[i].z, d1[i].w};
+      const bool live = vb + 64 * i < a.dhw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xhat = (yv[j] - mu[j]) * rs[j];
+        float dz = live ? dv[j] : 0.f;
+        if (a.relu && !(fmaf(g[j], xhat, bt[j]) > 0.f)) dz = 0.f;
+        s0[j] += dz;
+        s1[j] += dz * xhat;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { part[0][j][threadIdx.x] = s0[j]; part[1][j][threadIdx.x] = s1[j]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {                        // thread -> (k, octet, j): the 64 voxel-lane partials of one channel
+    const int k = threadIdx.x >> 5, q = (threadIdx.x >> 3) & 3, j = threadIdx.x & 7;
+    double t = 0.0;
+    for (int l = 0; l < 64; ++l) t += (double)part[k][j][l * 4 + q];
+    const int c = blockIdx.x * 32 + q * 8 + j;
+    const double gm = a.gamma ? (double)a.gamma[c] : 1.0;
+    mm[k][q * 8 + j] = (float)(gm * t / a.count);
+  }
+  __syncthreads();
+  float m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { m1[j] = mm[0][cg * 8 + j]; m2[j] = mm[1][cg * 8 + j]; }
+  for (unsigned vb = vl; vb < a.dhw; vb += 64 * IT) {
+    Oct8<YBF> yr[IT];
+    float4 d0[IT], d1[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const unsigned v = min(vb + 64 * i, a.dhw - 1);
+      yr[i] = oct8_ld<YBF>(yp, v * a.ysw + c0, v * a.ysw + c0 + 4);
+      d0[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0);
+      d1[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0 + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      float yv[8], ov[8];
+      oct8_f8(yr[i], yv);
+      const float dv[8] = {d0[i].x, d0[i].y, d0[i].z, d0[i].w, d1[i].x, d1[i].y, d1[i].z, d1[i].w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xhat = (yv[j] - mu[j]) * rs[j];
+        float dz = dv[j];
+        if (a.relu && !(fmaf(g[j], xhat, bt[j]) > 0.f)) dz = 0.f;
+        ov[j] = rs[j] * (g[j] * dz - m1[j] - xhat * m2[j]);
+      }
+      const unsigned v = vb + 64 * i;
+      if (v < a.dhw) {
+        *reinterpret_cast<float4*>(op + v * a.osw + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        *reinterpret_cast<float4*>(op + v * a.osw + c0 + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ combine, 8 channels per thread
 // out = Ta(a) + Tb(b) for voxel-dense tensors of one storage type with C a power of two >= 8: the same arithmetic as
 // elementwise_kernel<0, ...>, a thread's 16 coefficient pairs computed once, IT voxels' loads issued before the first use.
@@ -925,6 +1046,41 @@ extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor
     else hipLaunchKernelGGL((elementwise_kernel<1, 1>), grid, dim3(256), 0, s, e);
   }
   return launch_status("norm bwd apply");
+}
+
+// eligibility of the one-launch backward (host-only): instance statistics of a small voxel-dense tensor, channels in whole
+// groups of 32, 16-byte aligned octets
+static bool nbs_ok(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t, const mmtta_tensor* dy) {
+  if (!dout || !y || !t || !dy || !t->mean || !t->rstd) return false;
+  if (dout->dtype != MMTTA_F32 || dy->dtype != MMTTA_F32) return false;
+  if (!same_shape(dout, y) || !same_shape(dy, y) || !is_cl(dout) || !is_cl(y) || !is_cl(dy)) return false;
+  const long long dhw = (long long)y->d * y->h * y->w;
+  auto dense = [](const mmtta_tensor* x) { return x->sh == (int64_t)x->w * x->sw && x->sd == (int64_t)x->h * x->sh; };
+  auto al = [](const mmtta_tensor* x, int per) { return ((uintptr_t)x->ptr) % 16 == 0 && x->sw % per == 0 && x->sn % per == 0; };
+  auto a16 = [](const void* p) { return p == nullptr || ((uintptr_t)p) % 16 == 0; };
+  return y->c % 32 == 0 && dhw >= 1 && dhw <= 4096 && dense(dout) && dense(y) && dense(dy) && al(dout, 4) && al(dy, 4) &&
+         al(y, is_bf16(y) ? 8 : 4) && a16(t->mean) && a16(t->rstd) && a16(t->gamma) && a16(t->beta);
+}
+
+extern "C" int mmtta_norm_bwd_small_ok(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
+                                       const mmtta_tensor* dy) {
+  return nbs_ok(dout, y, t, dy) ? 1 : 0;
+}
+
+extern "C" int mmtta_norm_bwd_small(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
+                                    int64_t count, const mmtta_tensor* dy, void* stream) {
+  MMTTA_CHECK(nbs_ok(dout, y, t, dy), MMTTA_ERR_UNSUPPORTED, "norm bwd (one launch): tensors not eligible (mmtta_norm_bwd_small_ok)");
+  MMTTA_CHECK(count > 0, MMTTA_ERR_INVALID, "norm bwd (one launch): count must be positive");
+  NbsArgs q;
+  q.dout = (const float*)dout->ptr; q.y = (const float*)y->ptr; q.o = (float*)dy->ptr;
+  q.dsn = dout->sn; q.ysn = y->sn; q.osn = dy->sn;
+  q.dsw = (unsigned)dout->sw; q.ysw = (unsigned)y->sw; q.osw = (unsigned)dy->sw;
+  q.C = y->c; q.relu = t->relu; q.dhw = (unsigned)((long long)y->d * y->h * y->w); q.count = (double)count;
+  q.mean = t->mean; q.rstd = t->rstd; q.gamma = t->gamma; q.beta = t->beta;
+  const dim3 grid((unsigned)(y->c / 32), (unsigned)y->n);
+  if (is_bf16(y)) hipLaunchKernelGGL(norm_bwd_small_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  else hipLaunchKernelGGL(norm_bwd_small_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  return launch_status("norm bwd (one launch)");
 }
 
 extern "C" int mmtta_upsample2x_fwd(const mmtta_tensor* x, const mmtta_tensor* y, void* stream) {

@@ -186,13 +186,18 @@ class NormLayer:
     def backward(self, pool: Pool, key, dT: torch.Tensor, y: torch.Tensor, nl: NL, dy: torch.Tensor,
                  training: bool, accumulate: bool = False) -> None:
         n, d, h, w, c = y.shape
+        train_g = self.gamma is not None and self.gamma.trainable
+        # the deep levels: reduce + finalize + apply were three launch latencies; one workgroup per 32 channels does it all
+        if (self.kind == ops.NORM_INSTANCE and not train_g and d * h * w <= ops.small_norm_backward_max()
+                and ops.norm_bwd_small_ok(dT, y, nl, dy)):
+            ops.norm_bwd_small(dT, y, nl, d * h * w, dy)
+            return
         rows = ops.reduce_rows_per_n(y)
         part = pool.flat((key, "bpart"), n * rows * 2 * c)
         m1 = pool.flat((key, "m1"), n * c)
         m2 = pool.flat((key, "m2"), n * c)
         scratch = pool.flat((key, "tot"), n * c * 2, dtype=torch.float64)
         ops.norm_bwd_reduce(dT, y, nl, part)
-        train_g = self.gamma is not None and self.gamma.trainable
         use_batch = training or self.kind != ops.NORM_BATCH
         ops.norm_bwd_finalize(self.kind, self.groups, part, rows, n, c, d * h * w,
                               self.gamma.data if self.gamma else None, use_batch, m1, m2,

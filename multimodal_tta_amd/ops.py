@@ -9,6 +9,7 @@ the calls can be captured into a graph.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -491,6 +492,26 @@ def norm_bwd_apply(dout: torch.Tensor, y: torch.Tensor, nl: NL, m1: torch.Tensor
     s, r = _nl_ref(nl)
     check(_lib.load().mmtta_norm_bwd_apply(C.byref(td), C.byref(ty), r, ptr(m1), ptr(m2), C.byref(to), stream_ptr()),
           "norm_bwd_apply")
+
+
+def small_norm_backward_max() -> int:
+    """Largest voxel count per batch item that takes the one-launch norm backward (A/B aid: MMTTA_NORM_SMALL=<voxels>, 0 =
+    three passes at every level)."""
+    return int(os.environ.get("MMTTA_NORM_SMALL", "512"))
+
+
+def norm_bwd_small_ok(dout: torch.Tensor, y: torch.Tensor, nl: NL, dy: torch.Tensor) -> bool:
+    """True when mmtta_norm_bwd_small (instance-norm backward of a small tensor in one launch) takes these tensors."""
+    td, ty, to = desc_cl(dout), desc_cl(y), desc_cl(dy)
+    s, r = _nl_ref(nl)
+    return bool(_lib.load().mmtta_norm_bwd_small_ok(C.byref(td), C.byref(ty), r, C.byref(to)))
+
+
+def norm_bwd_small(dout: torch.Tensor, y: torch.Tensor, nl: NL, count: int, dy: torch.Tensor) -> None:
+    td, ty, to = desc_cl(dout), desc_cl(y), desc_cl(dy)
+    s, r = _nl_ref(nl)
+    check(_lib.load().mmtta_norm_bwd_small(C.byref(td), C.byref(ty), r, int(count), C.byref(to), stream_ptr()),
+          "norm_bwd_small")
 
 
 # ----------------------------------------------------------------------------- resample / glue

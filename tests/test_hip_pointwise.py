@@ -105,6 +105,64 @@ def test_norm_forward_backward(kind, groups, shape, affine):
         close("dbeta", db, beta.grad, rel=2e-4, abs_=1e-4)
 
 
+@pytest.mark.parametrize("stored", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape,affine", [((1, 128, 16, 16, 16), False), ((2, 64, 5, 7, 6), False), ((1, 512, 8, 8, 8), True),
+                                          ((1, 32, 1, 1, 3), False)])
+def test_small_instance_norm_backward_in_one_launch(shape, affine, stored):
+    """mmtta_norm_bwd_small (the deep levels: one workgroup per 32 channels, reduce + finalize + apply in one launch) against
+    torch autograd of relu(instance_norm(y) * gamma + beta) and against the three-pass form (same formulas, another fp32
+    summation order); fp32- and bf16-stored y; not eligible: > 4096 voxels, C no multiple of 32."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(9)
+    n, c, d, h, w = shape
+    y = (torch.randn(shape) * 1.7 + 0.3)
+    if stored == "bf16":
+        y = y.to(torch.bfloat16).float()
+    y.requires_grad_(True)
+    gamma = (torch.rand(c) + 0.5) if affine else None
+    beta = (torch.randn(c) * 0.1) if affine else None
+    ref = F.relu(F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5))
+    gout = torch.randn_like(ref)
+    ref.backward(gout)
+    y32 = cl(y.detach())
+    if stored == "bf16":
+        y_cl = ops.new_cl(n, d, h, w, c, "cuda", ldc=ops.row_pad(c, torch.bfloat16), dtype=torch.bfloat16)
+        y_cl.copy_(y32)
+    else:
+        y_cl = y32
+    rows = ops.reduce_rows_per_n(y32)
+    part = torch.empty(n * rows * 2 * c, device="cuda")
+    ops.channel_stats(y32, part)
+    mean, rstd = torch.empty(n * c, device="cuda"), torch.empty(n * c, device="cuda")
+    scratch = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
+    ops.norm_stats_finalize(ops.NORM_INSTANCE, 1, part, rows, n, c, d * h * w, 1e-5, True, None, None, 0.1, mean, rstd, scratch)
+    g_d = gamma.cuda() if affine else None
+    b_d = beta.cuda() if affine else None
+    nl = ops.NL(mean, rstd, g_d, b_d, relu=True)
+    dT = cl(gout)
+    dy1 = torch.empty_like(y32)
+    assert ops.norm_bwd_small_ok(dT, y_cl, nl, dy1)
+    ops.norm_bwd_small(dT, y_cl, nl, d * h * w, dy1)
+    bpart = torch.empty(n * rows * 2 * c, device="cuda")
+    m1, m2 = torch.empty(n * c, device="cuda"), torch.empty(n * c, device="cuda")
+    ops.norm_bwd_reduce(dT, y_cl, nl, bpart)
+    ops.norm_bwd_finalize(ops.NORM_INSTANCE, 1, bpart, rows, n, c, d * h * w, g_d, True, m1, m2, None, None, False, scratch)
+    dy3 = torch.empty_like(y32)
+    ops.norm_bwd_apply(dT, y_cl, nl, m1, m2, dy3)
+    torch.cuda.synchronize()
+    close("one launch vs autograd", ncdhw(dy1), y.grad, rel=2e-4, abs_=2e-6)
+    close("one launch vs three passes", dy1, dy3, rel=2e-5, abs_=1e-6)
+    # in place (dy aliases dout), as the engine may call it
+    ops.norm_bwd_small(dT, y_cl, nl, d * h * w, dT)
+    torch.cuda.synchronize()
+    assert torch.equal(dT, dy1)
+    big = torch.empty(1, 17, 16, 16, 32, device="cuda")
+    assert not ops.norm_bwd_small_ok(big, big, ops.NL(mean[:32], rstd[:32], None, None, relu=True), big)
+    odd = torch.empty(1, 4, 4, 4, 40, device="cuda")
+    assert not ops.norm_bwd_small_ok(odd, odd, ops.NL(mean[:40], rstd[:40], None, None, relu=True), odd)
+
+
 def test_batchnorm_eval_uses_running_stats():
     from multimodal_tta_amd import ops
     torch.manual_seed(5)
