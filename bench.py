@@ -89,8 +89,6 @@ def build_cfg(args):
         ov += [f"method.side_streams={args.side_streams}"]
     if getattr(args, "storage", None) or os.environ.get("MMTTA_STORAGE"):
         ov += [f"method.storage={getattr(args, 'storage', None) or os.environ['MMTTA_STORAGE']}"]
-    if "MMTTA_FUSE" in os.environ:                          # A/B aid: optimizer fused into the weight-gradient reductions
-        ov += [f"method.fuse_optimizer={'true' if os.environ['MMTTA_FUSE'] == '1' else 'false'}"]
     cfg = compose(overrides=ov)
     shape = args.shape or ([128, 128, 128] if args.task == "brats" else [48, 144, 144])
     cfg["dataset"]["synthetic"]["shape"] = list(shape)

@@ -101,15 +101,6 @@ int mmtta_abi_version(void);
  * the matrix cores work on stage k; 0: the generic loader, load -> barrier -> MFMA -> barrier as in round 1.  Same
  * results bit for bit. */
 #define MMTTA_OPT_IGEMM_PIPELINE 6
-/* Producer / consumer form of the bf16-operand implicit GEMM (512-thread workgroups: four loader waves and four MFMA
- * waves, double-buffered LDS, persistent over a contiguous range of tiles).  0 (default): off; 1: the wide small-grid
- * configurations only; 2: every bf16 configuration.  Same results as the default kernel up to the summation order of
- * the statistics rows.  Measured round 2: 5-15 % faster per launch on the 8^3 / 16^3 levels
- * when a lane runs alone, but 4 % SLOWER for four lanes (a 512-thread, 256-register workgroup owns its CU), and 2x
- * slower on the 64^3 layers - kept as a measured, tested alternative, not the default.  It changes the number of
- * statistics rows a convolution writes (mmtta_conv_plan reports it): set before planning.
- * IGEMM_WS_WORKGROUPS: workgroups of such a launch (default 256 = one per CU). */
-#define MMTTA_OPT_IGEMM_PRODUCER_CONSUMER 7
 /* 1 (default): implicit-GEMM epilogues store 16 bytes per lane through an LDS transposition (same values; the
  * statistics rows sum in a different order); 0: four-byte stores straight from the accumulators (round 1). */
 #define MMTTA_OPT_EPILOGUE_VEC16 9
@@ -120,16 +111,13 @@ int mmtta_abi_version(void);
  * implicit GEMM staged one item per trip (r02c), +1.2 % volumes/s with the row loaders (same-box A/B 65.2 against 64.4).
  * Changes the statistics rows a convolution writes: set before planning. */
 #define MMTTA_OPT_IGEMM_LEAN 10
-/* Kernel of the bf16-operand 27-tap weight gradient (csrc/conv_wgrad.hip):
- *   1  (default; 3 is a synonym) the transposed-read kernel for every operand pair that admits its 16-byte items
- *      (16-byte-aligned rows, strides < 2^24, < 2^31 elements; else as 0): operands stay [voxel][channel] in LDS as in
- *      HBM and ds_read_b64_tr_b16 transposes them on the way into the MFMA;
- *   0  element loads, one channel per thread, operands transposed to [channel][voxel] while staging (round 1);
- *   2  as 0 with 16-byte (bf16 storage: 8-byte) four-channel loads - bit-identical to 0.
- * 1 sums the voxels in another order than 0 / 2: equal within 2e-3 of max|dw|
- * (tests/test_hip_conv.py::test_transposed_read_wgrad). */
+/* Kernel of the bf16-operand weight gradients (csrc/conv_wgrad.hip):
+ *   1 (default)  the transposed-read kernels for every operand pair that admits their 16-byte items (16-byte-aligned
+ *      rows, strides < 2^24, < 2^31 elements): operands stay [voxel][channel] in LDS as in HBM and ds_read_b64_tr_b16
+ *      transposes them on the way into the MFMA (27 taps: wgrad_tr_kernel, 1x1x1: wgrad_tr1_kernel);
+ *   0  (and every operand pair the above cannot take) the fp32-operand kernel: exact fp32 products.
+ * Equal within the bf16 operand rounding (tests/test_hip_conv.py::test_transposed_read_wgrad). */
 #define MMTTA_OPT_WGRAD_VECTOR_STAGING 11
-#define MMTTA_OPT_IGEMM_WS_WORKGROUPS 8
 /* Stride-2 transposed forms (ConvTranspose3d forward, input gradient of a stride-2 Conv3d) in bf16 mode: when one
  * workgroup per coarse 4 x 4 x 8 tile and 32 output channels makes at least this many workgroups (default 128), all 8
  * output parity classes of a tile are produced by ONE workgroup from one staged halo box (csrc/conv_igemm.hip,
@@ -391,28 +379,6 @@ typedef struct mmtta_optim_desc {
 } mmtta_optim_desc;
 int mmtta_optim_step(const mmtta_optim_desc* desc, float* p, const float* g, float* m, float* v, int64_t n,
                      int64_t n_decay, int32_t* step, void* stream);
-
-/* Weight gradient with the optimizer update fused into its reduction: the same launches as mmtta_conv_wgrad, but the
- * reduce kernels, which are the first place the complete gradient of an element exists, apply mmtta_optim_step's arithmetic
- * to `param` / `exp_avg` / `exp_avg_sq` (the layout of dw: torch's weight layout) instead of writing dw - bit-identical
- * parameters, 8 of the optimizer's 28 bytes per parameter never move and the rest moves inside the backward pass.  `step`
- * is read, not advanced (advance it once per optimizer step, after every layer: mmtta_optim_step on the remaining
- * parameters does).  The bias gradient still goes to `db` (NULL: none).  Only layers whose weight gradient goes through the
- * slab reduction (mmtta_conv_wgrad_fusable() == 1: more than 4 channels on both sides) and no accumulation; the
- * reference's loss.backward(); optimizer.step() (src/core/trainers/seg_trainer.py:142-143) is the unfused pair.
- * Measured round 2: 3 % SLOWER than the separate pass on the U-Net (57.4 against 59.3 volumes/s), with 108-byte runs of dw
- * per reduce workgroup and with 864-byte runs (a reduce kernel of 8 cg per workgroup, itself 7 -> 12.5 us per launch and
- * dropped again) alike: the update turns a write-only reduction into three reads and three writes per element inside
- * small launches, and the arena pass it replaces streams at 6.4 TB/s.  `method.fuse_optimizer`
- * is off by default; kept because the result is bit-identical. */
-int mmtta_optim_step_partial(const mmtta_optim_desc* desc, float* p, const float* g, float* m, float* v, int64_t n,
-                             int64_t n_decay, int32_t* step, void* stream);     /* mmtta_optim_step without advancing `step` */
-int mmtta_optim_advance(int32_t* step, void* stream);                            /* step += 1 */
-int mmtta_conv_wgrad_fusable(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_tensor* dy);
-int mmtta_conv_wgrad_optim(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
-                           const mmtta_tensor* dy, float* db, void* workspace, int64_t workspace_bytes,
-                           const mmtta_optim_desc* opt, float* param, float* exp_avg, float* exp_avg_sq,
-                           const int32_t* step, int decay, void* stream);
 
 /* ------------------------------------------------------------------ evaluation tail ------ */
 /* sigmoid -> (>= threshold) -> uint8 mask; GT (> 0.5); per (n,r) integer counts

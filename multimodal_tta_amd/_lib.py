@@ -118,12 +118,6 @@ _SIGNATURES = {
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "mmtta_optim_step": (C.c_int, [_P(OptimDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                    C.c_void_p, C.c_void_p]),
-    "mmtta_optim_step_partial": (C.c_int, [_P(OptimDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
-                                           C.c_void_p, C.c_void_p]),
-    "mmtta_optim_advance": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "mmtta_conv_wgrad_fusable": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(Tensor)]),
-    "mmtta_conv_wgrad_optim": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(NormOnLoad), _P(Tensor), C.c_void_p, C.c_void_p, C.c_int64,
-                                         _P(OptimDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mmtta_mask_dice_counts": (C.c_int, [_P(Tensor), _P(Tensor), C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmtta_dice_ce_scratch_bytes": (C.c_int64, [_P(Tensor)]),
     "mmtta_dice_ce_sums": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -166,8 +160,6 @@ def load() -> C.CDLL:
         lib.mmtta_set_option(12, int(os.environ["MMTTA_CLSFUSE"]))
     if "MMTTA_LEAN" in os.environ:                       # A/B aid: MMTTA_OPT_IGEMM_LEAN
         lib.mmtta_set_option(10, int(os.environ["MMTTA_LEAN"]))
-    if "MMTTA_WS" in os.environ:                         # A/B aid: MMTTA_OPT_IGEMM_PRODUCER_CONSUMER = 0 / 1 / 2
-        lib.mmtta_set_option(7, int(os.environ["MMTTA_WS"]))
     _lib = lib
     return lib
 

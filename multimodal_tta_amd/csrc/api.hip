@@ -12,9 +12,6 @@ void set_error(const char* fmt, ...) {
 }
 int g_profile_main_only = 0;
 int g_igemm_pipeline = 1;
-int g_igemm_ws = 0;
-int g_ws_workgroups = 256;
-void* g_ws_debug = nullptr;
 int g_epilogue_vec = 1;
 int g_igemm_lean = 1;
 int g_cls_fused_min = 128;
@@ -31,20 +28,9 @@ extern "C" int mmtta_set_option(int key, int value) {
     mmtta::g_profile_main_only = value;
     return prev;
   }
-  if (key == MMTTA_OPT_IGEMM_PRODUCER_CONSUMER) {
-    const int prev = mmtta::g_igemm_ws;
-    mmtta::g_igemm_ws = value;      // 0 off, 1 wide small-grid configurations only, 2 all bf16 configurations
-    return prev;
-  }
-  if (key == MMTTA_OPT_IGEMM_WS_WORKGROUPS) {
-    if (value < 1) return MMTTA_ERR_INVALID;
-    const int prev = mmtta::g_ws_workgroups;
-    mmtta::g_ws_workgroups = value;
-    return prev;
-  }
   if (key == MMTTA_OPT_WGRAD_VECTOR_STAGING) {
     const int prev = mmtta::g_wgrad_vec;
-    mmtta::g_wgrad_vec = value < 0 ? 0 : (value > 3 ? 3 : value);
+    mmtta::g_wgrad_vec = value ? 1 : 0;
     return prev;
   }
   if (key == MMTTA_OPT_THIN_MFMA) {
@@ -69,7 +55,7 @@ extern "C" int mmtta_set_option(int key, int value) {
   }
   if (key == MMTTA_OPT_IGEMM_PIPELINE) {
     const int prev = mmtta::g_igemm_pipeline;
-    mmtta::g_igemm_pipeline = value;      // bit 0: pipeline; bits 1-3: diagnostic ablations of the producer/consumer kernel
+    mmtta::g_igemm_pipeline = value ? 1 : 0;
     return prev;
   }
   if (key >= MMTTA_OPT_SPLITK_BELOW && key <= MMTTA_OPT_WGRAD_THIN_SLABS) {
@@ -80,10 +66,6 @@ extern "C" int mmtta_set_option(int key, int value) {
   }
   return MMTTA_ERR_INVALID;
 }
-
-/* diagnostic builds only: a device buffer of 8 int64 per workgroup that the producer/consumer implicit GEMM fills with
- * s_memtime phase totals (loader: staging, barrier wait, steps; consumer: barrier wait, MFMA, epilogue); NULL = off */
-extern "C" void mmtta_debug_set_buffer(void* p) { mmtta::g_ws_debug = p; }
 
 extern "C" const char* mmtta_last_error(void) { return mmtta::g_err; }
 extern "C" int mmtta_abi_version(void) { return MMTTA_ABI_VERSION; }

@@ -345,14 +345,11 @@ int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s);  // 
 // direct path for layers producing <= 4 channels (conv_direct.hip)
 extern int g_profile_main_only;     // api.hip: mmtta_set_option(MMTTA_OPT_PROFILE_MAIN_KERNEL_ONLY)
 extern int g_igemm_pipeline;        // api.hip: MMTTA_OPT_IGEMM_PIPELINE
-extern int g_igemm_ws;              // api.hip: MMTTA_OPT_IGEMM_PRODUCER_CONSUMER
-extern int g_ws_workgroups;         // api.hip: MMTTA_OPT_IGEMM_WS_WORKGROUPS
 extern int g_wgrad_vec;             // api.hip: MMTTA_OPT_WGRAD_VECTOR_STAGING
 extern int g_igemm_lean;            // api.hip: MMTTA_OPT_IGEMM_LEAN
 extern int g_cls_fused_min;         // api.hip: MMTTA_OPT_CLASS_FUSED_MIN_WORKGROUPS
 extern int g_thin_mfma;             // api.hip: MMTTA_OPT_THIN_MFMA
 extern int g_epilogue_vec;          // api.hip: MMTTA_OPT_EPILOGUE_VEC16
-extern void* g_ws_debug;            // api.hip: mmtta_debug_set_buffer (phase stamps of the producer/consumer kernel)
 extern int g_tune[4];               // api.hip: launch-geometry knobs (MMTTA_OPT_SPLITK_BELOW ... MMTTA_OPT_WGRAD_THIN_SLABS)
 bool direct_applicable(const mmtta_conv_desc* d);
 int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);

@@ -77,7 +77,6 @@ struct GArgs {
   int in_bf, out_bf, add_bf;   // storage of the three activation operands: 1 = bf16 elements (common.h storage helpers)
   int vec4;
   int ovec;        // 16-byte epilogue stores (out / add rows 16-byte aligned, Co % 4 == 0)
-  int pipeline;    // box-load software pipeline on (MMTTA_OPT_IGEMM_PIPELINE; default 1)
   int coef_off;    // word offset of the coefficient table behind the LDS box image
   int rowload;     // the input admits the row-structured loader (alignment, 24-bit strides, < 2^31 elements)
   int ncls, tiles_per_cls;
@@ -147,7 +146,7 @@ __device__ __forceinline__ void epilogue_vec16(const GArgs& a, const ClassInfo& 
     }
     if (a.accumulate) { v[0] += oldq.x; v[1] += oldq.y; v[2] += oldq.z; v[3] += oldq.w; }
     if (okk) {
-      if (!(a.pipeline & 2)) st4_t<ABF>(outb, obase + oo, make_float4(v[0], v[1], v[2], v[3]));
+      st4_t<ABF>(outb, obase + oo, make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
     }
@@ -1102,451 +1101,6 @@ static int launch_cls8_t(const GArgs& a, int tiles, hipStream_t s) {
   return launch_status("conv igemm (class-fused stride-2 form)");
 }
 
-// ---------------------------------------------------------------- producer / consumer form (bf16 operands)
-// The same gather GEMM with the two halves of a stage on DIFFERENT waves of one 512-thread workgroup per CU:
-//   waves 4-7 (loaders)   fetch the input box of step i+1 from HBM / L2, apply norm + ReLU, round to bf16 and write
-//                         LDS buffer (i+1) & 1;
-//   waves 0-3 (consumers) run the MFMAs of step i out of buffer i & 1 (one wave per SIMD: the matrix pipe is theirs
-//                         alone) and, at the end of a unit, the epilogue from their accumulators.
-// One barrier per step.  A step = one KCI-channel stage of one unit; a unit = (tile, column group, K split); a
-// workgroup walks a CONTIGUOUS range of units (persistent: the box of the next tile is loaded while the last stage of
-// the current one is in the matrix cores and its outputs drain).  In the one-phase-at-a-time kernel above all
-// workgroups of a launch load, compute and store in lockstep - HBM, LDS and the matrix cores each idle two thirds of
-// the time (measured round 1); here the load stream never stops.  Statistics: every consumer wave writes its own
-// row (no cross-wave reduction, so no barrier inside the role-specific code): MG rows per tile.
-struct Unit {
-  int bx, lby, lbz, cidx, tile_in_n, n, gz0, gy0, gx0, BY, LP, boxvox, iz0, iy0, ix0, ks0, ks1;
-};
-
-template <int TZ, int TY, int TX>
-__device__ __forceinline__ void unit_geometry(const GArgs& a, int u, int ntiles, int ncolg, Unit& g) {
-  g.bx = u % ntiles;
-  const int rest = u / ntiles;
-  g.lby = rest % ncolg;
-  g.lbz = rest / ncolg;
-  g.cidx = g.bx / a.tiles_per_cls;
-  int t = g.bx % a.tiles_per_cls;
-  g.tile_in_n = t % (a.tz * a.ty * a.tx);
-  const int txi = t % a.tx; t /= a.tx;
-  const int tyi = t % a.ty; t /= a.ty;
-  const int tzi = t % a.tz;
-  g.n = t / a.tz;
-  g.gz0 = tzi * TZ; g.gy0 = tyi * TY; g.gx0 = txi * TX;
-  const int BZ = (TZ - 1) * a.si + a.cls[g.cidx].zext + 1;
-  g.BY = (TY - 1) * a.si + a.cls[g.cidx].yext + 1;
-  const int BX = (TX - 1) * a.si + a.cls[g.cidx].xext + 1;
-  g.boxvox = BZ * g.BY * BX;
-  g.LP = a.si == 1 ? LDS_PITCH_BF16 : BX;
-  g.iz0 = g.gz0 * a.si + a.cls[g.cidx].zmin; g.iy0 = g.gy0 * a.si + a.cls[g.cidx].ymin; g.ix0 = g.gx0 * a.si + a.cls[g.cidx].xmin;
-  g.ks0 = g.lbz * a.stages_per_split;
-  g.ks1 = min(a.nstages, g.ks0 + a.stages_per_split);
-}
-
-template <int NB, int MB, int TZ, int TY, int TX, int KCI>
-__global__ __launch_bounds__(512, 2) void igemm_ws_kernel(GArgs a, int ntiles, int ncolg, int nunits, int bufhw, long long* dbg) {
-  extern __shared__ float lds[];
-  constexpr int VS = KCI + 8;
-  constexpr int MT = TZ * TY * TX;
-  constexpr int MG = 4 / NB;
-  constexpr int KS = KCI / 16;
-  static_assert(MT == 32 * MB * MG, "tile rows must equal 32*MB*(4/NB)");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave >= 4;
-  const int ltid = tid & 255;                       // thread index inside its role
-  const int cw = wave & 3, cb = cw % NB, mg = cw / NB;
-  const int h0 = lane >> 5, r0 = lane & 31;
-  unsigned short* lhb = reinterpret_cast<unsigned short*>(lds);
-
-  const int L = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
-  const int per = (nunits + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int u0 = L * per, u1 = min(nunits, u0 + per);
-  if (u0 >= u1) return;
-
-  // Rendezvous schedule (S = total steps of this workgroup; one barrier B(s) per step):
-  //   loaders    stage(0) B0 stage(1) B1 ... stage(S-1) B(S-1)
-  //   consumers           B0 comp(0)  B1 comp(1) ... B(S-1) comp(S-1)
-  // comp(s) reads buffer s & 1 between B(s) and B(s+1); stage(s+2) overwrites it only after B(s+1).  Both roles walk the
-  // same units and stages, so they execute the same number of barriers; the role is wave-uniform and each role has its
-  // own loop nest (the register allocator sees the loader's staging registers and the consumer's accumulators and
-  // weight sets as disjoint live ranges).
-  int step = 0;
-  long long dl_stage = 0, dl_wait = 0, dc_wait = 0, dc_mfma = 0, dc_epi = 0;
-  if (loader) {
-    for (int u = u0; u < u1; ++u) {
-      Unit lg;
-      unit_geometry<TZ, TY, TX>(a, u, ntiles, ncolg, lg);
-      const ClassInfo ci = a.cls[lg.cidx];       // by value: a reference re-reads the kernel-argument segment at every use
-      const float* inb = a.in + (long long)lg.n * a.isn;
-      const int BY = lg.BY, LP = lg.LP, boxvox = lg.boxvox, iz0 = lg.iz0, iy0 = lg.iy0, ix0 = lg.ix0;
-      for (int lks = lg.ks0; lks < lg.ks1; ++lks, ++step) {
-        const long long tl0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        // ---------------- stage the input box of (lg, lks) into buffer step & 1 ----------------
-        unsigned short* lh = lhb + (step & 1) * bufhw;
-        const int c0 = lks * KCI;
-        if (a.vec4 && (a.Ci & 7) == 0) {              // 8-channel (32-byte) items; ragged channel counts take the scalar path
-          constexpr int CV8 = KCI / 8;
-          constexpr int STEP = 256 / CV8;
-          constexpr int U = 8;                        // loader waves own their registers: 8 box items in flight per thread
-          const int cv = ltid % CV8;
-          const int c = c0 + cv * 8;
-          float sc[8], sh[8];
-          nl_coeff_vec<8>(a.tin, lg.n, a.Ci, c, sc, sh);
-          const int cl = min(c, max(a.Ci - 8, 0));    // clamped channel of the (always valid) load address
-          for (int bv0 = ltid / CV8; bv0 < boxvox; bv0 += U * STEP) {
-            float4 x0[U], x1[U];
-            unsigned okm = 0u;
-#pragma unroll
-            for (int q = 0; q < U; ++q) {
-              const int bv = bv0 + q * STEP;
-              const int bvc = min(bv, boxvox - 1);
-              const int bz = (int)__umulhi((unsigned)bvc, ci.mBXY), brem = bvc - bz * ci.BXY;
-              const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
-              const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
-              const bool ok = bv < boxvox && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi &&
-                              (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
-              okm |= (ok ? 1u : 0u) << q;
-              // unconditional loads from clamped (always valid) addresses; masked below
-              const float* src = inb + min(max(iz, 0), a.Di - 1) * a.isd + min(max(iy, 0), a.Hi - 1) * a.ish +
-                                 min(max(ix, 0), a.Wi - 1) * a.isw + cl;
-              x0[q] = *reinterpret_cast<const float4*>(src);
-              x1[q] = *reinterpret_cast<const float4*>(src + 4);
-            }
-#pragma unroll
-            for (int q = 0; q < U; ++q) {
-              const int bv = bv0 + q * STEP;
-              if (bv < boxvox) {
-                uint4 pk = make_uint4(0u, 0u, 0u, 0u);
-                if ((okm >> q) & 1u) {
-                  const float xs[8] = {x0[q].x, x0[q].y, x0[q].z, x0[q].w, x1[q].x, x1[q].y, x1[q].z, x1[q].w};
-                  float v[8];
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) v[j] = nl_apply(xs[j], sc[j], sh[j], a.tin.relu);
-                  pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-                  pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
-                }
-                const int bz = (int)__umulhi((unsigned)bv, ci.mBXY), brem = bv - bz * ci.BXY;
-                const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
-                *reinterpret_cast<uint4*>(lh + ((bz * BY + by) * LP + bx) * VS + cv * 8) = pk;
-              }
-            }
-          }
-        } else {
-          const int cc = ltid % KCI;
-          const int c = c0 + cc;
-          float sc, sh;
-          nl_coeff_vec<1>(a.tin, lg.n, a.Ci, c, &sc, &sh);
-          for (int bv = ltid / KCI; bv < boxvox; bv += 256 / KCI) {
-            const int bz = (int)__umulhi((unsigned)bv, ci.mBXY), brem = bv - bz * ci.BXY;
-            const int by = (int)__umulhi((unsigned)brem, ci.mBX), bx = brem - by * ci.BX;
-            const int iz = iz0 + bz, iy = iy0 + by, ix = ix0 + bx;
-            const bool ok = (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi && c < a.Ci;
-            const float raw = inb[min(max(iz, 0), a.Di - 1) * a.isd + min(max(iy, 0), a.Hi - 1) * a.ish +
-                                  min(max(ix, 0), a.Wi - 1) * a.isw + min(c, a.Ci - 1)];
-            const float v = ok ? nl_apply(raw, sc, sh, a.tin.relu) : 0.f;
-            lh[((bz * BY + by) * LP + bx) * VS + cc] = __builtin_bit_cast(unsigned short, (__bf16)v);
-          }
-        }
-        long long tl1 = 0;
-        if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tl1 = (long long)__builtin_amdgcn_s_memtime(); }
-        __syncthreads();
-        if (dbg) { const long long tl2 = (long long)__builtin_amdgcn_s_memtime(); dl_stage += tl1 - tl0; dl_wait += tl2 - tl1; }
-      }
-    }
-    if (dbg && ltid == 0) { dbg[blockIdx.x * 8 + 0] = dl_stage; dbg[blockIdx.x * 8 + 1] = dl_wait; dbg[blockIdx.x * 8 + 2] = step; }
-    return;
-  }
-
-  // ---------------------------------------------------------------- consumer waves
-  for (int u = u0; u < u1; ++u) {
-    // lane coordinates re-materialised per unit behind an opaque barrier: everything derived from them (the 64 row ->
-    // voxel maps of the epilogue, the LDS row addresses) is otherwise hoisted out of the unit loop as loop invariant
-    // and kept live across it - 150 registers, i.e. spills (measured: 165 registers for one unit, 256 + 70 spilled for
-    // the loop)
-    int r = r0, h = h0, lane1 = lane;
-    asm volatile("" : "+v"(r), "+v"(h), "+v"(lane1));
-    Unit cg;
-    unit_geometry<TZ, TY, TX>(a, u, ntiles, ncolg, cg);
-    const ClassInfo ci = a.cls[cg.cidx];         // by value (scalar registers): see the loader
-    const int colbase = (cg.lby * NB + cb) * 32;
-    const bool colact = colbase < a.Np;
-    f32x16 acc[MB];
-    int rowaddr[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      int zl, yl, xl;
-      row_to_local<TZ, TY, TX, true>((mg * MB + mb) * 32 + r, zl, yl, xl);
-      rowaddr[mb] = (((zl * a.si) * cg.BY + yl * a.si) * cg.LP + xl * a.si) * VS + 8 * h;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
-    }
-    const long long tu0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    const long long dc_wait0 = dc_wait;
-    const uint4* wq = reinterpret_cast<const uint4*>(a.wp);   // image [tap][Kp/8][Np][8 bf16]
-    const long long slabsz8 = (long long)(a.Kp / 8) * a.Np;
-    const int np2 = 2 * a.Np;
-    const int ntap = ci.ntaps;
-    const int* tslab = a.slab + ci.tap0;
-    const int* ttoff = a.toff + ci.tap0;
-    // The tap tables of a full 27-tap class are copied into scalar registers ONCE per unit, behind an opaque barrier:
-    // a table read inside the MFMA phase is a scalar memory load, scalar loads share the lgkmcnt counter with the LDS
-    // reads and return out of order, so every one of them forces `s_waitcnt lgkmcnt(0)` - a full drain of the A-fragment
-    // reads in flight - and the compiler re-reads kernel arguments freely (it counts them as free to rematerialise).
-    // Measured with in-kernel stamps: the MFMA phase ran at 3.5x, the epilogue at ~7x their instruction cost.
-    int toffv[27], tslv[27];
-    if (ntap == 27) {
-#pragma unroll
-      for (int t = 0; t < 27; ++t) { toffv[t] = ttoff[t] * VS; tslv[t] = tslab[t]; }
-#pragma unroll
-      for (int t = 0; t < 27; ++t) asm volatile("" : "+s"(toffv[t]), "+s"(tslv[t]));
-    }
-    for (int cks = cg.ks0; cks < cg.ks1; ++cks, ++step) {
-      const int c0 = cks * KCI;
-      const int kreal = min(KCI, a.Ci - c0);
-      const int nks = (kreal + 15) >> 4;
-      const uint4* wcol = wq + (long long)(c0 / 8 + h) * a.Np + colbase + r;
-      // 16-channel stages: ALL 27 weight fragments of the stage are requested BEFORE the rendezvous (108 registers) -
-      // they travel while this wave waits for the loaders anyway, and the MFMA phase then touches LDS only: no weight
-      // fetch queues behind the loaders' box bursts in the CU's memory pipeline (in-order, shared by the 8 waves)
-      constexpr bool PRE = false;     // whole-stage weight prefetch before the rendezvous: measured neutral, costs 108 registers (spills)
-      constexpr int NWF = PRE ? 27 : 1;
-      constexpr int NWL = 0;
-      uint4 wfull[NWF];
-      const bool pre = PRE && colact && nks == KS && ntap == 27;
-      if (pre) {
-#pragma unroll
-        for (int t = 0; t < NWF; ++t) wfull[t] = wcol[tslab[t] * slabsz8];
-      }
-      const long long tc0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
-      __syncthreads();                                        // B(step): buffer step & 1 is staged
-      const long long tc1 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
-      dc_wait += tc1 - tc0;
-      if (!colact || (a.pipeline & 8)) continue;
-      const unsigned short* lh = lhb + (step & 1) * bufhw;
-      if (pre) {
-        if constexpr (PRE) {
-          uint4 wlate[NWL > 0 ? NWL : 1];
-          if constexpr (NWL > 0) {                             // the rest lands behind the first 16 taps' MFMAs
-#pragma unroll
-            for (int t = 0; t < NWL; ++t) wlate[t] = wcol[tslab[NWF + t] * slabsz8];
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#pragma unroll
-          for (int t = 0; t < 27; ++t) {
-            const int ta = ttoff[t] * VS;
-            const bf16x8 bfr = __builtin_bit_cast(bf16x8, t < NWF ? wfull[t < NWF ? t : 0] : wlate[t >= NWF ? t - NWF : 0]);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-              const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta);
-              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfr, acc[mb], 0, 0, 0);
-            }
-          }
-        }
-      } else if (!PRE && nks == KS && ntap == 27) {
-        // full 27-tap stage (32-channel stages): weight fragments in groups of G taps through two register sets, the
-        // next group requested (behind a scheduling barrier) before the current group's MFMAs
-        constexpr int G = PRE ? 1 : (KS == 1 ? 9 : 5);  // (PRE configurations never take this branch: keep its arrays tiny)
-        constexpr int NG = (27 + G - 1) / G;
-        uint4 wset[2][G][KS];
-#pragma unroll
-        for (int t = 0; t < G; ++t)
-#pragma unroll
-          for (int k2 = 0; k2 < KS; ++k2) wset[0][t][k2] = wcol[tslv[t] * slabsz8 + k2 * np2];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          if (g + 1 < NG) {
-#pragma unroll
-            for (int t = 0; t < G; ++t) {
-              if ((g + 1) * G + t < 27) {
-#pragma unroll
-                for (int k2 = 0; k2 < KS; ++k2) wset[(g + 1) & 1][t][k2] = wcol[tslv[(g + 1) * G + t] * slabsz8 + k2 * np2];
-              }
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int t = 0; t < G; ++t) {
-            if (g * G + t < 27) {
-              const int ta = toffv[g * G + t];
-#pragma unroll
-              for (int k2 = 0; k2 < KS; ++k2) {
-                const bf16x8 bfr = __builtin_bit_cast(bf16x8, wset[g & 1][t][k2]);
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                  const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + k2 * 16);
-                  acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfr, acc[mb], 0, 0, 0);
-                }
-              }
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else if (nks == KS && ntap >= 4) {
-        // parity classes of the transposed forms (4 or 8 taps): ring of D taps in flight, branch-free body
-        constexpr int D = 4;
-        uint4 ring[D][KS];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const uint4* wb = wcol + tslab[d] * slabsz8;
-#pragma unroll
-          for (int k2 = 0; k2 < KS; ++k2) ring[d][k2] = wb[k2 * np2];
-        }
-        const int ntap_pad = (ntap + D - 1) / D * D;
-        for (int tp0 = 0; tp0 < ntap_pad; tp0 += D) {
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            const int tp = tp0 + d;
-            const bool live = tp < ntap;
-            bf16x8 bfrag[KS];
-#pragma unroll
-            for (int k2 = 0; k2 < KS; ++k2) {
-              uint4 q = ring[d][k2];
-              q.x = live ? q.x : 0u; q.y = live ? q.y : 0u; q.z = live ? q.z : 0u; q.w = live ? q.w : 0u;
-              bfrag[k2] = __builtin_bit_cast(bf16x8, q);
-            }
-            const uint4* wb = wcol + tslab[min(tp + D, ntap - 1)] * slabsz8;
-#pragma unroll
-            for (int k2 = 0; k2 < KS; ++k2) ring[d][k2] = wb[k2 * np2];
-            const int ta = ttoff[min(tp, ntap - 1)] * VS;
-#pragma unroll
-            for (int k2 = 0; k2 < KS; ++k2) {
-#pragma unroll
-              for (int mb = 0; mb < MB; ++mb) {
-                const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + k2 * 16);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag[k2], acc[mb], 0, 0, 0);
-              }
-            }
-          }
-        }
-      } else {
-        for (int tp = 0; tp < ntap; ++tp) {
-          const uint4* wb = wcol + tslab[tp] * slabsz8;
-          const int ta = ttoff[tp] * VS;
-          for (int k2 = 0; k2 < nks; ++k2) {
-            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, wb[k2 * np2]);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-              const uint4 av = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta + k2 * 16);
-              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag, acc[mb], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-    const long long te0 = dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    // ---------------- epilogue of the unit (consumer waves only; barrier-free) ----------------
-    const int n = cg.n;
-    const int col = colbase + r;
-    const bool colok = colact && col < a.Co;
-    if (a.ksplit > 1) {
-      if (colact) {
-        float* wsb = a.ws + ((long long)cg.lbz * ntiles + cg.bx) * MT * a.Np + col;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            wsb[(long long)((mg * MB + mb) * 32 + row) * a.Np] = acc[mb][i];
-          }
-      }
-      continue;
-    }
-    if (a.pipeline & 4) continue;
-    if (a.ovec) {
-      // 16-byte stores through this wave's LDS tile (behind the two box buffers)
-      float v_sum[4], v_sq[4];
-      epilogue_vec16<TZ, TY, TX, MB, true, false>(a, ci, acc, lds + bufhw + cw * EPI_TILE_FLOATS, lane1, mg * MB, colbase, colact, n,
-                                           cg.gz0, cg.gy0, cg.gx0, v_sum, v_sq);
-      if (a.stats != nullptr && lane1 < 8 && colact) {
-        const long long row = (long long)n * a.stats_rows_per_n +
-                              ((long long)cg.cidx * (a.tz * a.ty * a.tx) + cg.tile_in_n) * MG + mg;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int cc = colbase + lane1 * 4 + j;
-          if (cc < a.Co) {
-            a.stats[(row * 2 + 0) * a.Co + cc] = v_sum[j];
-            a.stats[(row * 2 + 1) * a.Co + cc] = v_sq[j];
-          }
-        }
-      }
-      if (dbg) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const long long te1 = (long long)__builtin_amdgcn_s_memtime();
-        dc_mfma += (te0 - tu0) - (dc_wait - dc_wait0);
-        dc_epi += te1 - te0;
-      }
-      continue;
-    }
-    float s_sum = 0.f, s_sq = 0.f;
-    float bias = 0.f, asc = 1.f, ash = 0.f;
-    if (colok) {
-      if (a.bias) bias = a.bias[col];
-      if (a.add) nl_coeff(a.tadd, n, a.Co, col, asc, ash);
-    }
-    const int colc = min(col, a.Co - 1);
-    const float* addb = a.add ? a.add + (long long)n * a.asn + colc : nullptr;
-    float* outb = a.out + (long long)n * a.osn + colc;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        int ooff[8], aoff[8];
-        bool ok[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int i = half * 8 + j;
-          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-          int zl, yl, xl;
-          row_to_local<TZ, TY, TX, true>((mg * MB + mb) * 32 + row, zl, yl, xl);
-          const int gz = cg.gz0 + zl, gy = cg.gy0 + yl, gx = cg.gx0 + xl;
-          const int oz = gz * a.so + ci.oz, oy = gy * a.so + ci.oy, ox = gx * a.so + ci.ox;
-          ok[j] = colok && gz < ci.Dg && gy < ci.Hg && gx < ci.Wg && oz < a.Do && oy < a.Ho && ox < a.Wo;
-          const int cz = min(oz, a.Do - 1), cy = min(oy, a.Ho - 1), cx = min(ox, a.Wo - 1);
-          ooff[j] = cz * (int)a.osd + cy * (int)a.osh + cx * (int)a.osw;
-          aoff[j] = cz * (int)a.asd + cy * (int)a.ash + cx * (int)a.asw;
-        }
-        float addv[8], oldv[8];
-        if (a.add) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) addv[j] = addb[aoff[j]];
-        }
-        if (a.accumulate) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) oldv[j] = outb[ooff[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float v = acc[mb][half * 8 + j] + bias;
-          if (a.add) v += nl_apply(addv[j], asc, ash, a.tadd.relu);
-          if (a.accumulate) v += oldv[j];
-          if (ok[j]) {
-            outb[ooff[j]] = v;
-            s_sum += v;
-            s_sq += v * v;
-          }
-        }
-      }
-    }
-    if (a.stats != nullptr) {
-      s_sum += __shfl_xor(s_sum, 32, 64);        // lanes l and l+32 hold the same column
-      s_sq += __shfl_xor(s_sq, 32, 64);
-      if (h == 0 && colok) {
-        const long long row = (long long)n * a.stats_rows_per_n +
-                              ((long long)cg.cidx * (a.tz * a.ty * a.tx) + cg.tile_in_n) * MG + mg;
-        a.stats[(row * 2 + 0) * a.Co + col] = s_sum;
-        a.stats[(row * 2 + 1) * a.Co + col] = s_sq;
-      }
-    }
-    if (dbg) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const long long te1 = (long long)__builtin_amdgcn_s_memtime();
-      dc_mfma += (te0 - tu0) - (dc_wait - dc_wait0);
-      dc_epi += te1 - te0;
-    }
-  }
-  if (dbg && tid == 0) { dbg[blockIdx.x * 8 + 3] = dc_wait; dbg[blockIdx.x * 8 + 4] = dc_mfma; dbg[blockIdx.x * 8 + 5] = dc_epi; }
-}
-
 // Reduce split-K slabs: sum over splits, then the same epilogue as above.
 // grid (tiles * MT/32, ceil(Np/32)); 256 threads = 8 row lanes x 32 columns, 4 rows per thread, i.e. one
 // block per 32 rows x 32 columns; each block writes ONE statistics row (rows per tile = MT/32).
@@ -1886,7 +1440,6 @@ struct Geometry {
   int tz, ty, tx, tiles_per_n, tiles, ncls;
   int nstages, ksplit, sps;
   int launches;
-  bool ws;        // producer / consumer kernel (bf16 operands)
   bool fused;     // class-fused kernel of the stride-2 transposed forms (its own tiling: coarse 4 x 4 x 8, one row per tile)
 };
 
@@ -1935,7 +1488,6 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   g.tiles = g.tiles_per_n * x->n * g.ncls;     // the parity classes share one launch
   g.nstages = (g.K + g.cfg.KCI - 1) / g.cfg.KCI;
   g.launches = 1;
-  g.ws = g.cfg.bf && (g_igemm_ws == 2 || (g_igemm_ws == 1 && g.cfg.NB == 4)) && !is_bf16(x) && !is_bf16(y);
   const int ncolgroups = (g.Np + 32 * g.cfg.NB - 1) / (32 * g.cfg.NB);
   const int wgs = g.tiles * ncolgroups;
   g.ksplit = 1;
@@ -1969,17 +1521,16 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
       g.ncls = 1;                                  // one statistics row per fused tile
       g.tiles = g.tiles_per_n * x->n;
       g.nstages = (g.K + 15) / 16;
-      g.ksplit = 1; g.sps = g.nstages; g.ws = false;
+      g.ksplit = 1; g.sps = g.nstages;
     }
   }
   return MMTTA_OK;
 }
 
 // statistics rows written per tile: 1 by the conv epilogue, MT/32 by the split-K finalize
-// (the producer / consumer kernel: one row per consumer wave group, 4 / NB of them)
 static int stats_rows_per_tile(const Geometry& g) {
   if (g.fused) return 1;
-  return g.ksplit > 1 ? g.cfg.TZ * g.cfg.TY * g.cfg.TX / 32 : (g.ws ? 4 / g.cfg.NB : 1);
+  return g.ksplit > 1 ? g.cfg.TZ * g.cfg.TY * g.cfg.TX / 32 : 1;
 }
 
 static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t) {
@@ -2016,12 +1567,6 @@ static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t
   t.zext = zmx - zmn; t.yext = ymx - ymn; t.xext = xmx - xmn;
 }
 
-// MMTTA_OPT_IGEMM_PRODUCER_CONSUMER: 0 never, 1 (default) the wide small-grid configurations (NB == 4: the 8^3 / 16^3
-// levels, where it measured 5-15 % faster), 2 every bf16 configuration (2x SLOWER on the 64^3 layers: four consumer waves
-// cannot issue the epilogue and the MFMA phases of a 512-voxel tile as fast as eight waves of two workgroups do)
-template <int NB>
-static bool ws_selected() { return g_igemm_ws == 2 || (g_igemm_ws == 1 && NB == 4); }
-
 template <int NB, int MB, int TZ, int TY, int TX, int KCI, bool BF, int OCC, bool ABF>
 static int launch_cfg_t(const GArgs& a_in, const Taps* ht, int tiles, hipStream_t s) {
   GArgs a = a_in;
@@ -2042,36 +1587,10 @@ static int launch_cfg_t(const GArgs& a_in, const Taps* ht, int tiles, hipStream_
   }
   if (lds < (4 * EPI_TILE_FLOATS + 4 * 2 * 32) * sizeof(float)) lds = (4 * EPI_TILE_FLOATS + 4 * 2 * 32) * sizeof(float);
   lds = (lds + 15) / 16 * 16;
-  const size_t lds_box = lds;
   a.coef_off = (int)(lds / sizeof(float));
   if (BF) lds += (size_t)2 * a.stages_per_split * KCI * sizeof(float);     // scale | shift of the staged channels
   MMTTA_CHECK(lds <= 160 * 1024, MMTTA_ERR_UNSUPPORTED, "conv: LDS box of %zu bytes exceeds 160 KiB", lds);
   int st;
-  if constexpr (BF) {
-    if (ws_selected<NB>() && !a.in_bf && !a.out_bf && 2 * lds_box + 4 * EPI_TILE_FLOATS * sizeof(float) <= 160 * 1024) {
-      // producer / consumer form: one 512-thread workgroup per CU, two LDS box buffers, a contiguous range of units each
-      MMTTA_CHECK(!a.add_bf, MMTTA_ERR_UNSUPPORTED, "conv (producer/consumer): bf16-stored epilogue operand");
-      auto kws = igemm_ws_kernel<NB, MB, TZ, TY, TX, KCI>;
-      static bool ws_attr_set = false;
-      if (!ws_attr_set) {
-        (void)hipFuncSetAttribute((const void*)kws, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        ws_attr_set = true;
-      }
-      const int ncolg = (a.Np + 32 * NB - 1) / (32 * NB);
-      const int nunits = tiles * ncolg * a.ksplit;
-      const int wgs = nunits < g_ws_workgroups ? nunits : g_ws_workgroups;
-      hipLaunchKernelGGL(kws, dim3(wgs), dim3(512), 2 * lds_box + 4 * EPI_TILE_FLOATS * sizeof(float), s, a, tiles, ncolg, nunits,
-                         (int)(lds_box / 2), (long long*)g_ws_debug);
-      st = launch_status("conv igemm (producer/consumer)");
-      if (st) return st;
-      if (a.ksplit > 1 && !g_profile_main_only) {
-        dim3 g2(tiles * (TZ * TY * TX / 32), (a.Np + 31) / 32);
-        hipLaunchKernelGGL((splitk_finalize_kernel<TZ, TY, TX, BF, ABF>), g2, dim3(256), 0, s, a, tiles);
-        st = launch_status("conv split-K finalize");
-      }
-      return st;
-    }
-  }
   auto kern = igemm_kernel<NB, MB, TZ, TY, TX, KCI, BF, OCC, ABF>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -2307,12 +1826,11 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   const int am = a.in_bf ? 8 : 4;
   const bool al = (((uintptr_t)x->ptr) % 16 == 0) && x->sw % am == 0 && x->sh % am == 0 && x->sd % am == 0 && x->sn % am == 0;
   a.vec4 = al ? 1 : 0;
-  a.pipeline = g_igemm_pipeline;
   {  // row-structured loader of the 3x3x3 stride-1 stages: 32-bit element offsets from 24-bit multiply-adds
     const int64_t lim24 = (int64_t)1 << 24;
     const int64_t last = (int64_t)(x->d - 1) * x->sd + (int64_t)(x->h - 1) * x->sh + (int64_t)(x->w - 1) * x->sw + x->c + 16;
     a.rowload = (al && x->sd < lim24 && x->sh < lim24 && x->sw < lim24 && x->d < lim24 && x->h < lim24 && x->w < lim24 &&
-                 last < ((int64_t)1 << 31) && (g_igemm_pipeline & 1)) ? 1 : 0;
+                 last < ((int64_t)1 << 31) && g_igemm_pipeline) ? 1 : 0;
   }
   Taps ht[8];
   a.ncls = g.classes ? 8 : 1;

@@ -235,43 +235,11 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
 // dw[cd][cg][tap] (+)= sum_sl slab[sl][tap][cg][cd]   (torch weight layout out of the [tap][cg][cd] slabs)
 // The transpose goes through LDS so that both sides stay coalesced: reads run along cd, writes are runs of
 // `ntaps` consecutive floats per (cd, cg).  27 taps: one block = one cg x 64 cd;  1 tap: 32 cg x 32 cd.
-// Optimizer fused into the reduction (mmtta_conv_wgrad_optim): the reduce kernels are the first place the COMPLETE weight
-// gradient exists, so they apply the parameter update there instead of writing dw for a later pass over the arena to read
-// back - the arithmetic of optim_kernel on the same fp32 value, element by element (bit-identical parameters), 8 of the
-// optimizer's 28 bytes per parameter never move, and the remaining 24 move inside small launches that overlap the
-// backward pass instead of in one chip-filling stream at the end of the step.  p == nullptr: plain reduction.
-struct FusedOpt {
-  float* p; float* m; float* v;      // parameter, first / second moment: the layout of dw
-  const int* step;
-  OptimArgs a;
-  int kind, decay;
-};
-
-__device__ __forceinline__ void fused_update(const FusedOpt& fo, long long idx, float g, float step_size, float bc2_sqrt, bool first) {
-  float pi = fo.p[idx], mi = 0.f, vi = 0.f;
-  const bool decay = fo.decay && fo.a.wd != 0.f;
-  if (fo.kind == 0) {
-    mi = fo.m[idx]; vi = fo.v[idx];
-    optim_update<0>(pi, g, mi, vi, decay, fo.a, step_size, bc2_sqrt, first);
-    fo.m[idx] = mi; fo.v[idx] = vi;
-  } else if (fo.kind == 1) {
-    mi = fo.m[idx]; vi = fo.v[idx];
-    optim_update<1>(pi, g, mi, vi, decay, fo.a, step_size, bc2_sqrt, first);
-    fo.m[idx] = mi; fo.v[idx] = vi;
-  } else {
-    if (fo.a.momentum != 0.f) mi = fo.m[idx];
-    optim_update<2>(pi, g, mi, vi, decay, fo.a, step_size, bc2_sqrt, first);
-    if (fo.a.momentum != 0.f) fo.m[idx] = mi;
-  }
-  fo.p[idx] = pi;
-}
-
 __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                              int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate,
                                                              const float* __restrict__ dbpart, float* __restrict__ db,
-                                                             int db_nsl, FusedOpt fo) {
+                                                             int db_nsl) {
   __shared__ float tile[32][28];
-  __shared__ float s_opt[2];
   const int cd0 = blockIdx.y * 32;
   if ((int)blockIdx.x == Cg) {
     // bias gradient rows ride in the same launch: db[cd] (+)= sum_sl dbpart[sl][cd]; 8 threads per channel
@@ -328,11 +296,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __rest
     const int i = threadIdx.x + 256 * it;
     if (i < 27 * 32) tile[i & 31][i >> 5] = live[it] ? acc[it] : 0.f;
   }
-  int t0 = 0;
-  if (fo.p != nullptr) {
-    t0 = *fo.step;
-    if (threadIdx.x == 0) optim_scalars(fo.kind, fo.a, t0, s_opt[0], s_opt[1]);
-  }
   __syncthreads();
   for (int i = threadIdx.x; i < 27 * 32; i += 256) {
     const int cdl = i / 27, tap = i % 27;
@@ -340,16 +303,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __rest
     if (cd < Cd) {
       const long long idx = ((long long)cd * Cg + cg) * 27 + tap;
       const float v = tile[cdl][tap];
-      if (fo.p != nullptr) fused_update(fo, idx, v, s_opt[0], s_opt[1], t0 == 0);
-      else dw[idx] = accumulate ? (dw[idx] + v) : v;
+      dw[idx] = accumulate ? (dw[idx] + v) : v;
     }
   }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                            int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate, FusedOpt fo) {
+                                                            int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate) {
   __shared__ float tile[32][33];
-  __shared__ float s_opt[2];
   const int cg0 = blockIdx.x * 32, cd0 = blockIdx.y * 32;
   for (int i = threadIdx.x; i < 32 * 32; i += 256) {
     const int cdl = i & 31, cgl = i >> 5;
@@ -358,19 +319,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restr
       for (int sl = 0; sl < nsl; ++sl) s += slab[((long long)sl * CGp + cg0 + cgl) * CDp + cd0 + cdl];
     tile[cdl][cgl] = s;
   }
-  int t0 = 0;
-  if (fo.p != nullptr) {
-    t0 = *fo.step;
-    if (threadIdx.x == 0) optim_scalars(fo.kind, fo.a, t0, s_opt[0], s_opt[1]);
-  }
   __syncthreads();
   for (int i = threadIdx.x; i < 32 * 32; i += 256) {
     const int cgl = i & 31, cdl = i >> 5;
     if (cg0 + cgl < Cg && cd0 + cdl < Cd) {
       const long long idx = (long long)(cd0 + cdl) * Cg + cg0 + cgl;
       const float v = tile[cdl][cgl];
-      if (fo.p != nullptr) fused_update(fo, idx, v, s_opt[0], s_opt[1], t0 == 0);
-      else dw[idx] = accumulate ? (dw[idx] + v) : v;
+      dw[idx] = accumulate ? (dw[idx] + v) : v;
     }
   }
 }
@@ -402,14 +357,7 @@ __global__ __launch_bounds__(64) void db_reduce_kernel(const float* __restrict__
   if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
 }
 
-// ------------------------------------------------------------------ bf16-operand weight gradient (27 taps)
-// Same decomposition as wgrad_f32_kernel, on v_mfma_f32_32x32x16_bf16.  The reduction index is the voxel, and a
-// bf16 fragment holds 8 CONSECUTIVE k per lane, so the LDS images are channel-major with 8-voxel x-rows:
-//   D tile  Dl[cd][xrow][8 x]                       (xrow = z*TY + y of the coarse tile)
-//   G box   Gl[dx][cg][(bz,by) row][8 x]            three x-shifted (and, for stride 2, de-interleaved) copies,
-//                                                   so that the 8 voxels a tap needs start 16-byte aligned
-// k16 step ks covers the two x-rows 2ks (lanes 0-31) and 2ks+1 (lanes 32-63).  Channel strides are an odd
-// number of 16-byte slots: the 16 lanes of a ds_read_b128 group hit 16 distinct slots.
+// ------------------------------------------------------------------ bf16 helpers of the matrix-core weight gradients
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int wpack2(float lo, float hi) {
@@ -417,408 +365,6 @@ __device__ __forceinline__ unsigned int wpack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned int, v);
 }
 
-template <int TZ, int TY, int SI>
-struct WBGeo {
-  static constexpr int TX = 8;
-  static constexpr int NXR = TZ * TY;                    // x-rows of the coarse tile
-  static constexpr int BZr = (TZ - 1) * SI + 3, BYr = (TY - 1) * SI + 3;
-  static constexpr int RG = BZr * BYr;                   // (z,y) rows of the gathered box
-  static constexpr int NX = 7 * SI + 3;                  // fine x positions a row needs
-  static constexpr int SLG = (RG + 1) | 1;               // slots per channel, odd
-  static constexpr int SLD = (NXR + 1) | 1;
-  static constexpr int CHS_G = SLG * 16, CHS_D = SLD * 16;     // bytes
-  static constexpr int COPY = 32 * CHS_G;
-  static constexpr int LDS_BYTES = 3 * COPY + 32 * CHS_D + 256 * 4;
-};
-
-template <int TZ, int TY, int SI, bool GBF = false, bool DBF = false>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WArgs a) {   // two workgroups per CU (LDS allows two)
-  using G = WBGeo<TZ, TY, SI>;
-  extern __shared__ float lds[];
-  unsigned char* lb = reinterpret_cast<unsigned char*>(lds);
-  unsigned char* gl = lb;                       // 3 copies
-  unsigned char* dl = lb + 3 * G::COPY;
-  float* dbred = reinterpret_cast<float*>(lb + 3 * G::COPY + 32 * G::CHS_D);   // [256]
-  constexpr int MT = G::NXR * 8;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, r = lane & 31;
-  const int cg0 = blockIdx.y * 32, cd0 = blockIdx.z * 32;
-  const int cs = tid & 31;                      // staging channel of this thread (256 % 32 == 0)
-
-  int toffb[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int tap = min(wave + 4 * j, 26);
-    toffb[j] = (tap % 3) * G::COPY + ((tap / 9) * G::BYr + ((tap / 3) % 3)) * 16;
-  }
-  f32x16 acc[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-  float dbsum = 0.f;
-
-  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);     // see wgrad_f32_kernel: one part of the volume per XCD
-  const int t0 = sx * a.tiles_per_split;
-  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
-  const int tpn = a.tz * a.ty * a.tx;
-  // Software pipeline over the tiles of this workgroup: the global loads of tile i+1 (the whole D tile and the first
-  // RB box rows per thread - all of them for stride 1) are issued right after tile i's LDS image is complete and land
-  // while its MFMAs run (the MFMA loop reads LDS only, so no vmcnt wait sits in between).  Loads are unconditional
-  // from clamped addresses and masked at commit time (a load inside a branch is waited for on the spot).
-  constexpr int ND = (G::NXR + 7) / 8;          // D x-rows per thread
-  constexpr int RB = SI == 1 ? 5 : 2;           // G box rows per thread and trip
-  const int gc = cg0 + cs, dc = cd0 + cs;
-  const bool gcok = gc < a.Cg, dcok = dc < a.Cd;
-  float gv[RB][G::NX], dv[ND][8];
-  float gsc = 0.f, gsh = 0.f, dsc = 0.f, dsh = 0.f;
-  int pn = 0, poz0 = 0, poy0 = 0, pox0 = 0;     // coordinates of the tile whose loads are in gv / dv
-
-  auto issue = [&](int tile) {
-    pn = tile / tpn;
-    int t = tile % tpn;
-    const int txi = t % a.tx; t /= a.tx;
-    const int tyi = t % a.ty;
-    const int tzi = t / a.ty;
-    poz0 = tzi * TZ; poy0 = tyi * TY; pox0 = txi * 8;
-    const int iz0 = poz0 * SI - 1, iy0 = poy0 * SI - 1, ix0 = pox0 * SI - 1;
-    nl_coeff_vec<1>(a.td, pn, a.Cd, dc, &dsc, &dsh);
-    nl_coeff_vec<1>(a.tg, pn, a.Cg, gc, &gsc, &gsh);
-    const long long dbo = (long long)pn * a.dsn + min(dc, a.Cd - 1);
-#pragma unroll
-    for (int q = 0; q < ND; ++q) {
-      const int xr = min((tid >> 5) + 8 * q, G::NXR - 1);
-      const long long rpo = dbo + (long long)min(poz0 + xr / TY, a.Dd - 1) * a.dsd + (long long)min(poy0 + xr % TY, a.Hd - 1) * a.dsh;
-#pragma unroll
-      for (int x = 0; x < 8; ++x) dv[q][x] = ld1_t<DBF>(a.dn, rpo + (long long)min(pox0 + x, a.Wd - 1) * a.dsw);
-    }
-    const long long gbo = (long long)pn * a.gsn + min(gc, a.Cg - 1);
-#pragma unroll
-    for (int q = 0; q < RB; ++q) {
-      const int row = min((tid >> 5) + 8 * q, G::RG - 1);
-      const int bz = row / G::BYr, by = row % G::BYr;
-      const long long rpo = gbo + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd + (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
-#pragma unroll
-      for (int x = 0; x < G::NX; ++x) gv[q][x] = ld1_t<GBF>(a.g, rpo + (long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw);
-    }
-  };
-  // transform + pack + LDS write of RB box rows starting at row0 (values in v)
-  auto commit_g = [&](float (&v)[RB][G::NX], int row0, int iz0, int iy0, int ix0) {
-#pragma unroll
-    for (int q = 0; q < RB; ++q) {
-      const int row = row0 + 8 * q;
-      if (row < G::RG) {
-        const int bz = row / G::BYr, by = row % G::BYr;
-        const int iz = iz0 + bz, iy = iy0 + by;
-        const bool rok = gcok && (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg;
-#pragma unroll
-        for (int x = 0; x < G::NX; ++x) {
-          const int ix = ix0 + x;
-          v[q][x] = (rok && (unsigned)ix < (unsigned)a.Wgg) ? nl_apply(v[q][x], gsc, gsh, a.tg.relu) : 0.f;
-        }
-#pragma unroll
-        for (int dxi = 0; dxi < 3; ++dxi) {
-          uint4 pk;
-          pk.x = wpack2(v[q][0 * SI + dxi], v[q][1 * SI + dxi]); pk.y = wpack2(v[q][2 * SI + dxi], v[q][3 * SI + dxi]);
-          pk.z = wpack2(v[q][4 * SI + dxi], v[q][5 * SI + dxi]); pk.w = wpack2(v[q][6 * SI + dxi], v[q][7 * SI + dxi]);
-          *reinterpret_cast<uint4*>(gl + dxi * G::COPY + cs * G::CHS_G + row * 16) = pk;
-        }
-      }
-    }
-  };
-
-  if (t0 < t1) issue(t0);
-  for (int tile = t0; tile < t1; ++tile) {
-    const int n = pn, oz0 = poz0, oy0 = poy0, ox0 = pox0;
-    const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
-    commit_g(gv, tid >> 5, iz0, iy0, ix0);                       // the prefetched trip
-    if (8 * RB < G::RG) {                                        // stride 2: the remaining box rows, RB at a time
-      const long long gbo = (long long)n * a.gsn + min(gc, a.Cg - 1);
-      for (int row0 = (tid >> 5) + 8 * RB; row0 < G::RG; row0 += 8 * RB) {
-        float v[RB][G::NX];
-#pragma unroll
-        for (int q = 0; q < RB; ++q) {
-          const int row = min(row0 + 8 * q, G::RG - 1);
-          const int bz = row / G::BYr, by = row % G::BYr;
-          const long long rpo = gbo + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd +
-                                (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
-#pragma unroll
-          for (int x = 0; x < G::NX; ++x) v[q][x] = ld1_t<GBF>(a.g, rpo + (long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw);
-        }
-        commit_g(v, row0, iz0, iy0, ix0);
-      }
-    }
-    {  // ---- D tile: thread = (channel, x-row)
-#pragma unroll
-      for (int q = 0; q < ND; ++q) {
-        const int xr = (tid >> 5) + 8 * q;
-        if (xr < G::NXR) {
-          const int oz = oz0 + xr / TY, oy = oy0 + xr % TY;
-          const bool rok = dcok && oz < a.Dd && oy < a.Hd;
-#pragma unroll
-          for (int x = 0; x < 8; ++x) {
-            dv[q][x] = (rok && ox0 + x < a.Wd) ? nl_apply(dv[q][x], dsc, dsh, a.td.relu) : 0.f;
-            dbsum += dv[q][x];
-          }
-          uint4 pk;
-          pk.x = wpack2(dv[q][0], dv[q][1]); pk.y = wpack2(dv[q][2], dv[q][3]);
-          pk.z = wpack2(dv[q][4], dv[q][5]); pk.w = wpack2(dv[q][6], dv[q][7]);
-          *reinterpret_cast<uint4*>(dl + cs * G::CHS_D + xr * 16) = pk;
-        }
-      }
-    }
-    __syncthreads();
-    if (tile + 1 < t1) issue(tile + 1);                          // lands during the MFMAs below
-#pragma unroll 2
-    for (int ks = 0; ks < G::NXR / 2; ++ks) {
-      const int xr = 2 * ks + h;
-      const int z = xr / TY, y = xr % TY;
-      const uint4 bq = *reinterpret_cast<const uint4*>(dl + r * G::CHS_D + xr * 16);
-      const unsigned char* ga = gl + r * G::CHS_G + ((z * SI) * G::BYr + y * SI) * 16;
-      uint4 aq[7];
-#pragma unroll
-      for (int j = 0; j < 7; ++j) aq[j] = *reinterpret_cast<const uint4*>(ga + toffb[j]);
-      const wbf16x8 bfrag = __builtin_bit_cast(wbf16x8, bq);
-#pragma unroll
-      for (int j = 0; j < 7; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, aq[j]), bfrag, acc[j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  (void)MT;
-  const int sl = blockIdx.x;
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int tap = wave + 4 * j;
-    if (tap < 27) {
-      float* sb = a.slab + (((long long)sl * 27 + tap) * a.CGp + cg0) * a.CDp + cd0 + r;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        sb[(long long)row * a.CDp] = acc[j][i];
-      }
-    }
-  }
-  if (a.dbpart != nullptr && blockIdx.y == 0) {     // bias gradient from the fp32 values seen while staging
-    dbred[tid] = dbsum;
-    __syncthreads();
-    if (tid < 32) {
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) s += dbred[q * 32 + tid];
-      a.dbpart[(long long)sl * a.CDp + cd0 + tid] = s;
-    }
-  }
-}
-
-template <int TZ, int TY, int SI, bool GBF, bool DBF>
-static int launch_wgrad_bf16_t(const WArgs& a, int S, hipStream_t s) {
-  using G = WBGeo<TZ, TY, SI>;
-  auto kern = wgrad_bf16_kernel<TZ, TY, SI, GBF, DBF>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  dim3 grid(S, a.CGp / 32, a.CDp / 32);
-  hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, s, a);
-  return launch_status("conv wgrad bf16");
-}
-
-// The same kernel with VECTOR staging loads (16-byte-aligned tensors: every pooled buffer).  Above, a thread owns one
-// channel and fetches its voxels one 4-byte (bf16 storage: 2-byte) element at a time - 66 load instructions per thread
-// and tile, and the staging is bound by their count, not by bytes (measured: bf16 storage, half the bytes, made that
-// kernel 8-19 % SLOWER).  Here a thread owns FOUR channels (cq = tid & 7) of one box row (rt = tid >> 3, 32 rows per
-// pass): NX loads of 16 bytes (8 bytes for bf16 storage) per row instead of 4 x NX scalar ones, then 4 channels x 3
-// x-shifted copies = 12 LDS writes of 16 bytes.  The D tile: (channel group, x-row half): 4 loads, 4 LDS writes of 8
-// bytes.  Same LDS images, same MFMA loop, same slabs: results are bit-identical to the scalar loader.
-template <int TZ, int TY, int SI, bool GBF, bool DBF>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16v_kernel(WArgs a) {
-  using G = WBGeo<TZ, TY, SI>;
-  extern __shared__ float lds[];
-  unsigned char* lb = reinterpret_cast<unsigned char*>(lds);
-  unsigned char* gl = lb;                       // 3 copies
-  unsigned char* dl = lb + 3 * G::COPY;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, r = lane & 31;
-  const int cg0 = blockIdx.y * 32, cd0 = blockIdx.z * 32;
-  const int cq = tid & 7, rt = tid >> 3;        // staging: channel group (4 channels), row slot
-
-  int toffb[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int tap = min(wave + 4 * j, 26);
-    toffb[j] = (tap % 3) * G::COPY + ((tap / 9) * G::BYr + ((tap / 3) % 3)) * 16;
-  }
-  f32x16 acc[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-  float dbs[4] = {0.f, 0.f, 0.f, 0.f};
-
-  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
-  const int t0 = sx * a.tiles_per_split;
-  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
-  const int tpn = a.tz * a.ty * a.tx;
-  constexpr int NPASS = (G::RG + 31) / 32;      // box rows: 32 per pass
-  const int gcb = cg0 + 4 * cq, dcb = cd0 + 4 * cq;
-  const int gcl = min(gcb, (a.Cg - 1) & ~3), dcl = min(dcb, (a.Cd - 1) & ~3);     // clamped (always valid) load channels
-  float4 dv[4];                                 // the prefetched D half row (the box rows are loaded per pass: registers)
-  float gsc[4], gsh[4], dsc[4], dsh[4];
-  int pn = 0, poz0 = 0, poy0 = 0, pox0 = 0;
-  const int dxr = rt >> 1, dhalf = rt & 1;      // D item of this thread: x-row, half (4 voxels)
-
-  auto load_g_row = [&](float4 (&v)[G::NX], int n, int row, int iz0, int iy0, int ix0) {
-    const int rowc = min(row, G::RG - 1);
-    const int bz = rowc / G::BYr, by = rowc % G::BYr;
-    const long long rpo = (long long)n * a.gsn + gcl + (long long)min(max(iz0 + bz, 0), a.Dgg - 1) * a.gsd +
-                          (long long)min(max(iy0 + by, 0), a.Hgg - 1) * a.gsh;
-#pragma unroll
-    for (int x = 0; x < G::NX; ++x) v[x] = ld4_t<GBF>(a.g, rpo + (long long)min(max(ix0 + x, 0), a.Wgg - 1) * a.gsw);
-  };
-  auto commit_g_row = [&](float4 (&v)[G::NX], int row, int iz0, int iy0, int ix0) {
-    if (row >= G::RG) return;
-    const int bz = row / G::BYr, by = row % G::BYr;
-    const int iz = iz0 + bz, iy = iy0 + by;
-    const bool rok = (unsigned)iz < (unsigned)a.Dgg && (unsigned)iy < (unsigned)a.Hgg;
-    // transform in place (no second register array), then pack per channel and x shift
-#pragma unroll
-    for (int x = 0; x < G::NX; ++x) {
-      const bool ok = rok && (unsigned)(ix0 + x) < (unsigned)a.Wgg;
-      v[x].x = (ok && gcb + 0 < a.Cg) ? nl_apply(v[x].x, gsc[0], gsh[0], a.tg.relu) : 0.f;
-      v[x].y = (ok && gcb + 1 < a.Cg) ? nl_apply(v[x].y, gsc[1], gsh[1], a.tg.relu) : 0.f;
-      v[x].z = (ok && gcb + 2 < a.Cg) ? nl_apply(v[x].z, gsc[2], gsh[2], a.tg.relu) : 0.f;
-      v[x].w = (ok && gcb + 3 < a.Cg) ? nl_apply(v[x].w, gsc[3], gsh[3], a.tg.relu) : 0.f;
-    }
-    unsigned char* gdst = gl + (4 * cq) * G::CHS_G + row * 16;
-#pragma unroll
-    for (int dxi = 0; dxi < 3; ++dxi) {
-      uint4 p0, p1, p2, p3;
-      p0.x = wpack2(v[0 * SI + dxi].x, v[1 * SI + dxi].x); p0.y = wpack2(v[2 * SI + dxi].x, v[3 * SI + dxi].x);
-      p0.z = wpack2(v[4 * SI + dxi].x, v[5 * SI + dxi].x); p0.w = wpack2(v[6 * SI + dxi].x, v[7 * SI + dxi].x);
-      p1.x = wpack2(v[0 * SI + dxi].y, v[1 * SI + dxi].y); p1.y = wpack2(v[2 * SI + dxi].y, v[3 * SI + dxi].y);
-      p1.z = wpack2(v[4 * SI + dxi].y, v[5 * SI + dxi].y); p1.w = wpack2(v[6 * SI + dxi].y, v[7 * SI + dxi].y);
-      p2.x = wpack2(v[0 * SI + dxi].z, v[1 * SI + dxi].z); p2.y = wpack2(v[2 * SI + dxi].z, v[3 * SI + dxi].z);
-      p2.z = wpack2(v[4 * SI + dxi].z, v[5 * SI + dxi].z); p2.w = wpack2(v[6 * SI + dxi].z, v[7 * SI + dxi].z);
-      p3.x = wpack2(v[0 * SI + dxi].w, v[1 * SI + dxi].w); p3.y = wpack2(v[2 * SI + dxi].w, v[3 * SI + dxi].w);
-      p3.z = wpack2(v[4 * SI + dxi].w, v[5 * SI + dxi].w); p3.w = wpack2(v[6 * SI + dxi].w, v[7 * SI + dxi].w);
-      *reinterpret_cast<uint4*>(gdst + dxi * G::COPY + 0 * G::CHS_G) = p0;
-      *reinterpret_cast<uint4*>(gdst + dxi * G::COPY + 1 * G::CHS_G) = p1;
-      *reinterpret_cast<uint4*>(gdst + dxi * G::COPY + 2 * G::CHS_G) = p2;
-      *reinterpret_cast<uint4*>(gdst + dxi * G::COPY + 3 * G::CHS_G) = p3;
-    }
-  };
-  auto issue = [&](int tile) {
-    pn = tile / tpn;
-    int t = tile % tpn;
-    const int txi = t % a.tx; t /= a.tx;
-    const int tyi = t % a.ty;
-    const int tzi = t / a.ty;
-    poz0 = tzi * TZ; poy0 = tyi * TY; pox0 = txi * 8;
-    nl_coeff_vec<4>(a.td, pn, a.Cd, dcb, dsc, dsh);
-    nl_coeff_vec<4>(a.tg, pn, a.Cg, gcb, gsc, gsh);
-    const int xr = min(dxr, G::NXR - 1);
-    const long long dpo = (long long)pn * a.dsn + dcl + (long long)min(poz0 + xr / TY, a.Dd - 1) * a.dsd +
-                          (long long)min(poy0 + xr % TY, a.Hd - 1) * a.dsh;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) dv[x] = ld4_t<DBF>(a.dn, dpo + (long long)min(pox0 + 4 * dhalf + x, a.Wd - 1) * a.dsw);
-  };
-
-  if (t0 < t1) issue(t0);
-  for (int tile = t0; tile < t1; ++tile) {
-    const int n = pn, oz0 = poz0, oy0 = poy0, ox0 = pox0;
-    const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
-#pragma unroll 1
-    for (int p = 0; p < NPASS; ++p) {                            // 32 box rows per pass
-      if (rt + 32 * p < G::RG) {
-        float4 v[G::NX];
-        load_g_row(v, n, rt + 32 * p, iz0, iy0, ix0);
-        commit_g_row(v, rt + 32 * p, iz0, iy0, ix0);
-      }
-    }
-    if (dxr < G::NXR) {  // ---- D tile: thread = (channel group, x-row, half)
-      const int oz = oz0 + dxr / TY, oy = oy0 + dxr % TY;
-      const bool rok = oz < a.Dd && oy < a.Hd;
-      float w[4][4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const bool ok = rok && ox0 + 4 * dhalf + x < a.Wd;
-        const float raw[4] = {dv[x].x, dv[x].y, dv[x].z, dv[x].w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          w[c][x] = (ok && dcb + c < a.Cd) ? nl_apply(raw[c], dsc[c], dsh[c], a.td.relu) : 0.f;
-          dbs[c] += w[c][x];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint2 pk;
-        pk.x = wpack2(w[c][0], w[c][1]); pk.y = wpack2(w[c][2], w[c][3]);
-        *reinterpret_cast<uint2*>(dl + (4 * cq + c) * G::CHS_D + dxr * 16 + dhalf * 8) = pk;
-      }
-    }
-    __syncthreads();
-    if (tile + 1 < t1) issue(tile + 1);                          // lands during the MFMAs below
-#pragma unroll 2
-    for (int ks = 0; ks < G::NXR / 2; ++ks) {
-      const int xr = 2 * ks + h;
-      const int z = xr / TY, y = xr % TY;
-      const uint4 bq = *reinterpret_cast<const uint4*>(dl + r * G::CHS_D + xr * 16);
-      const unsigned char* ga = gl + r * G::CHS_G + ((z * SI) * G::BYr + y * SI) * 16;
-      uint4 aq[7];
-#pragma unroll
-      for (int j = 0; j < 7; ++j) aq[j] = *reinterpret_cast<const uint4*>(ga + toffb[j]);
-      const wbf16x8 bfrag = __builtin_bit_cast(wbf16x8, bq);
-#pragma unroll
-      for (int j = 0; j < 7; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, aq[j]), bfrag, acc[j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  const int sl = blockIdx.x;
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int tap = wave + 4 * j;
-    if (tap < 27) {
-      float* sb = a.slab + (((long long)sl * 27 + tap) * a.CGp + cg0) * a.CDp + cd0 + r;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        sb[(long long)row * a.CDp] = acc[j][i];
-      }
-    }
-  }
-  if (a.dbpart != nullptr && blockIdx.y == 0) {     // bias gradient from the fp32 values seen while staging
-    float* red4 = lds;                              // the images are dead: the loop ended with a barrier
-#pragma unroll
-    for (int c = 0; c < 4; ++c) red4[tid * 4 + c] = dbs[c];
-    __syncthreads();
-    if (tid < 32) {
-      float sacc = 0.f;
-#pragma unroll 8
-      for (int q = 0; q < 32; ++q) sacc += red4[((q << 3) | (tid >> 2)) * 4 + (tid & 3)];
-      a.dbpart[(long long)sl * a.CDp + cd0 + tid] = sacc;
-    }
-  }
-}
-
-template <int TZ, int TY, int SI, bool GBF, bool DBF>
-static int launch_wgrad_bf16v_t(const WArgs& a, int S, hipStream_t s) {
-  using G = WBGeo<TZ, TY, SI>;
-  auto kern = wgrad_bf16v_kernel<TZ, TY, SI, GBF, DBF>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  dim3 grid(S, a.CGp / 32, a.CDp / 32);
-  const size_t ldsb = G::LDS_BYTES > 4096 ? G::LDS_BYTES : 4096;
-  hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, s, a);
-  return launch_status("conv wgrad bf16 (vector staging)");
-}
 
 // ------------------------------------------------------------------ transposed-read weight gradient (bf16 operands)
 // The kernels above keep the contraction index (voxels) contiguous per lane by transposing while staging: a thread owns
@@ -1322,31 +868,12 @@ static int launch_wgrad_tr(const WArgs& a, int S, hipStream_t s) {
   return launch_wgrad_tr_t<TZ, TY, SI, false, false, false>(a, S, s);
 }
 
-// one instantiation per storage combination (the forward activation may be bf16-stored, the gradient never is)
-template <int TZ, int TY, int SI>
-static int launch_wgrad_bf16(const WArgs& a, int S, hipStream_t s) {
-  MMTTA_CHECK(!(a.g_bf && a.d_bf), MMTTA_ERR_UNSUPPORTED, "wgrad: both operands bf16-stored");
-  // MMTTA_OPT_WGRAD_VECTOR_STAGING = 2: the staging-transposed kernel with 4-channel vector loads (measured,
-  // profiles/r02_wgrad_vector.txt: 1116 us of weight gradient per step either storage; the element loader 1075 us with
-  // fp32 storage, 1189 us with bf16 storage; the transposed-read kernel 1090 us with bf16 storage, 1204 us with fp32)
-  if (a.gvec4 && a.dvec4 && g_wgrad_vec == 2) {
-    if (a.g_bf) return launch_wgrad_bf16v_t<TZ, TY, SI, true, false>(a, S, s);
-    if (a.d_bf) return launch_wgrad_bf16v_t<TZ, TY, SI, false, true>(a, S, s);
-    return launch_wgrad_bf16v_t<TZ, TY, SI, false, false>(a, S, s);
-  }
-  if (a.g_bf) return launch_wgrad_bf16_t<TZ, TY, SI, true, false>(a, S, s);
-  if (a.d_bf) return launch_wgrad_bf16_t<TZ, TY, SI, false, true>(a, S, s);
-  return launch_wgrad_bf16_t<TZ, TY, SI, false, false>(a, S, s);
-}
-
 // ------------------------------------------------------------------ small-channel weight gradient
 // When one side of the layer has <= 4 channels (first layers: Cin = 1..4; last layers: Cout = 1..3) the
 // 32x32 (cg x cd) blocking above would pad it 8-32x.  Here the small tensor Q is the GATHERED one and its
 // (tap, channel) pairs are flattened into the MFMA row index (27*4 = 108 <= 128 rows = 4 waves x 32), the
 // big tensor P is dense:      S[row=(tap,cs)][col=cb] = sum_o T(Q[o*si + tap - 1][cs]) * T(P[o][cb])
 // One MFMA per voxel pair and wave instead of seven, and no padded channels.
-typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
-
 struct W2Args {
   const float* q; long long qsn, qsd, qsh, qsw; int Cs, Dq, Hq, Wq; NL tq;
   const float* p; long long psn, psd, psh, psw; int Cb, Dp, Hp, Wp; NL tp;
@@ -1876,7 +1403,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.small = false; w.bf16 = false; w.small_is_cd = 0; w.q = w.pb = nullptr; w.q_is_x = false;
   if (!w.convt && d->cin <= 4) { w.small = true; w.q = x; w.pb = dy; w.q_is_x = true; }
   else if (!w.convt && d->cout <= 4 && d->ksize == 1 &&
-           !(d->dtype == MMTTA_BF16 && d->cin >= 16 && wtr_ok(x) && wtr_ok(dy) && !is_bf16(dy) && (g_wgrad_vec == 1 || g_wgrad_vec == 3))) {
+           !(d->dtype == MMTTA_BF16 && d->cin >= 16 && wtr_ok(x) && wtr_ok(dy) && !is_bf16(dy) && g_wgrad_vec)) {
     // (in bf16 precision the 1x1x1 streaming kernel below takes these heads too: N padded to 32 costs nothing there)
     w.small = true; w.q = dy; w.pb = x; w.small_is_cd = 1;
   }
@@ -1904,14 +1431,16 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     else { w.colsum_blocks = (int64_t)dy->n * channel_partial_rows(dy); w.db_floats = w.colsum_blocks * 2 * dy->c; }
     return MMTTA_OK;
   }
-  w.bf16 = d->dtype == MMTTA_BF16 && w.ntaps == 27;
-  w.tr = w.bf16 && wtr_ok(w.g) && wtr_ok(w.dn) && !(w.convt && is_bf16(w.g)) && !(!w.convt && is_bf16(w.dn)) &&
-         (g_wgrad_vec == 1 || g_wgrad_vec == 3);
+  // bf16 operands: the transposed-read kernel, for operand pairs that admit its 16-byte items; anything else (ragged
+  // channel slices, MMTTA_OPT_WGRAD_VECTOR_STAGING = 0) computes on the fp32-operand kernel
+  w.tr = d->dtype == MMTTA_BF16 && w.ntaps == 27 && wtr_ok(w.g) && wtr_ok(w.dn) && !(w.convt && is_bf16(w.g)) &&
+         !(!w.convt && is_bf16(w.dn)) && g_wgrad_vec;
+  w.bf16 = w.tr;
   w.tr1 = !w.convt && d->dtype == MMTTA_BF16 && w.ntaps == 1 && w.si == 1 && wtr_ok(w.g) && wtr_ok(w.dn) && !is_bf16(w.dn) &&
-          (g_wgrad_vec == 1 || g_wgrad_vec == 3);
+          g_wgrad_vec;
   if ((w.tr && w.si == 1) || w.tr1) { w.TZ = 4; w.TY = 8; w.TX = 8; }
   else if (w.si == 1) { w.TZ = 4; w.TY = 4; w.TX = 8; }
-  else if (w.bf16) { w.TZ = 2; w.TY = 4; w.TX = 8; }
+  else if (w.tr) { w.TZ = 2; w.TY = 4; w.TX = 8; }
   else { w.TZ = 2; w.TY = 2; w.TX = 8; }
   w.tz = (w.dn->d + w.TZ - 1) / w.TZ;
   w.ty = (w.dn->h + w.TY - 1) / w.TY;
@@ -1986,20 +1515,17 @@ extern "C" int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* d, const mmtta_ten
   if (w.small) return 3;
   if (w.tr1) return 9;
   if (w.tr) return w.si == 1 ? 7 : 8;
-  if (w.bf16) return w.si == 1 ? 4 : 5;
   if (w.ntaps == 1) return 2;
   return w.si == 1 ? 0 : 1;
 }
 
 static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
                            const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
-                           int64_t workspace_bytes, void* stream, const FusedOpt& fo) {
+                           int64_t workspace_bytes, void* stream) {
   WGeo w;
   int st = wgeometry(d, x, dy, w);
   if (st) return st;
-  MMTTA_CHECK(dw != nullptr || fo.p != nullptr, MMTTA_ERR_INVALID, "wgrad: null dw");
-  MMTTA_CHECK(fo.p == nullptr || (!w.tiny && !w.small && !accumulate), MMTTA_ERR_UNSUPPORTED,
-              "wgrad + optimizer: only the slab-reduced layers (more than 4 channels on both sides), without accumulate");
+  MMTTA_CHECK(dw != nullptr, MMTTA_ERR_INVALID, "wgrad: null dw");
   const int64_t need = (w.slab_floats + w.db_floats + w.pre_floats) * 4;
   MMTTA_CHECK(workspace != nullptr && workspace_bytes >= need, MMTTA_ERR_WORKSPACE, "wgrad: workspace %lld bytes, need %lld",
               (long long)workspace_bytes, (long long)need);
@@ -2110,7 +1636,6 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
   a.dvec4 = wvec_ok(w.dn) ? 1 : 0;
   if (w.tr1) st = launch_wgrad_tr1(a, w.S, s);
   else if (w.tr) st = (w.si == 1) ? launch_wgrad_tr<4, 8, 1>(a, w.S, s) : launch_wgrad_tr<2, 4, 2>(a, w.S, s);
-  else if (w.bf16) st = (w.si == 1) ? launch_wgrad_bf16<4, 4, 1>(a, w.S, s) : launch_wgrad_bf16<2, 4, 2>(a, w.S, s);
   else if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, w.S, s);
   else st = (w.si == 1) ? launch_wgrad<4, 4, 8, 7>(a, w.S, s) : launch_wgrad<2, 2, 8, 7>(a, w.S, s);
   if (st || g_profile_main_only) return st;
@@ -2128,10 +1653,10 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
   const bool db_here = db != nullptr && !w.convt;      // bias partials written by the main kernel: [nsl][CDp]
   if (w.ntaps == 27)
     hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3(a.Cg + (db_here ? 1 : 0), (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
-                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, dbws, db, w.nsl, fo);
+                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, dbws, db, w.nsl);
   else
     hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((a.Cg + 31) / 32, (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
-                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, fo);
+                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate);
   st = launch_status("wgrad reduce");
   if (st) return st;
   if (db != nullptr) {
@@ -2153,32 +1678,5 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
 extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
                                 const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
                                 int64_t workspace_bytes, void* stream) {
-  FusedOpt fo;
-  fo.p = fo.m = fo.v = nullptr; fo.step = nullptr; fo.kind = 0; fo.decay = 0;
-  fo.a = OptimArgs{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
-  return conv_wgrad_impl(d, x, x_norm, dy, dw, db, accumulate, workspace, workspace_bytes, stream, fo);
-}
-
-// 1 when mmtta_conv_wgrad_optim can take this layer (its weight gradient goes through the slab reduce kernels), else 0
-extern "C" int mmtta_conv_wgrad_fusable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* dy) {
-  WGeo w;
-  const int st = wgeometry(d, x, dy, w);
-  if (st) return st < 0 ? st : -st;
-  return (!w.tiny && !w.small) ? 1 : 0;
-}
-
-extern "C" int mmtta_conv_wgrad_optim(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
-                                      const mmtta_tensor* dy, float* db, void* workspace, int64_t workspace_bytes,
-                                      const mmtta_optim_desc* opt, float* param, float* exp_avg, float* exp_avg_sq,
-                                      const int32_t* step, int decay, void* stream) {
-  MMTTA_CHECK(opt != nullptr && param != nullptr && step != nullptr, MMTTA_ERR_INVALID, "wgrad + optimizer: null argument");
-  MMTTA_CHECK(opt->kind == MMTTA_OPTIM_SGD ? (opt->momentum == 0.f || exp_avg != nullptr) : (exp_avg != nullptr && exp_avg_sq != nullptr),
-              MMTTA_ERR_INVALID, "wgrad + optimizer: missing optimizer state buffers");
-  if (opt->kind == MMTTA_OPTIM_SGD)
-    MMTTA_CHECK(!(opt->nesterov && (opt->momentum <= 0.f || opt->dampening != 0.f)), MMTTA_ERR_INVALID,
-                "optimizer: nesterov needs momentum > 0 and zero dampening (torch.optim.SGD raises the same)");
-  FusedOpt fo;
-  fo.p = param; fo.m = exp_avg; fo.v = exp_avg_sq; fo.step = step; fo.kind = opt->kind; fo.decay = decay ? 1 : 0;
-  fo.a = OptimArgs{opt->lr, opt->beta1, opt->beta2, opt->eps, opt->weight_decay, opt->momentum, opt->dampening, opt->nesterov};
-  return conv_wgrad_impl(d, x, x_norm, dy, nullptr, db, 0, workspace, workspace_bytes, stream, fo);
+  return conv_wgrad_impl(d, x, x_norm, dy, dw, db, accumulate, workspace, workspace_bytes, stream);
 }

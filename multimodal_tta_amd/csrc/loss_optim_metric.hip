@@ -140,7 +140,7 @@ static int entropy_blocks(const mmtta_tensor* z) {
 // nesterov).  One thread owns 4 consecutive parameters (16-byte accesses; the arena keeps every parameter and both
 // segment boundaries 16-byte aligned), the decay / no-decay split is the segment boundary n_decay
 // (reference src/core/experiment_manager.py:199-237).
-// OptimArgs / optim_update / optim_scalars: common.h (shared with the fused weight-gradient reduce kernels)
+// OptimArgs / optim_update / optim_scalars: common.h
 
 template <int KIND>
 __global__ __launch_bounds__(256) void optim_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -408,7 +408,7 @@ extern "C" int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const
 }
 
 static int optim_launch(int kind, float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, const OptimArgs& a,
-                        int32_t* step, hipStream_t s, bool advance = true) {
+                        int32_t* step, hipStream_t s) {
   MMTTA_CHECK(p && g && m && step && n >= 0 && n_decay >= 0 && n_decay <= n, MMTTA_ERR_INVALID, "optimizer: bad argument");
   MMTTA_CHECK(kind == MMTTA_OPTIM_SGD || v != nullptr, MMTTA_ERR_INVALID, "optimizer: Adam/AdamW need the second-moment buffer");
   MMTTA_CHECK(kind >= MMTTA_OPTIM_ADAM && kind <= MMTTA_OPTIM_SGD, MMTTA_ERR_INVALID, "optimizer: kind %d", kind);
@@ -425,7 +425,7 @@ static int optim_launch(int kind, float* p, const float* g, float* m, float* v, 
   else
     hipLaunchKernelGGL(optim_kernel<2>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step);
   int st = launch_status("optimizer");
-  if (st || !advance) return st;
+  if (st) return st;
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
   return launch_status("optimizer step counter");
 }
@@ -444,24 +444,6 @@ extern "C" int mmtta_optim_step(const mmtta_optim_desc* d, float* p, const float
     MMTTA_CHECK(!(d->nesterov && (d->momentum <= 0.f || d->dampening != 0.f)), MMTTA_ERR_INVALID,
                 "optimizer: nesterov needs momentum > 0 and zero dampening (torch.optim.SGD raises the same)");
   return optim_launch(d->kind, p, g, m, v, n, n_decay, a, step, (hipStream_t)stream);
-}
-
-// one RANGE of the parameters without advancing the step counter (the ranges a fused weight-gradient launch did not
-// update; the last range, or mmtta_optim_advance, advances it)
-extern "C" int mmtta_optim_step_partial(const mmtta_optim_desc* d, float* p, const float* g, float* m, float* v, int64_t n,
-                                        int64_t n_decay, int32_t* step, void* stream) {
-  MMTTA_CHECK(d != nullptr, MMTTA_ERR_INVALID, "optimizer: null desc");
-  OptimArgs a{d->lr, d->beta1, d->beta2, d->eps, d->weight_decay, d->momentum, d->dampening, d->nesterov};
-  if (d->kind == MMTTA_OPTIM_SGD)
-    MMTTA_CHECK(!(d->nesterov && (d->momentum <= 0.f || d->dampening != 0.f)), MMTTA_ERR_INVALID,
-                "optimizer: nesterov needs momentum > 0 and zero dampening (torch.optim.SGD raises the same)");
-  return optim_launch(d->kind, p, g, m, v, n, n_decay, a, step, (hipStream_t)stream, false);
-}
-
-extern "C" int mmtta_optim_advance(int32_t* step, void* stream) {
-  MMTTA_CHECK(step != nullptr, MMTTA_ERR_INVALID, "optimizer: null step counter");
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
-  return launch_status("optimizer step counter");
 }
 
 extern "C" int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label, float threshold, int64_t* counts,

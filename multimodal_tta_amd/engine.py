@@ -42,7 +42,6 @@ class ParamRef:
         self.group = GROUP_DECAY
         self.data: Optional[torch.Tensor] = None
         self.grad: Optional[torch.Tensor] = None
-        self.fused = False       # updated by a fused weight-gradient + optimizer launch (Runtime.fused_opt): no gradient kept
 
     @property
     def trainable(self) -> bool:
@@ -102,20 +101,6 @@ class Arena:
 
     def zero_grad(self) -> None:
         self.grads.zero_()
-
-    def unfused_ranges(self):
-        """[(begin, end, decays)] of the trainable parameters no fused launch updated in the last backward pass, adjacent
-        ranges of one group merged."""
-        out = []
-        for r in sorted(self.refs, key=lambda r: r.offset):
-            if not r.trainable or r.fused:
-                continue
-            a, b, dec = r.offset, r.offset + (r.numel + 3) // 4 * 4, r.group == GROUP_DECAY
-            if out and out[-1][1] == a and out[-1][2] == dec:
-                out[-1] = (out[-1][0], b, dec)
-            else:
-                out.append((a, b, dec))
-        return out
 
     def publish_grads(self) -> None:
         """Expose gradients as ``param.grad`` for external torch optimizers (drop-in run_step path)."""
@@ -210,7 +195,6 @@ class ConvLayer:
     def __init__(self, op: ConvOp, weight: ParamRef, bias: Optional[ParamRef], rt: Optional["Runtime"] = None):
         self.op, self.weight, self.bias, self.rt = op, weight, bias, rt
         self.side_index = 0          # which side stream takes this layer's weight gradient (Runtime.make_conv)
-        self._fusable: Optional[bool] = None
 
     def pack(self) -> None:
         self.op.pack(self.weight.data)
@@ -219,22 +203,6 @@ class ConvLayer:
         return self.bias.data if self.bias is not None else None
 
     def _wgrad_launch(self, x, x_nl, dy, db, accumulate) -> None:
-        """The weight gradient - with the optimizer update of this weight fused into its reduction when the runtime asks
-        for it (Runtime.fused_opt) and the layer qualifies: its own weight (no accumulation over call sites), trainable,
-        reduced through slabs (ops.ConvOp.wgrad_fusable)."""
-        rt = self.rt
-        spec = getattr(rt, "fused_opt", None) if rt is not None else None
-        if spec is not None and not accumulate and self.weight.trainable:
-            if self._fusable is None:
-                self._fusable = self.op.wgrad_fusable(x, dy)
-            if self._fusable:
-                ar, r = rt.arena, self.weight
-                sl = slice(r.offset, r.offset + r.numel)
-                self.op.wgrad_optim(x, x_nl, dy, db, spec, ar.params[sl], ar.exp_avg[sl], ar.exp_avg_sq[sl], ar.step,
-                                    r.group == GROUP_DECAY)
-                r.fused = True
-                return
-        self.weight.fused = False
         self.op.wgrad(x, x_nl, dy, self.weight.grad, db, accumulate)
 
     def wgrad(self, x, x_nl, dy, accumulate=False) -> None:
@@ -371,10 +339,6 @@ class Runtime:
         # forward activations of more than 4 channels stored as bf16 (torch-autocast style): set by runtimes whose every
         # layer kind has storage-agnostic kernels (models/unet.py); gradients, logits, statistics, weights stay fp32
         self.act_bf16 = False
-        # optimizer fused into the weight-gradient reductions: an ops.OptimSpec while a backward pass that wants it runs (set
-        # by the adaptation plugin), only on runtimes whose every ConvLayer has ONE call site (fuse_optimizer_ok)
-        self.fused_opt = None
-        self.fuse_optimizer_ok = False
         self.training = False
         self.overlap_wgrad = True      # weight gradients on a side stream (joined before the optimizer)
         self.n_side = 2                # layers alternate between the side streams (a layer always uses the same one)

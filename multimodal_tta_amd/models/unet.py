@@ -35,7 +35,6 @@ class UNetRuntime(Runtime):
         norm_name = model.norm[0] if isinstance(model.norm, (tuple, list)) else model.norm
         # (the thin first / last layers run on dedicated kernels: 4 -> 32|64 channels in, <= 4 out; narrower toy networks
         # take generic direct kernels that work on fp32-stored tensors only and keep fp32 storage)
-        self.fuse_optimizer_ok = True      # every ConvLayer of this runtime has exactly one call site
         self.act_bf16 = (model.conv_dtype == ops.BF16 and getattr(model, "act_storage", "bf16") == "bf16" and self.nru > 0
                          and str(norm_name).upper() == "INSTANCE" and self.channels[0] in (32, 64)
                          and all(c % 8 == 0 and c >= 32 for c in self.channels)

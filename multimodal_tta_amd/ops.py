@@ -391,28 +391,6 @@ class ConvOp:
                          self._detail(-1, x), self.io_bytes(x, dy, dw) * PROFILER.reps)
 
 
-    def wgrad_fusable(self, x: torch.Tensor, dy: torch.Tensor) -> bool:
-        """True when this layer's weight gradient goes through the slab reduction, i.e. ``wgrad_optim`` can take it."""
-        tx, tdy = desc_cl(x), desc_cl(dy)
-        return int(_lib.load().mmtta_conv_wgrad_fusable(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy))) == 1
-
-    def wgrad_optim(self, x: torch.Tensor, x_nl: Optional[NL], dy: torch.Tensor, db: Optional[torch.Tensor], spec: "OptimSpec",
-                    param: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: Optional[torch.Tensor], step: torch.Tensor,
-                    decay: bool) -> None:
-        """``wgrad`` with the optimizer update of this weight fused into its reduction (``mmtta_conv_wgrad_optim``): no dw is
-        written; `param` / `exp_avg` / `exp_avg_sq` are views of the arena with the weight's shape; `step` is read only."""
-        lib = _lib.load()
-        tx, tdy = desc_cl(x), desc_cl(dy)
-        need = lib.mmtta_conv_wgrad_workspace_bytes(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy))
-        if need < 0:
-            check(-1, "conv_wgrad_workspace_bytes")
-        ws = Workspace.get(int(need), x.device)
-        nls, nlr = _nl_ref(x_nl)
-        d = spec.struct()
-        check(lib.mmtta_conv_wgrad_optim(C.byref(self.d_fwd), C.byref(tx), nlr, C.byref(tdy), ptr(db), ptr(ws), int(need), C.byref(d),
-                                         ptr(param), ptr(exp_avg), ptr(exp_avg_sq), ptr(step), 1 if decay else 0, stream_ptr()),
-              "conv_wgrad_optim")
-
 
 class BatchedPacker:
     """Every packed weight image of a model refreshed by ONE kernel launch (the table is built once: parameter
@@ -595,22 +573,6 @@ def optim_step(spec: OptimSpec, p: torch.Tensor, g: torch.Tensor, m: torch.Tenso
     d = spec.struct()
     check(_lib.load().mmtta_optim_step(C.byref(d), ptr(p), ptr(g), ptr(m), ptr(v), n, int(n_decay), ptr(step),
                                        stream_ptr()), "optim_step")
-
-
-def optim_step_ranges(spec: OptimSpec, arena_p: torch.Tensor, arena_g: torch.Tensor, arena_m: torch.Tensor,
-                      arena_v: Optional[torch.Tensor], ranges, step: torch.Tensor) -> None:
-    """The optimizer over `ranges` = [(begin, end, decays)] of the flat arena (what fused weight-gradient launches left out),
-    the step counter advanced exactly once afterwards."""
-    lib = _lib.load()
-    d = spec.struct()
-    for a, b, decays in ranges:
-        n = b - a
-        if n <= 0:
-            continue
-        check(lib.mmtta_optim_step_partial(C.byref(d), ptr(arena_p[a:b]), ptr(arena_g[a:b]), ptr(arena_m[a:b]),
-                                           ptr(arena_v[a:b]) if arena_v is not None else None, n, n if decays else 0, ptr(step),
-                                           stream_ptr()), "optim_step_partial")
-    check(lib.mmtta_optim_advance(ptr(step), stream_ptr()), "optim_advance")
 
 
 def _desc_any(t: torch.Tensor, channels_last: bool):

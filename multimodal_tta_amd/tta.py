@@ -77,10 +77,6 @@ class EntropyMinimizationTTA:
         self.params_spec = get_config(m, "params", "all")
         self.precision = str(get_config(m, "precision", "fp32")).lower()
         self.storage = str(get_config(m, "storage", "bf16")).lower()      # activation storage of bf16 precision
-        # optimizer update of the convolution weights inside their weight-gradient reductions (mmtta_conv_wgrad_optim:
-        # bit-identical parameters, their gradients are then never materialised).  Off by default: measured 57.4 against
-        # 59.3 volumes/s - six accesses per element inside small reduce launches against an arena pass that streams
-        self.fuse_optimizer = bool(get_config(m, "fuse_optimizer", False))
         self.missing = [int(i) for i in (get_config(m, "missing_modalities", []) or [])]
         md = get_config(m, "moddrop", {}) or {}
         self.moddrop_p = float(get_config(md, "p", 0.0)) if bool(get_config(md, "enabled", False)) else 0.0
@@ -157,22 +153,12 @@ class EntropyMinimizationTTA:
         loss = rt.pool.flat("ent_loss", 1)
         ops.entropy_loss(logits, dlogits, partial, loss, softmax=self.softmax)
         if ar.n_train > 0:
-            fuse = self.fuse_optimizer and getattr(rt, "fuse_optimizer_ok", False)
-            rt.fused_opt = self.optim if fuse else None
-            try:
-                rt.run_backward(dlogits)
-            finally:
-                rt.fused_opt = None
+            rt.run_backward(dlogits)
             self.optimizer_step()
 
     def optimizer_step(self) -> None:
-        """The arena optimizer: ONE launch over [decay | no-decay] (+ the device step counter) - or, when the backward pass
-        just run updated the convolution weights inside their weight-gradient reductions (`method.fuse_optimizer`), the
-        parameters that pass left out (biases, norm affines, the <= 4-channel layers) and the step counter."""
+        """The arena optimizer: ONE launch over [decay | no-decay] (+ the device step counter)."""
         ar = self.rt.arena
-        if any(r.fused for r in ar.refs):
-            ops.optim_step_ranges(self.optim, ar.params, ar.grads, ar.exp_avg, ar.exp_avg_sq, ar.unfused_ranges(), ar.step)
-            return
         ops.optim_step(self.optim, ar.params[:ar.n_train], ar.grads[:ar.n_train], ar.exp_avg[:ar.n_train],
                        ar.exp_avg_sq[:ar.n_train], ar.n_decay, ar.step)
 

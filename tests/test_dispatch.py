@@ -5,8 +5,9 @@ parity cases (tests/test_hip_conv.py::CASES / BF16_CASES) - asserted through the
 config ids: csrc/conv_igemm.hip::config_id (0-5 fp32 igemm, 6 direct, 7-12 bf16 igemm, 13 channel kernel, 14 the lean 4x8x8 tile
 of the 32-output-channel bf16 layers: the default, id 7 = the 8x8x8 tile under MMTTA_OPT_IGEMM_LEAN = 0, parity case
 test_lean_tile_matches_the_wide_tile; 15 class-fused);
-weight-gradient ids: mmtta_conv_wgrad_kernel (0 f32 s1, 1 f32 s2, 2 1x1, 3 small-channel, 4 bf16 s1, 5 bf16 s2, 6 tiny,
-7 / 8 transposed-read bf16 s1 / s2: the default of bf16 precision, parity cases test_transposed_read_wgrad; 4 / 5 under option 11 = 0;
+weight-gradient ids: mmtta_conv_wgrad_kernel (0 f32 s1, 1 f32 s2, 2 1x1, 3 small-channel, 6 tiny, 7 / 8 transposed-read
+bf16 s1 / s2: the default of bf16 precision, parity cases test_transposed_read_wgrad; 0 / 1 under option 11 = 0; ids 4 / 5
+were round 1's staging-transposed bf16 kernels, removed in round 3;
 9 the 1x1x1 streaming kernel of bf16 precision, parity cases test_pointwise_conv_weight_gradient_on_transposed_reads).
 VERDICT r1 P1: ids 2 and 9 (igemm <4,4,4,4,8,32>) used to be reachable only by the full-size bench."""
 import ctypes as C
@@ -92,16 +93,18 @@ def test_every_kernel_instantiation_is_reached_by_a_parity_case():
                 # the same layer with its module input bf16-stored (method.storage: bf16): the same kernel
                 kid = int(lib.mmtta_conv_wgrad_kernel(C.byref(dsc), C.byref(_desc(x, BF16)), C.byref(ty)))
                 assert kid == wg, f"{case} bf16-stored: weight-gradient kernel {kid}, expected {wg}"
-                # the staging-transposed kernels (ids 4 / 5) stay reachable through MMTTA_OPT_WGRAD_VECTOR_STAGING = 0
+                # MMTTA_OPT_WGRAD_VECTOR_STAGING = 0 (and every operand pair the 16-byte loader cannot take): the fp32-operand
+                # kernels (ids 0 / 1)
                 prev = lib.mmtta_set_option(11, 0)
                 try:
                     kid0 = int(lib.mmtta_conv_wgrad_kernel(C.byref(dsc), C.byref(tx), C.byref(ty)))
                 finally:
                     lib.mmtta_set_option(11, prev)
-                assert kid0 == wg - 3, f"{case} option 0: weight-gradient kernel {kid0}, expected {wg - 3}"
+                assert kid0 == wg - 7, f"{case} option 0: weight-gradient kernel {kid0}, expected {wg - 7}"
                 seen_wg.add(kid0)
     assert seen_cfg == set(range(15)), f"conv configs without a parity case: {sorted(set(range(15)) - seen_cfg)}"
-    assert seen_wg == set(range(10)), f"weight-gradient kernels without a parity case: {sorted(set(range(10)) - seen_wg)}"
+    live_wg = set(range(10)) - {4, 5}            # ids 4 / 5 were the round-1 staging-transposed bf16 kernels (removed in round 3)
+    assert seen_wg == live_wg, f"weight-gradient kernels without a parity case: {sorted(live_wg - seen_wg)}"
     assert {2, 9} <= splitk_wide, "the 32-channel-stage igemm also needs a split-K parity case"
 
 

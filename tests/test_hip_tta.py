@@ -557,42 +557,3 @@ def test_adaptation_with_the_other_factory_optimizers(opt, over):
     logits_close(plug.logits(res).cpu(), out_ref, ref0, x, cfg["training"], steps=3)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("opt,over", [("adam", {}), ("adamw", {"weight_decay": 1e-2}), ("sgd", {"lr": 1e-2}),
-                                      ("sgd", {"lr": 1e-2, "nesterov": True})])
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_optimizer_fused_into_the_weight_gradient_is_bit_identical(opt, over, precision):
-    """`method.fuse_optimizer` (off by default: measured slower): the convolution weights are updated inside their weight-gradient reductions
-    (mmtta_conv_wgrad_optim) - the optimizer's arithmetic on the same fp32 gradient value, so after S episodic steps every
-    parameter, both optimizer moments, the step counter, the losses and the logits equal the unfused run BIT FOR BIT; and the
-    fused run really took the fused path (convolution weights flagged, their gradient buffers untouched)."""
-    from multimodal_tta_amd.registry import get_plugin
-
-    outs = {}
-    for fuse in (False, True):
-        cfg = root_cfg(SMALL, steps=3, lr=1e-3)
-        cfg["training"]["optimizer"] = opt
-        cfg["training"]["optimizers"][opt].update(over)
-        cfg["method"]["precision"] = precision
-        cfg["method"]["fuse_optimizer"] = fuse
-        cfg["method"]["episodic"] = False        # keep the adapted state for the comparison
-        _, hip = build_pair(SMALL)
-        x, _ = volume(7)
-        plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
-        assert plug.fuse_optimizer == fuse
-        plug.rt.arena.grads.fill_(123.0)
-        res = plug.adapt_volume(x.cuda())
-        torch.cuda.synchronize()
-        ar = plug.rt.arena
-        fused = [r for r in ar.refs if r.fused]
-        assert bool(fused) == fuse
-        if fuse:
-            assert all(r.grad.eq(123.0).all() for r in fused), "a fused weight's gradient buffer was written"
-            assert any(not r.fused and r.trainable for r in ar.refs)      # biases / norm affines go through the arena pass
-        outs[fuse] = (ar.params.clone(), ar.exp_avg.clone(), ar.exp_avg_sq.clone(), int(ar.step.item()), res["losses"].clone(),
-                      plug.logits(res).clone())
-    a, b = outs[False], outs[True]
-    assert a[3] == b[3] == 3
-    for name, u, v in zip(("parameters", "exp_avg", "exp_avg_sq", "losses", "logits"), (a[0], a[1], a[2], a[4], a[5]),
-                          (b[0], b[1], b[2], b[4], b[5])):
-        assert torch.equal(u, v), f"{name} differ between the fused and the unfused optimizer"
