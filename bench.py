@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--lanes", type=int, default=None,
                     help="volumes adapted concurrently per GPU, each with its own weights, buffers, graph and stream "
                          "(episodic adaptation has no cross-volume state; one volume alone leaves most CUs waiting)")
+    ap.add_argument("--group", type=int, default=None,
+                    help="volumes adapted TOGETHER as the batch items of one launch sequence, each on its own replica of the "
+                         "weights and optimizer state (method.group); lanes x group volumes are in flight per GPU")
     ap.add_argument("--side-streams", type=int, default=None, help="side streams for the weight gradients (default: config)")
     ap.add_argument("--storage", default=None, choices=["bf16", "fp32"],
                     help="bf16 precision: storage of the wide forward activations (default: the method config, bf16)")
@@ -87,6 +90,8 @@ def build_cfg(args):
         ov += ["method.use_graph=false"]
     if getattr(args, "side_streams", None) is not None:
         ov += [f"method.side_streams={args.side_streams}"]
+    if getattr(args, "group", None) is not None:
+        ov += [f"method.group={args.group}"]
     if getattr(args, "storage", None) or os.environ.get("MMTTA_STORAGE"):
         ov += [f"method.storage={getattr(args, 'storage', None) or os.environ['MMTTA_STORAGE']}"]
     cfg = compose(overrides=ov)
@@ -225,11 +230,30 @@ def main():
     thr = float(cfg["evaluation"]["seg"]["threshold"])
     nvol = args.steps + args.warmup
     lanes = max(1, int(args.lanes if args.lanes is not None else cfg["method"].get("lanes", 1)))
+    group = max(1, int(cfg["method"].get("group", 1)))
     lane_streams = ops.lane_streams(lanes, device)      # first GPU work of the process: one hardware queue per lane
     vols = []
     for i in range(nvol):
         v = synth_volume(rank * nvol + i, C, shape, R)
         vols.append((v["image"].unsqueeze(0).to(device), v["label"].unsqueeze(0).to(device)))
+
+    def schedule(first, last, group_):
+        """[(lane, [volume indices])]: consecutive volumes form groups of `group_` (the last one may be partial), groups go
+        round-robin over the lanes."""
+        out_ = []
+        for k, a in enumerate(range(first, last, group_)):
+            out_.append((k, list(range(a, min(a + group_, last)))))
+        return out_
+
+    # the timed volumes as resident group tensors (inputs are in HBM before the timed region starts)
+    _grouped = {}
+
+    def group_tensors(idx):
+        key = tuple(idx)
+        if key not in _grouped:
+            _grouped[key] = (torch.cat([vols[i % nvol][0] for i in idx]), torch.cat([vols[i % nvol][1] for i in idx])) \
+                if len(idx) > 1 else vols[idx[0] % nvol]
+        return _grouped[key]
 
     def make_lanes(cfg_, lanes_, lane0=0, streams_=None):
         """`lanes_` plugins with the same seeded source weights (episodic: restored per volume), a stream each."""
@@ -246,19 +270,23 @@ def main():
             plugs_.append(p_.setup(m, device))
         return plugs_, streams_
 
-    def run_volumes(plugs_, streams_, first, last, counts_):
-        for i in range(first, last):
-            lane = i % len(plugs_)
-            x, y = vols[i % nvol]
+    def run_volumes(plugs_, streams_, first, last, counts_, group_=None):
+        group_ = group if group_ is None else group_
+        for k, idx in schedule(first, last, group_):
+            lane = k % len(plugs_)
+            x, y = group_tensors(idx)
             with torch.cuda.stream(streams_[lane]):
                 res = plugs_[lane].adapt_volume(x)
-                ops.mask_dice_counts(res["logits_cl"], y, thr, counts_[i % nvol:i % nvol + 1], None)
+                ops.mask_dice_counts(res["logits_cl"], y, thr, counts_[idx[0] % nvol:idx[0] % nvol + len(idx)], None)
 
     plugs, streams = make_lanes(cfg, lanes, streams_=lane_streams)
     plug = plugs[0]
     counts = torch.zeros((nvol, R, 3), dtype=torch.int64, device=device)
 
-    run_volumes(plugs, streams, 0, max(args.warmup, lanes), counts)      # every lane captures its graph before the timed region
+    # untimed: the W warm-up volumes, then one dry run of the timed schedule itself, so that every lane has captured the
+    # graph of every group size it will see (a partial last group included) and every group tensor is resident
+    run_volumes(plugs, streams, 0, args.warmup, counts)
+    run_volumes(plugs, streams, args.warmup, nvol, counts)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -299,36 +327,45 @@ def main():
                           "weight gradients / optimizer / master weights fp32") if args.precision == "bf16"
             else "fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32)", "weights": "seeded default init (no checkpoint offline)",
             "parallelism": f"{world} rank(s), one per GPU, volumes sharded round-robin, no data-path collective; the "
-                           f"per-volume Dice table is merged by one all_gather; {lanes} volume(s) in flight per GPU on "
-                           "separate streams",
-            "graph": bool(plug.use_graph), "lanes": lanes,
+                           f"per-volume Dice table is merged by one all_gather; per GPU {lanes} lane(s) (own stream = "
+                           f"hardware queue, own graph) x {group} volume(s) per launch sequence, every volume on its own "
+                           "replica of the weights and optimizer state",
+            "graph": bool(plug.use_graph), "lanes": lanes, "group": group,
+            "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
         },
         "ranks": {"volumes_per_s_min": args.steps / t_local_max, "volumes_per_s_max": args.steps / t_local_min,
                   "gather_ms": 1000.0 * t_gather},
     }
 
     if rank == 0 and not args.no_profile_pass:
-        out["roofline"] = roofline_block(args, cfg, plug, vols[0][0], elapsed / args.steps)
+        first_group = schedule(args.warmup, nvol, group)[0][1]
+        out["roofline"] = roofline_block(args, cfg, plug, group_tensors(first_group)[0], elapsed / args.steps)
         out["config"]["algorithmic_conv_tflop_per_volume"] = out["roofline"]["whole_volume"]["algorithmic_tflop"]
     if rank == 0 and world == 1 and not args.no_variants:
-        # the same workload (a) with one volume in flight, (b) in fp32 mode: the reference's own arithmetic
+        # the same workload (a) one volume at a time (one lane, group 1: the single-volume latency - and the check that the
+        # grouped, multi-lane headline run produced the SAME results for the same volumes), (b) in fp32 mode: the reference's
+        # own arithmetic
         variants = {}
-        for name, prec, nl in (("one_lane", args.precision, 1), ("fp32", "fp32", lanes)):
-            if (prec, nl) == (args.precision, lanes):
+        for name, prec, nl, ng in (("one_volume", args.precision, 1, 1), ("fp32", "fp32", lanes, group)):
+            if (prec, nl, ng) == (args.precision, lanes, group):
                 continue
             a2 = argparse.Namespace(**vars(args))
-            a2.precision = prec
+            a2.precision, a2.group = prec, ng
             cfg2, _ = build_cfg(a2)
             pl2, st2 = make_lanes(cfg2, nl, lane0=8 if name == "fp32" else 6, streams_=streams)      # the same queues
             c2 = torch.zeros_like(counts)
-            nv = min(args.steps, 4)
-            run_volumes(pl2, st2, 0, nl, c2)
+            nv = min(args.steps, max(8, 2 * nl * ng))         # steady state: at least two rounds of every lane
+            run_volumes(pl2, st2, args.warmup, args.warmup + nv, c2, group_=ng)      # untimed: graphs of this schedule
             torch.cuda.synchronize()
             tv = time.perf_counter()
-            run_volumes(pl2, st2, args.warmup, args.warmup + nv, c2)
+            run_volumes(pl2, st2, args.warmup, args.warmup + nv, c2, group_=ng)
             torch.cuda.synchronize()
             tv = time.perf_counter() - tv
-            variants[name] = {"value": nv / tv, "unit": "volumes/s", "precision": prec, "lanes": nl, "volumes": nv}
+            variants[name] = {"value": nv / tv, "unit": "volumes/s", "precision": prec, "lanes": nl, "group": ng, "volumes": nv}
+            if name == "one_volume":
+                same = bool(torch.equal(c2[args.warmup:args.warmup + nv], counts[args.warmup:args.warmup + nv]))
+                variants[name]["latency_ms"] = 1000.0 * tv / nv
+                out["lanes_equal"] = same      # Dice counts of the grouped / multi-lane run == one volume at a time, exactly
             del pl2, st2
         out["variants"] = variants
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -351,6 +388,7 @@ def roofline_block(args, cfg, plug, x0, s_per_volume):
     saved = plug.use_graph
     plug.use_graph = False
     _lib.load().mmtta_set_option(1, 1)
+    B = int(x0.shape[0])        # the volumes of one group: every figure below is divided down to ONE volume
     try:
         plug.adapt_volume(x0, steps=2)
         torch.cuda.synchronize()
@@ -365,8 +403,8 @@ def roofline_block(args, cfg, plug, x0, s_per_volume):
     for rname, _launches, rflops, _e0, _e1, detail, rbytes in prof.records:
         kind = detail.split(" ")[0]
         kind = "fwd" if kind.startswith("fwd") else ("dgrad" if kind.startswith("dgrad") else "wgrad")
-        per_kind[kind][0] += rflops / prof.reps
-        per_kind[kind][1] += rbytes / prof.reps
+        per_kind[kind][0] += rflops / prof.reps / B
+        per_kind[kind][1] += rbytes / prof.reps / B
     S = args.tta_steps
     f_fwd, b_fwd = per_kind["fwd"][0] / 3.0, per_kind["fwd"][1] / 3.0
     f_vol = S * (f_fwd + per_kind["dgrad"][0] / 2.0 + per_kind["wgrad"][0] / 2.0) + f_fwd

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTTA_ABI_VERSION 1
+#define MMTTA_ABI_VERSION 2
 
 typedef enum {
   MMTTA_OK = 0,
@@ -222,6 +222,37 @@ int mmtta_conv_run(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmt
                    const mmtta_tensor* y, int accumulate, float* stats, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* ---- per-volume parameter sets: N volumes (or N identical sub-networks) in ONE launch, each with ITS OWN parameters.
+ * Episodic adaptation has no cross-volume state: every test volume adapts its own copy of the source weights (SURVEY.md
+ * Appendix C), and the M modality encoders of the deep-fusion network are M identical graphs with different weights run
+ * one after another by the reference (reference src/models/unet_multimodal_midfusion.py:214-218).  Alone, a volume's
+ * launches at the 8^3 / 16^3 / 32^3 levels fill a quarter of the chip or less; here they become the batch items of one
+ * launch and the batch index selects the parameter set:
+ *     set q of batch item n:   q = n / items_per_set
+ *     its parameters:          base + (q / inner) * outer + (q % inner) * inner_stride
+ * for the packed weight images (`packed_*`, BYTES) and for what lives in the fp32 parameter arenas: weight gradients
+ * (`weight_*`, ELEMENTS) and bias vectors / bias gradients (`bias_*`, ELEMENTS; the arenas of a group of volumes are replicas
+ * of one layout, so the outer strides are normally all the replica stride, while the inner ones differ).  Examples:
+ * G volumes through a U-Net layer: items_per_set 1, inner 1, outer = replica stride.  G volumes x M modality encoders:
+ * batch G*M, items_per_set 1, inner M, inner stride = one encoder's parameters.  The fusion layer the reference applies M
+ * times with shared weights: batch G*M, items_per_set M, inner 1 (its weight gradient then sums over the M items of a
+ * volume).  NULL = one parameter set for the whole batch (the plain entry points).  Strides must keep 16-byte alignment.
+ * Every batch item is computed exactly as if it had been launched alone with its set: same tiles, same reduction splits,
+ * same summation order - grouped and one-at-a-time runs agree bit for bit (tests/test_hip_groups.py). */
+typedef struct {
+  int32_t items_per_set; /* consecutive batch items that share a parameter set (>= 1; must divide N) */
+  int32_t inner;         /* sets per outer step (>= 1) */
+  int64_t packed_outer, packed_inner; /* BYTES between packed weight images */
+  int64_t weight_outer, weight_inner; /* ELEMENTS between weight gradients dw (torch weight layout) */
+  int64_t bias_outer, bias_inner;     /* ELEMENTS between bias vectors / bias gradients db */
+} mmtta_param_sets;
+
+/* mmtta_conv_run with per-item parameter sets: `packed` and `bias` are the base pointers of set 0. */
+int mmtta_conv_run_sets(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                        const void* packed, const float* bias, const mmtta_conv_epilogue* epi,
+                        const mmtta_tensor* y, int accumulate, float* stats, void* workspace,
+                        int64_t workspace_bytes, const mmtta_param_sets* sets, void* stream);
+
 /* Weight (and bias) gradient.
  *   Replaces: autograd's weight-gradient of Conv3d / ConvTranspose3d
  *   (reference src/core/trainers/seg_trainer.py:142).
@@ -241,6 +272,15 @@ int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* desc, const mmtta_tensor* x, 
 int mmtta_conv_wgrad(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
                      const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
                      int64_t workspace_bytes, void* stream);
+
+/* The weight gradient of every parameter set of the batch in one launch sequence: `dw` / `db` are the base pointers of
+ * set 0; set q's gradient is the sum over ITS batch items only (slabs never mix sets), reduced in the order the plain call
+ * uses for a batch of items_per_set.  Workspace: mmtta_conv_wgrad_workspace_bytes_sets. */
+int64_t mmtta_conv_wgrad_workspace_bytes_sets(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_tensor* dy,
+                                              const mmtta_param_sets* sets);
+int mmtta_conv_wgrad_sets(const mmtta_conv_desc* desc, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                          const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
+                          int64_t workspace_bytes, const mmtta_param_sets* sets, void* stream);
 
 /* ------------------------------------------------------------------ input pre-pass -------- */
 /* Per-channel intensity rule of one image [C,D,H,W] (reference src/datasets/transforms.py:129-223).
@@ -352,6 +392,14 @@ int64_t mmtta_entropy_partials(const mmtta_tensor* logits);
 int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits,
                        double* partial, float* loss, void* stream);
 
+/* The same objective for N INDEPENDENT volumes in one launch (a group of volumes adapting side by side, each with its
+ * own parameters): loss[n] = mean over batch item n alone, dlogits of item n scaled by item n's count - exactly what N
+ * calls of mmtta_entropy_loss on the N items would produce (same block partials, same order).
+ *   partial  fp64 [N * mmtta_entropy_partials(one item)] scratch; loss  fp32 [N] */
+int64_t mmtta_entropy_partials_items(const mmtta_tensor* logits);
+int mmtta_entropy_loss_items(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits,
+                             double* partial, float* loss, void* stream);
+
 /* ------------------------------------------------------------------ optimizer ------------ */
 /* torch.optim.Adam (amsgrad=False, coupled L2) over a flat parameter arena, two segments:
  * [0, n_decay) with weight_decay, [n_decay, n) without - the decay / no-decay groups of
@@ -379,6 +427,12 @@ typedef struct mmtta_optim_desc {
 } mmtta_optim_desc;
 int mmtta_optim_step(const mmtta_optim_desc* desc, float* p, const float* g, float* m, float* v, int64_t n,
                      int64_t n_decay, int32_t* step, void* stream);
+
+/* mmtta_optim_step over `sets` replicas of the arena in one launch (a group of volumes, each adapting its own copy):
+ * replica r occupies [r * set_stride, r * set_stride + n) of p / g / m / v, its first n_decay elements decay.  One shared
+ * step counter, advanced once.  set_stride a multiple of 4. */
+int mmtta_optim_step_sets(const mmtta_optim_desc* desc, float* p, const float* g, float* m, float* v, int64_t n,
+                          int64_t n_decay, int sets, int64_t set_stride, int32_t* step, void* stream);
 
 /* ------------------------------------------------------------------ evaluation tail ------ */
 /* sigmoid -> (>= threshold) -> uint8 mask; GT (> 0.5); per (n,r) integer counts

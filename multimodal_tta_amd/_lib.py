@@ -49,6 +49,11 @@ class PackItem(C.Structure):
     _fields_ = [("desc", ConvDesc), ("w_master", C.c_void_p), ("packed", C.c_void_p)]
 
 
+class ParamSets(C.Structure):          # mmtta_param_sets
+    _fields_ = [("items_per_set", C.c_int32), ("inner", C.c_int32), ("packed_outer", C.c_int64), ("packed_inner", C.c_int64),
+                ("weight_outer", C.c_int64), ("weight_inner", C.c_int64), ("bias_outer", C.c_int64), ("bias_inner", C.c_int64)]
+
+
 class ConvPlan(C.Structure):
     _fields_ = [
         ("tiles", C.c_int32), ("launches", C.c_int32), ("ksplit", C.c_int32), ("stats_rows", C.c_int32),
@@ -90,7 +95,12 @@ _SIGNATURES = {
     "mmtta_conv_plan": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(Tensor), _P(ConvPlan)]),
     "mmtta_conv_run": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(NormOnLoad), C.c_void_p, C.c_void_p, _P(ConvEpilogue),
                                  _P(Tensor), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mmtta_conv_run_sets": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(NormOnLoad), C.c_void_p, C.c_void_p, _P(ConvEpilogue),
+                                      _P(Tensor), C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _P(ParamSets), C.c_void_p]),
     "mmtta_conv_wgrad_workspace_bytes": (C.c_int64, [_P(ConvDesc), _P(Tensor), _P(Tensor)]),
+    "mmtta_conv_wgrad_workspace_bytes_sets": (C.c_int64, [_P(ConvDesc), _P(Tensor), _P(Tensor), _P(ParamSets)]),
+    "mmtta_conv_wgrad_sets": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(NormOnLoad), _P(Tensor), C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_int64, _P(ParamSets), C.c_void_p]),
     "mmtta_conv_wgrad_kernel": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(Tensor)]),
     "mmtta_conv_wgrad": (C.c_int, [_P(ConvDesc), _P(Tensor), _P(NormOnLoad), _P(Tensor), C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -114,10 +124,14 @@ _SIGNATURES = {
     "mmtta_lincomb": (C.c_int, [C.c_int, _P(_P(Tensor)), _P(C.c_float), _P(Tensor), C.c_int, C.c_void_p]),
     "mmtta_entropy_partials": (C.c_int64, [_P(Tensor)]),
     "mmtta_entropy_loss": (C.c_int, [_P(Tensor), C.c_int, _P(Tensor), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmtta_entropy_partials_items": (C.c_int64, [_P(Tensor)]),
+    "mmtta_entropy_loss_items": (C.c_int, [_P(Tensor), C.c_int, _P(Tensor), C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmtta_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "mmtta_optim_step": (C.c_int, [_P(OptimDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                    C.c_void_p, C.c_void_p]),
+    "mmtta_optim_step_sets": (C.c_int, [_P(OptimDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                        C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "mmtta_mask_dice_counts": (C.c_int, [_P(Tensor), _P(Tensor), C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmtta_dice_ce_scratch_bytes": (C.c_int64, [_P(Tensor)]),
     "mmtta_dice_ce_sums": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -146,7 +160,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI and the binding drifted apart
         fn.restype = res
         fn.argtypes = args
-    if lib.mmtta_abi_version() != 1:
+    if lib.mmtta_abi_version() != 2:
         raise MmttaError("libmmtta.so ABI version mismatch")
     if os.environ.get("MMTTA_NO_PIPE", "0") == "1":      # A/B aid: MMTTA_OPT_IGEMM_PIPELINE off (same results bit for bit)
         lib.mmtta_set_option(6, 0)

@@ -203,6 +203,59 @@ inline NL nl(const mmtta_norm_on_load* t) {
   return r;
 }
 
+// Per-volume parameter sets (mmtta_param_sets): which set batch item n reads / writes.  Items [q * ips, (q + 1) * ips)
+// share set q; set q lives (q / inner) outer strides + (q % inner) inner strides behind the base pointer.  All-zero
+// strides = one set for the whole batch (the plain entry points).  n is workgroup-uniform everywhere it is used, so the
+// two divisions are scalar work paid once per workgroup.
+struct PSets {
+  int ips, inner;
+  long long packed_outer, packed_inner;   // bytes between packed weight images
+  long long weight_outer, weight_inner;   // elements between the weight gradients (torch weight layout)
+  long long bias_outer, bias_inner;       // elements between bias vectors / bias gradients
+};
+
+inline PSets psets(const mmtta_param_sets* g) {
+  PSets r;
+  if (g == nullptr) { r.ips = 1; r.inner = 1; r.packed_outer = r.packed_inner = r.weight_outer = r.weight_inner = r.bias_outer = r.bias_inner = 0; return r; }
+  r.ips = g->items_per_set; r.inner = g->inner;
+  r.packed_outer = g->packed_outer; r.packed_inner = g->packed_inner;
+  r.weight_outer = g->weight_outer; r.weight_inner = g->weight_inner;
+  r.bias_outer = g->bias_outer; r.bias_inner = g->bias_inner;
+  return r;
+}
+inline int psets_validate(const mmtta_param_sets* g, int n) {
+  if (g == nullptr) return MMTTA_OK;
+  MMTTA_CHECK(g->items_per_set >= 1 && g->inner >= 1, MMTTA_ERR_INVALID, "param sets: items_per_set %d, inner %d (both >= 1)",
+              g->items_per_set, g->inner);
+  MMTTA_CHECK(n % g->items_per_set == 0, MMTTA_ERR_INVALID, "param sets: batch %d is no multiple of items_per_set %d", n,
+              g->items_per_set);
+  MMTTA_CHECK(g->packed_outer % 16 == 0 && g->packed_inner % 16 == 0 && g->weight_outer % 4 == 0 && g->weight_inner % 4 == 0 &&
+                  g->bias_outer % 4 == 0 && g->bias_inner % 4 == 0,
+              MMTTA_ERR_INVALID, "param sets: strides must keep 16-byte alignment");
+  return MMTTA_OK;
+}
+__host__ __device__ __forceinline__ bool psets_on(const PSets& g) {
+  return (g.packed_outer | g.packed_inner | g.weight_outer | g.weight_inner | g.bias_outer | g.bias_inner) != 0;
+}
+__device__ __forceinline__ int pset_of(const PSets& g, int n) { return g.ips == 1 ? n : n / g.ips; }
+__device__ __forceinline__ long long pset_packed_bytes(const PSets& g, int q) {
+  return g.inner == 1 ? q * g.packed_outer : (q / g.inner) * g.packed_outer + (q % g.inner) * g.packed_inner;
+}
+__device__ __forceinline__ long long pset_weight_elems(const PSets& g, int q) {
+  return g.inner == 1 ? q * g.weight_outer : (q / g.inner) * g.weight_outer + (q % g.inner) * g.weight_inner;
+}
+__device__ __forceinline__ long long pset_bias_elems(const PSets& g, int q) {
+  return g.inner == 1 ? q * g.bias_outer : (q / g.inner) * g.bias_outer + (q % g.inner) * g.bias_inner;
+}
+// base pointers of batch item n's set (null stays null)
+template <class T>
+__device__ __forceinline__ const T* pset_packed(const PSets& g, const T* base, int n) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + pset_packed_bytes(g, pset_of(g, n)));
+}
+__device__ __forceinline__ const float* pset_bias(const PSets& g, const float* base, int n) {
+  return base == nullptr ? nullptr : base + pset_bias_elems(g, pset_of(g, n));
+}
+
 // scale/shift of channel c of batch item n for a norm-on-load (identity when mean == nullptr)
 __device__ __forceinline__ void nl_coeff(const NL& t, int n, int C, int c, float& sc, float& sh) {
   if (t.scale != nullptr) { sc = t.scale[n * C + c]; sh = t.shift[n * C + c]; return; }   // precombined: two loads
@@ -356,14 +409,14 @@ int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const m
 bool pointwise_small_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y, const float* stats,
                                 const mmtta_conv_epilogue* epi, const mmtta_norm_on_load* x_norm);
 int pointwise_small_run(const mmtta_tensor* x, const void* packed, int Kp, int Np, const float* bias, const mmtta_tensor* y,
-                        int accumulate, hipStream_t stream);
+                        int accumulate, const PSets& sets, hipStream_t stream);
 bool chan_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);
 int chan_tiles_per_n(const mmtta_tensor* y);
 int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed, int Kp,
                   int Np, const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
-                  hipStream_t stream);
+                  const PSets& sets, hipStream_t stream);
 int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed,
                     const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
-                    hipStream_t stream);
+                    const PSets& sets, hipStream_t stream);
 
 }  // namespace mmtta

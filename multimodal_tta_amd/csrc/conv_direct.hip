@@ -29,6 +29,7 @@ struct DArgs {
   const float* add; long long asn, asd, ash, asw; NL tadd;
   int K, N, ksize, stride, transposed, accumulate;
   float* stats; int blocks_per_n;
+  PSets ps;            // per-item parameter sets: w / bias are set 0's (common.h)
   int out_vec4;        // N < 4, 16-byte voxel rows whose pad lanes this view owns: one full store per voxel
 };
 
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DArgs a) {
   float* coef = lds + T * a.K * 4;       // [K][2] scale, shift
   float* red = coef + 2 * a.K;           // [sum|sq][wave][channel] = 32 floats
   const int n = blockIdx.y;
+  a.w = pset_packed(a.ps, a.w, n); a.bias = pset_bias(a.ps, a.bias, n);      // this batch item's parameter set
   for (int i = threadIdx.x; i < T * a.K * 4; i += 256) wl[i] = a.w[i];
   if (HAS_T)
     for (int k = threadIdx.x; k < a.K; k += 256) {
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
   float* wl = lds;                       // [T][K][4]
   float* red = lds + T * a.K * 4;        // [sum|sq][wave][channel]
   const int n = blockIdx.y;
+  a.w = pset_packed(a.ps, a.w, n); a.bias = pset_bias(a.ps, a.bias, n);      // this batch item's parameter set
   for (int i = threadIdx.x; i < T * a.K; i += 256)
     *reinterpret_cast<float4*>(wl + 4 * i) = *reinterpret_cast<const float4*>(a.w + 4 * i);
   __syncthreads();
@@ -362,8 +365,9 @@ typedef float cf4 __attribute__((ext_vector_type(4)));
 template <int KI, int NO, bool HAS_T>
 __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
   __shared__ float red[32];
-  cfloat* wc = (cfloat*)a.w;             // [27][KI][4]
   const int n = blockIdx.y;
+  a.w = pset_packed(a.ps, a.w, n); a.bias = pset_bias(a.ps, a.bias, n);      // this batch item's parameter set
+  cfloat* wc = (cfloat*)a.w;             // [27][KI][4]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float sc[KI], sh[KI];
@@ -487,6 +491,7 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
   __shared__ uint2 wtab[27 * 4];                // [tap][column] x 4 k values (bf16)
   __shared__ float red[32];
   const int n = blockIdx.y;
+  a.w = pset_packed(a.ps, a.w, n); a.bias = pset_bias(a.ps, a.bias, n);      // this batch item's parameter set
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int txn = (a.out.w + TX - 1) / TX, tyn = (a.out.h + TY - 1) / TY;
@@ -675,8 +680,9 @@ __global__ __launch_bounds__(256) void direct_upconv_kernel(DArgs a) {
   constexpr int VS = K + 4;                    // LDS voxel stride (floats)
   constexpr int XV = 65;                       // staged voxels per row
   float* red = lds + 4 * XV * VS;
-  cfloat* wc = (cfloat*)a.w;                   // [27][K][4]
   const int n = blockIdx.y;
+  a.w = pset_packed(a.ps, a.w, n); a.bias = pset_bias(a.ps, a.bias, n);      // this batch item's parameter set
+  cfloat* wc = (cfloat*)a.w;                   // [27][K][4]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chunks = (a.in.w + 63) / 64;
@@ -792,6 +798,7 @@ struct CArgs {
   int accumulate;
   float* stats; int tiles_per_n;
   int tz, ty, tx;
+  PSets ps;                       // per-item parameter sets: w / bias are set 0's (common.h)
   int koff;                       // KI == 1: the channel sits at float `koff` of the 16-byte group `in.p` points at
 };
 
@@ -810,6 +817,7 @@ __global__ __launch_bounds__(256) void direct_chan_kernel(CArgs a) {
   const int tyi = t % a.ty; t /= a.ty;
   const int tzi = t % a.tz;
   const int n = t / a.tz;
+  a.w = pset_packed(a.ps, a.w, n); a.bias = pset_bias(a.ps, a.bias, n);      // this batch item's parameter set
   const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
   const int iz0 = oz0 * S - 1, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   {  // ---- stage the halo box: all loads (clamped) first, then transform / zero-fill.  A thread keeps one box column and
@@ -933,6 +941,7 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
   const int tyi = t % a.ty; t /= a.ty;
   const int tzi = t % a.tz;
   const int n = t / a.tz;
+  a.w = pset_packed(a.ps, a.w, n); a.bias = pset_bias(a.ps, a.bias, n);      // this batch item's parameter set
   const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
   const int iz0 = oz0 * S - 1, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int N = a.out.c;
@@ -1168,8 +1177,9 @@ static void launch_chan_mfma(const CArgs& a, int K, int N, int blocks, hipStream
 
 int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed, int Kp,
                   int Np, const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
-                  hipStream_t stream) {
+                  const PSets& sets, hipStream_t stream) {
   CArgs a;
+  a.ps = sets;
   a.in = tv(x); a.tin = nl(x_norm); a.out = tv(y);
   a.koff = (int)((((uintptr_t)x->ptr) % 16) / 4);
   MMTTA_CHECK(a.koff == 0 || x->c == 1, MMTTA_ERR_UNSUPPORTED, "thin-K conv: only a one-channel slice may start inside a 16-byte group");
@@ -1217,6 +1227,7 @@ struct PArgs {
   const float* w; int Kp, Np;      // implicit-GEMM fp32 image [1][Kp][Np]
   const float* bias;
   int accumulate;
+  PSets ps;                        // per-item parameter sets (the batch item varies per thread here)
 };
 
 template <int KI>
@@ -1226,29 +1237,36 @@ __global__ __launch_bounds__(256) void pointwise_small_k_kernel(PArgs a) {
   const long long total = (long long)a.out.n * dhw * NV;
   const bool dense = a.in.sh == (long long)a.in.w * a.in.sw && a.in.sd == (long long)a.in.h * a.in.sh &&
                      a.out.sh == (long long)a.out.w * a.out.sw && a.out.sd == (long long)a.out.h * a.out.sh;
+  const bool sets = psets_on(a.ps);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int n0 = (int)(i % NV) * 4;
     long long ioff, ooff;
+    int nb;
     if (dense) {                                   // dense voxel order on both sides: no coordinate arithmetic
       const long long v = i / NV, n = v / dhw, r = v - n * dhw;
       ioff = n * a.in.sn + r * a.in.sw;
       ooff = n * a.out.sn + r * a.out.sw;
+      nb = (int)n;
     } else {
       int n, z, y, x;
       vox_decompose(a.out, i / NV, n, z, y, x);
       ioff = vox_addr(a.in, n, z, y, x);
       ooff = vox_addr(a.out, n, z, y, x);
+      nb = n;
     }
+    const float* wn = a.w;
+    const float* bn = a.bias;
+    if (sets) { wn = pset_packed(a.ps, a.w, nb); bn = pset_bias(a.ps, a.bias, nb); }
     const float4 x4 = *reinterpret_cast<const float4*>(a.in.p + ioff);
     const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
     float o[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
+    if (bn) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = a.bias[n0 + j];
+      for (int j = 0; j < 4; ++j) o[j] = bn[n0 + j];
     }
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
-      const float4 w4 = *reinterpret_cast<const float4*>(a.w + (long long)k * a.Np + n0);
+      const float4 w4 = *reinterpret_cast<const float4*>(wn + (long long)k * a.Np + n0);
       o[0] = fmaf(xs[k], w4.x, o[0]); o[1] = fmaf(xs[k], w4.y, o[1]); o[2] = fmaf(xs[k], w4.z, o[2]); o[3] = fmaf(xs[k], w4.w, o[3]);
     }
     float* op = a.out.p + ooff + n0;
@@ -1269,9 +1287,10 @@ bool pointwise_small_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x,
 }
 
 int pointwise_small_run(const mmtta_tensor* x, const void* packed, int Kp, int Np, const float* bias, const mmtta_tensor* y,
-                        int accumulate, hipStream_t stream) {
+                        int accumulate, const PSets& sets, hipStream_t stream) {
   PArgs a;
   a.in = tv(x); a.out = tv(y); a.w = (const float*)packed; a.Kp = Kp; a.Np = Np; a.bias = bias; a.accumulate = accumulate;
+  a.ps = sets;
   const long long total = (long long)y->n * y->d * y->h * y->w * (y->c / 4);
   long long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
@@ -1364,6 +1383,7 @@ __global__ __launch_bounds__(256) void upconv_mfma_kernel(DArgs a) {
   uint4* wimg = reinterpret_cast<uint4*>(lds + 4 * XV * VS);          // [27][KS][2][4] x 8 bf16
   float* red = lds + 4 * XV * VS + 27 * KS * 2 * 4 * 4;
   const int n = blockIdx.y;
+  a.w = pset_packed(a.ps, a.w, n); a.bias = pset_bias(a.ps, a.bias, n);      // this batch item's parameter set
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chunks = (a.in.w + 63) / 64;
@@ -1556,8 +1576,9 @@ static void launch_row(const DArgs& a, int n, hipStream_t stream) {
 
 int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm, const void* packed,
                     const float* bias, const mmtta_conv_epilogue* epi, const mmtta_tensor* y, int accumulate, float* stats,
-                    hipStream_t stream) {
+                    const PSets& sets, hipStream_t stream) {
   DArgs a;
+  a.ps = sets;
   a.in = tv(x); a.tin = nl(x_norm); a.out = tv(y);
   a.w = (const float*)packed; a.bias = bias;
   a.add = nullptr; a.asn = a.asd = a.ash = a.asw = 0; a.tadd = nl(nullptr);

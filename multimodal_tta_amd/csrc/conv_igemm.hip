@@ -69,6 +69,7 @@ struct GArgs {
   int si;
   const float* wp; int Kp, Np;
   const float* bias;
+  PSets ps;        // per-item parameter sets: wp / bias are set 0's (common.h)
   const float* add; long long asn, asd, ash, asw; NL tadd;
   int accumulate;
   float* stats; int stats_rows_per_n;
@@ -114,8 +115,8 @@ constexpr int LDS_PITCH_BF16 = 12;   // x-row pitch (voxels) of the bf16 LDS ima
 // `tr`: 32 x 36 floats of this wave.  Per-lane sums for the following norm: channels colbase + 4*(lane&7) + 0..3,
 // already added up over the 8 row lanes (valid in lanes 0-7).
 template <int TZ, int TY, int TX, int MB, bool PERM, bool ABF>
-__device__ __forceinline__ void epilogue_vec16(const GArgs& a, const ClassInfo& ci, f32x16 (&acc)[MB], float* tr, int lane,
-                                               int rowblock0, int colbase, bool colact, int n, int gz0, int gy0, int gx0,
+__device__ __forceinline__ void epilogue_vec16(const GArgs& a, const float* biasp, const ClassInfo& ci, f32x16 (&acc)[MB], float* tr,
+                                               int lane, int rowblock0, int colbase, bool colact, int n, int gz0, int gy0, int gx0,
                                                float (&ssum)[4], float (&ssq)[4]) {
   // kernel-argument fields used per row: opaque scalar copies (see the tap tables of the producer/consumer kernel)
   int osd = (int)a.osd, osh = (int)a.osh, osw = (int)a.osw, asd = (int)a.asd, ash_ = (int)a.ash, asw = (int)a.asw;
@@ -129,7 +130,7 @@ __device__ __forceinline__ void epilogue_vec16(const GArgs& a, const ClassInfo& 
   const int colc = min(colv, a.Co - 4);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float asc[4] = {1.f, 1.f, 1.f, 1.f}, ash[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + colc);
+  if (biasp) bias4 = *reinterpret_cast<const float4*>(biasp + colc);
   if (a.add) nl_coeff_vec<4>(a.tadd, n, a.Co, colc, asc, ash);
 #pragma unroll
   for (int j = 0; j < 4; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
@@ -288,6 +289,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
   const int tyi = t % a.ty; t /= a.ty;
   const int tzi = t % a.tz;
   const int n = t / a.tz;
+  const float* wpn = pset_packed(a.ps, a.wp, n);        // this batch item's parameter set (workgroup-uniform)
+  const float* biasn = pset_bias(a.ps, a.bias, n);
   const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;
   const int BZ = (TZ - 1) * a.si + ci.zext + 1;
   const int BY = (TY - 1) * a.si + ci.yext + 1;
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
     if constexpr (BF) {
       if (colact && ci.ntaps == 27 && ((min(KCI, a.Ci - c0) + 15) >> 4) == WKS) {   // same test as the MFMA section
         wfirst_ok = true;
-        const uint4* wq0 = reinterpret_cast<const uint4*>(a.wp) + (long long)(c0 / 8 + h) * a.Np + colbase + r;
+        const uint4* wq0 = reinterpret_cast<const uint4*>(wpn) + (long long)(c0 / 8 + h) * a.Np + colbase + r;
         const long long slabsz8 = (long long)(a.Kp / 8) * a.Np;
 #pragma unroll
         for (int t = 0; t < WG0; ++t)
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
         const unsigned short* lh = reinterpret_cast<const unsigned short*>(lds);
         const int kreal = min(KCI, a.Ci - c0);
         const int nks = (kreal + 15) >> 4;         // 16-channel steps that carry data
-        const uint4* wq = reinterpret_cast<const uint4*>(a.wp);   // image [tap][Kp/8][Np][8 bf16]
+        const uint4* wq = reinterpret_cast<const uint4*>(wpn);   // image [tap][Kp/8][Np][8 bf16]
         const long long slabsz8 = (long long)(a.Kp / 8) * a.Np;
         const uint4* wcol = wq + (long long)(c0 / 8 + h) * a.Np + colbase + r;
         const int np2 = 2 * a.Np;
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
     if (colact) {
       constexpr int KK = KCI / 2;
       const int kreal = min(KCI, a.Ci - c0);
-      const float* wcol = a.wp + (long long)c0 * a.Np + colbase + r + (long long)h * a.Np;
+      const float* wcol = wpn + (long long)c0 * a.Np + colbase + r + (long long)h * a.Np;
       const long long slabsz = (long long)a.Kp * a.Np;
       const int np2 = 2 * a.Np;
       const int ntap = ci.ntaps;
@@ -801,8 +804,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
   if (a.ovec) {
     // 16-byte stores through a wave-private LDS tile (the K loop ended with a barrier: the box image is dead)
     float v_sum[4], v_sq[4];
-    epilogue_vec16<TZ, TY, TX, MB, BF, ABF>(a, ci, acc, lds + wave * EPI_TILE_FLOATS, lane, mg * MB, colbase, colact, n, gz0, gy0,
-                                       gx0, v_sum, v_sq);
+    epilogue_vec16<TZ, TY, TX, MB, BF, ABF>(a, biasn, ci, acc, lds + wave * EPI_TILE_FLOATS, lane, mg * MB, colbase, colact, n, gz0,
+                                            gy0, gx0, v_sum, v_sq);
     if (a.stats != nullptr) {
       float* red = lds + 4 * EPI_TILE_FLOATS;      // [4 waves][2][32], behind the four tiles
       if (lane < 8) {
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
   }
   float bias = 0.f, asc = 1.f, ash = 0.f;
   if (colok) {
-    if (a.bias) bias = a.bias[col];
+    if (biasn) bias = biasn[col];
     if (a.add) nl_coeff(a.tadd, n, a.Co, col, asc, ash);
   }
   // Per 32-row block: addresses and masks of its 16 rows first, then ALL loads of the fused add / accumulate
@@ -951,6 +954,7 @@ __global__ __launch_bounds__(256, 2) void igemm_cls8_kernel(GArgs a) {
   const int tyi = t % a.ty; t /= a.ty;
   const int tzi = t % a.tz;
   const int n = t / a.tz;
+  const float* biasn = pset_bias(a.ps, a.bias, n);
   const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;
   const int colbase = blockIdx.y * 32;
   const bool colact = colbase < a.Np;
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(256, 2) void igemm_cls8_kernel(GArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
-  const uint4* wq = reinterpret_cast<const uint4*>(a.wp);
+  const uint4* wq = reinterpret_cast<const uint4*>(pset_packed(a.ps, a.wp, n));
   const long long slabsz8 = (long long)(a.Kp / 8) * a.Np;
   const unsigned isd = (unsigned)a.isd, ish = (unsigned)a.ish, isw = (unsigned)a.isw;
   const int cmax = ABF ? ((a.Ci - 1) & ~7) : ((a.Ci - 1) & ~3);
@@ -1058,8 +1062,8 @@ __global__ __launch_bounds__(256, 2) void igemm_cls8_kernel(GArgs a) {
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     float v_sum[4], v_sq[4];
-    epilogue_vec16<TZ, TY, TX, 1, true, ABF>(a, a.cls[c], *reinterpret_cast<f32x16(*)[1]>(&acc[c]), lds + wave * EPI_TILE_FLOATS, lane,
-                                             wave, colbase, colact, n, gz0, gy0, gx0, v_sum, v_sq);
+    epilogue_vec16<TZ, TY, TX, 1, true, ABF>(a, biasn, a.cls[c], *reinterpret_cast<f32x16(*)[1]>(&acc[c]), lds + wave * EPI_TILE_FLOATS,
+                                             lane, wave, colbase, colact, n, gz0, gy0, gx0, v_sum, v_sq);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { tsum[j] += v_sum[j]; tsq[j] += v_sq[j]; }
   }
@@ -1123,7 +1127,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
   const bool colok = col < a.Co;
   float bias = 0.f, asc = 1.f, ash = 0.f;
   if (colok) {
-    if (a.bias) bias = a.bias[col];
+    const float* biasn = pset_bias(a.ps, a.bias, n);
+    if (biasn) bias = biasn[col];
     if (a.add) nl_coeff(a.tadd, n, a.Co, col, asc, ash);
   }
   float s_sum = 0.f, s_sq = 0.f;
@@ -1479,7 +1484,9 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   g.Np = roundup(g.N, 32);
   int Dg = y->d, Hg = y->h, Wg = y->w;
   if (g.classes) { Dg = (y->d + 1) / 2; Hg = (y->h + 1) / 2; Wg = (y->w + 1) / 2; }
-  g.cfg = pick_config(g.Np, g.si, (long long)x->n * Dg * Hg * Wg * (g.classes ? 8 : 1), g.K, use_bf16(d, g.K));
+  // launch geometry is a function of ONE batch item's extent: every item is computed as if launched alone (the contract of
+  // the per-item parameter sets, include/mmtta.h), the batch only multiplies the workgroups
+  g.cfg = pick_config(g.Np, g.si, (long long)Dg * Hg * Wg * (g.classes ? 8 : 1), g.K, use_bf16(d, g.K));
   g.tz = (Dg + g.cfg.TZ - 1) / g.cfg.TZ;
   g.ty = (Hg + g.cfg.TY - 1) / g.cfg.TY;
   g.tx = (Wg + g.cfg.TX - 1) / g.cfg.TX;
@@ -1489,7 +1496,7 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   g.nstages = (g.K + g.cfg.KCI - 1) / g.cfg.KCI;
   g.launches = 1;
   const int ncolgroups = (g.Np + 32 * g.cfg.NB - 1) / (32 * g.cfg.NB);
-  const int wgs = g.tiles * ncolgroups;
+  const int wgs = g.tiles_per_n * g.ncls * ncolgroups;      // per batch item
   g.ksplit = 1;
   g.sps = g.nstages;
   // Split the reduction when a launch has fewer than 192 workgroups, up to ~256.  Measured on the U-Net: with ONE volume
@@ -1507,7 +1514,7 @@ static int geometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   g.fused = false;
   if (g.classes && g.cfg.bf && g_cls_fused_min > 0) {
     const int ftz = (Dg + 3) / 4, fty = (Hg + 3) / 4, ftx = (Wg + 7) / 8;
-    const long long fw = (long long)ftz * fty * ftx * x->n * (g.Np / 32);
+    const long long fw = (long long)ftz * fty * ftx * (g.Np / 32);      // per batch item
     auto al = [](const mmtta_tensor* t) {
       const int64_t q = is_bf16(t) ? 8 : 4, lim24 = (int64_t)1 << 24;
       const int64_t last = (int64_t)(t->d - 1) * t->sd + (int64_t)(t->h - 1) * t->sh + (int64_t)(t->w - 1) * t->sw + t->c + 16;
@@ -1774,15 +1781,25 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
                               const void* packed, const float* bias, const mmtta_conv_epilogue* epi,
                               const mmtta_tensor* y, int accumulate, float* stats, void* workspace,
                               int64_t workspace_bytes, void* stream) {
+  return mmtta_conv_run_sets(d, x, x_norm, packed, bias, epi, y, accumulate, stats, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int mmtta_conv_run_sets(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                                   const void* packed, const float* bias, const mmtta_conv_epilogue* epi,
+                                   const mmtta_tensor* y, int accumulate, float* stats, void* workspace,
+                                   int64_t workspace_bytes, const mmtta_param_sets* sets, void* stream) {
   Geometry g;
   int st = geometry(d, x, y, g);
   if (st) return st;
   MMTTA_CHECK(packed != nullptr, MMTTA_ERR_INVALID, "conv: null packed weights");
-  if (direct_applicable(d)) return direct_conv_run(d, x, x_norm, packed, bias, epi, y, accumulate, stats, (hipStream_t)stream);
+  st = psets_validate(sets, x->n);
+  if (st) return st;
+  const PSets ps = psets(sets);
+  if (direct_applicable(d)) return direct_conv_run(d, x, x_norm, packed, bias, epi, y, accumulate, stats, ps, (hipStream_t)stream);
   if (pointwise_small_applicable(d, x, y, stats, epi, x_norm) && !use_bf16(d, g.K) && is_f32(x) && is_f32(y))
-    return pointwise_small_run(x, packed, g.Kp, g.Np, bias, y, accumulate, (hipStream_t)stream);
+    return pointwise_small_run(x, packed, g.Kp, g.Np, bias, y, accumulate, ps, (hipStream_t)stream);
   if (chan_applicable(d, x, y) && !use_bf16(d, g.K))
-    return chan_conv_run(d, x, x_norm, packed, g.Kp, g.Np, bias, epi, y, accumulate, stats, (hipStream_t)stream);
+    return chan_conv_run(d, x, x_norm, packed, g.Kp, g.Np, bias, epi, y, accumulate, stats, ps, (hipStream_t)stream);
   const int64_t need = g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * 4 : 0;
   MMTTA_CHECK(need == 0 || (workspace != nullptr && workspace_bytes >= need), MMTTA_ERR_WORKSPACE,
               "conv: workspace %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);
@@ -1795,6 +1812,7 @@ extern "C" int mmtta_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, c
   a.si = g.si;
   a.wp = (const float*)packed; a.Kp = g.Kp; a.Np = g.Np;
   a.bias = bias;
+  a.ps = ps;
   a.add = nullptr; a.asn = a.asd = a.ash = a.asw = 0; a.tadd = nl(nullptr);
   if (epi && epi->add) {
     const mmtta_tensor* ad = epi->add;

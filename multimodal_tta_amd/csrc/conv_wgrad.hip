@@ -31,6 +31,7 @@ struct WArgs {
   float* slab;     // [nsl][ntaps][CGp][CDp]
   float* dbpart;   // [nsl][CDp] or null
   int tz, ty, tx, tiles, tiles_per_split;
+  int S, tiles_set;   // slabs and tiles per parameter set (one set: S = launch slabs, tiles_set = tiles)
   int CGp, CDp;
   int gvec4, dvec4;
   int g_bf, d_bf;   // storage of the gathered / dense tensor: 1 = bf16 elements (the forward activation of bf16 precision)
@@ -71,9 +72,12 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
 
   // slab index = blockIdx.x; the TILE RANGE of a slab follows the XCD-contiguous order, so the workgroups of one XCD
   // sweep one contiguous part of the volume and re-read each other's halo rows from their own L2
+  // slab sx = slab (sx % S) of parameter set (sx / S): a set's slabs cover ITS batch items only, in the order a launch of
+  // those items alone would use (the reduce kernels then sum a set's rows in that same order)
   const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
-  const int t0 = sx * a.tiles_per_split;
-  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
+  const int qset = sx / a.S, sls = sx - qset * a.S;
+  const int t0 = qset * a.tiles_set + sls * a.tiles_per_split;
+  const int t1 = min((qset + 1) * a.tiles_set, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
   for (int tile = t0; tile < t1; ++tile) {
     const int n = tile / tpn;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
   }
 
   // ---- flush partials
-  const int sl = NTW == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x;
+  const int sl = NTW == 1 ? (sx * 4 + wave) : sx;
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const int tap = NTW == 1 ? 0 : wave + 4 * j;
@@ -238,8 +242,14 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WArgs a) {
 __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                              int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate,
                                                              const float* __restrict__ dbpart, float* __restrict__ db,
-                                                             int db_nsl) {
+                                                             int db_nsl, PSets ps) {
   __shared__ float tile[32][28];
+  {  // parameter set blockIdx.z: its rows of the slab / bias partials, its dw / db
+    const int q = blockIdx.z;
+    slab += (long long)q * nsl * 27 * CGp * CDp;
+    dw += pset_weight_elems(ps, q);
+    if (db != nullptr) { dbpart += (long long)q * db_nsl * CDp; db += pset_bias_elems(ps, q); }
+  }
   const int cd0 = blockIdx.y * 32;
   if ((int)blockIdx.x == Cg) {
     // bias gradient rows ride in the same launch: db[cd] (+)= sum_sl dbpart[sl][cd]; 8 threads per channel
@@ -309,8 +319,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce27_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                            int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate) {
+                                                            int nsl, int Cg, int Cd, int CGp, int CDp, int accumulate, PSets ps) {
   __shared__ float tile[32][33];
+  slab += (long long)blockIdx.z * nsl * CGp * CDp;       // parameter set blockIdx.z
+  dw += pset_weight_elems(ps, blockIdx.z);
   const int cg0 = blockIdx.x * 32, cd0 = blockIdx.y * 32;
   for (int i = threadIdx.x; i < 32 * 32; i += 256) {
     const int cdl = i & 31, cgl = i >> 5;
@@ -335,6 +347,8 @@ __global__ __launch_bounds__(256) void slab_prereduce_kernel(const float* __rest
                                                              int nsl, long long elems) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= elems) return;
+  slab += (long long)blockIdx.z * nsl * elems;           // parameter set blockIdx.z: its slabs, its chunks
+  out += (long long)blockIdx.z * gridDim.y * elems;
   const int s0 = blockIdx.y * 32, s1 = min(nsl, s0 + 32);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int sl = s0; sl < s1; sl += 8) {          // 8 independent loads per trip (clamped, masked)
@@ -349,8 +363,10 @@ __global__ __launch_bounds__(256) void slab_prereduce_kernel(const float* __rest
 
 // db[c] (+)= sum_sl part[sl*ld + c]: one wave per channel, lanes stride the partial rows
 __global__ __launch_bounds__(64) void db_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, int nsl,
-                                                       int C, int ld, int accumulate) {
+                                                       int C, int ld, int accumulate, PSets ps, int is_weight) {
   const int c = blockIdx.x;
+  part += (long long)blockIdx.y * nsl * ld;              // parameter set blockIdx.y
+  db += is_weight ? pset_weight_elems(ps, blockIdx.y) : pset_bias_elems(ps, blockIdx.y);
   float s = 0.f;
   for (int sl = threadIdx.x; sl < nsl; sl += 64) s += part[(long long)sl * ld + c];
   s = wave_sum(s);
@@ -471,9 +487,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
   const unsigned gsd = (unsigned)a.gsd, gsh = (unsigned)a.gsh, gsw = (unsigned)a.gsw;
   const unsigned dsd = (unsigned)a.dsd, dsh = (unsigned)a.dsh, dsw = (unsigned)a.dsw;
 
+  // slab sx = slab (sx % S) of parameter set (sx / S): a set's slabs cover ITS batch items only, in the order a launch of
+  // those items alone would use (the reduce kernels then sum a set's rows in that same order)
   const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
-  const int t0 = sx * a.tiles_per_split;
-  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
+  const int qset = sx / a.S, sls = sx - qset * a.S;
+  const int t0 = qset * a.tiles_set + sls * a.tiles_per_split;
+  const int t1 = min((qset + 1) * a.tiles_set, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
   constexpr int GP = G::GP, DP = G::DP;
   constexpr int PREF = (GBF || DBF) ? 40 : 32;                         // registers the cross-loop prefetch may hold
@@ -640,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
     }
     __syncthreads();
   }
-  const int sl = blockIdx.x;
+  const int sl = sx;
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     const int tap = wave + 4 * j;
@@ -723,9 +742,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr1_kernel(WArgs a) {
   const unsigned gsd = (unsigned)a.gsd, gsh = (unsigned)a.gsh, gsw = (unsigned)a.gsw;
   const unsigned dsd = (unsigned)a.dsd, dsh = (unsigned)a.dsh, dsw = (unsigned)a.dsw;
 
+  // slab sx = slab (sx % S) of parameter set (sx / S): a set's slabs cover ITS batch items only, in the order a launch of
+  // those items alone would use (the reduce kernels then sum a set's rows in that same order)
   const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
-  const int t0 = sx * a.tiles_per_split;
-  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
+  const int qset = sx / a.S, sls = sx - qset * a.S;
+  const int t0 = qset * a.tiles_set + sls * a.tiles_per_split;
+  const int t1 = min((qset + 1) * a.tiles_set, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
   Oct8<GBF> gv[NP];
   Oct8<DBF> dq[NP];
@@ -810,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr1_kernel(WArgs a) {
     for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[i], acc, 0, 0, 0);
     __syncthreads();
   }
-  const int sl = blockIdx.x * 4 + wave;                               // one slab per wave (the reduce kernels sum them)
+  const int sl = sx * 4 + wave;                                       // one slab per wave (the reduce kernels sum them)
   {
     float* sb = a.slab + ((long long)sl * a.CGp + cg0) * a.CDp + cd0 + r;
 #pragma unroll
@@ -828,9 +850,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr1_kernel(WArgs a) {
       float sacc = 0.f;
 #pragma unroll 8
       for (int q = 0; q < 64; ++q) sacc += red8[((q << 2) | (tid >> 3)) * 8 + (tid & 7)];
-      a.dbpart[(long long)(blockIdx.x * 4) * a.CDp + cd0 + tid] = sacc;
+      a.dbpart[(long long)(sx * 4) * a.CDp + cd0 + tid] = sacc;
 #pragma unroll
-      for (int w2 = 1; w2 < 4; ++w2) a.dbpart[(long long)(blockIdx.x * 4 + w2) * a.CDp + cd0 + tid] = 0.f;
+      for (int w2 = 1; w2 < 4; ++w2) a.dbpart[(long long)(sx * 4 + w2) * a.CDp + cd0 + tid] = 0.f;
     }
   }
 }
@@ -881,6 +903,7 @@ struct W2Args {
   float* slab;     // [nsl][128][CBp]
   float* dbpart;   // [nsl][CBp] or null: per-channel sums of P (bias gradient when cb is the output channel)
   int tz, ty, tx, tiles, tiles_per_split, CBp;
+  int S, tiles_set;   // slabs and tiles per parameter set
   int qvec4, pvec4;
   int p_bf;        // the dense tensor P is bf16-stored (forward activation of bf16 precision)
   int bf;          // bf16 precision mode: operands rounded to bf16, 16 voxels per v_mfma_f32_32x32x16_bf16
@@ -914,8 +937,10 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float dbacc = 0.f;
-  const int t0 = (int)xcd_contiguous_id(blockIdx.x, gridDim.x) * a.tiles_per_split;   // one part of the volume per XCD
-  const int t1 = min(a.tiles, t0 + a.tiles_per_split);
+  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);                       // one part of the volume per XCD
+  const int qset = sx / a.S, sls = sx - qset * a.S;                                   // (parameter set, slab of the set)
+  const int t0 = qset * a.tiles_set + sls * a.tiles_per_split;
+  const int t1 = min((qset + 1) * a.tiles_set, t0 + a.tiles_per_split);
   const int tpn = a.tz * a.ty * a.tx;
   // Both operands 16-byte addressable (every layer of the shipped networks): the NEXT tile's global loads are issued
   // before this tile's MFMAs and land while they run (a workgroup walked load -> barrier -> MFMA -> barrier with one
@@ -1132,7 +1157,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
     }
     __syncthreads();
   }
-  const int sl = blockIdx.x;
+  const int sl = sx;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -1147,7 +1172,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
 // small_is_cd == 0: dw[(cb*Cs + cs)*ntaps + tap]   (Conv3d with tiny Cin, ConvTranspose3d with tiny Cout)
 // small_is_cd == 1: dw[(cs*Cb + cb)*ntaps + tap]   (1x1x1 Conv3d with tiny Cout)
 __global__ void wgrad_small_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsl, int ntaps, int Cs,
-                                          int Cb, int CBp, int small_is_cd, int accumulate) {
+                                          int Cb, int CBp, int small_is_cd, int accumulate, PSets ps) {
+  slab += (long long)blockIdx.y * nsl * 128 * CBp;       // parameter set blockIdx.y
+  dw += pset_weight_elems(ps, blockIdx.y);
   const int total = ntaps * Cs * Cb;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int cb = i % Cb, row = i / Cb;
@@ -1173,6 +1200,7 @@ struct WTArgs {
   float* part;      // [blocks][ld]: dw layout [cb][cs][27]
   float* dbpart;    // [blocks][4] or null
   int ld;
+  int B, ips;       // workgroups and batch items per parameter set
 };
 
 template <int CS, int CB, bool HAS_T>
@@ -1183,7 +1211,7 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
   const int kz = blockIdx.y;
   const int chunks = (a.dy.w + 63) / 64;
   const int hp = (a.dy.h + 1) / 2;                     // a wave takes two adjacent rows per step
-  const long long units = (long long)a.dy.n * a.dy.d * hp * chunks;
+  const long long units = (long long)a.ips * a.dy.d * hp * chunks;       // of ONE parameter set
   const int xsw4 = (int)a.x.sw * 4, dsw4 = (int)a.dy.sw * 4;
   float acc[9][CS][CB];
 #pragma unroll
@@ -1200,7 +1228,10 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
 #pragma unroll
   for (int i = 0; i < CS; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
   long long ufirst, ulast;
-  unit_range(units, xcd_contiguous_id(blockIdx.x, gridDim.x), gridDim.x, ufirst, ulast);
+  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int qset = sx / a.B;                            // workgroup sx = workgroup (sx % B) of parameter set (sx / B)
+  unit_range(units, sx - qset * a.B, a.B, ufirst, ulast);
+  ufirst += (long long)qset * units; ulast += (long long)qset * units;
   // the unit index is decoded ONCE (three 64-bit divisions) and then advanced by carries: all of it wave-uniform
   int chunk, oyp, oz, n;
   {
@@ -1300,9 +1331,9 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
     const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     if (e < 9 * CS * CB) {
       const int j = e % CB, i = (e / CB) % CS, t = e / (CB * CS);
-      a.part[(long long)blockIdx.x * a.ld + (j * CS + i) * 27 + kz * 9 + t] = v;
+      a.part[(long long)sx * a.ld + (j * CS + i) * 27 + kz * 9 + t] = v;
     } else if (kz == 1 && a.dbpart != nullptr) {
-      a.dbpart[(long long)blockIdx.x * 4 + (e - 9 * CS * CB)] = v;
+      a.dbpart[(long long)sx * 4 + (e - 9 * CS * CB)] = v;
     }
   }
 }
@@ -1354,10 +1385,18 @@ struct WGeo {
   bool convt;
   bool tr;        // bf16 27-tap layer on the transposed-read kernel (its own tile shape)
   bool tr1;       // 1x1x1 layer of bf16 precision on the transposed-read streaming kernel
+  int ips, nsets; // batch items per parameter set, sets per launch: tiles / S / nsl / *_floats / colsum_blocks are PER SET
 };
 
-static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* dy, WGeo& w) {
+static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* dy, const mmtta_param_sets* sets, WGeo& w) {
   MMTTA_CHECK(d && x && dy && x->ptr && dy->ptr, MMTTA_ERR_INVALID, "wgrad: null argument");
+  {
+    const int st = psets_validate(sets, x->n);
+    if (st) return st;
+  }
+  // one parameter set = `ips` consecutive batch items; everything below describes ONE set (the launch repeats it nsets times)
+  w.ips = sets ? sets->items_per_set : x->n;
+  w.nsets = x->n / w.ips;
   MMTTA_CHECK(d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_FWD, MMTTA_ERR_INVALID,
               "wgrad: desc.op must name the module (CONV_FWD or CONVT_FWD)");
   MMTTA_CHECK(d->ksize == 1 || d->ksize == 3, MMTTA_ERR_UNSUPPORTED, "wgrad: ksize %d", d->ksize);
@@ -1388,7 +1427,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   };
   w.tiny = !w.convt && d->cin <= 4 && d->cout <= 4 && d->ksize == 3 && d->stride == 1 && al16(x) && al16(dy);
   if (w.tiny) {
-    const long long units = (long long)dy->n * dy->d * ((dy->h + 1) / 2) * ((dy->w + 63) / 64);
+    const long long units = (long long)w.ips * dy->d * ((dy->h + 1) / 2) * ((dy->w + 63) / 64);
     long long blocks = (units + 3) / 4;
     if (blocks > 512) blocks = 512;
     w.tiny_blocks = (int)blocks;
@@ -1411,7 +1450,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   if (w.small) {
     w.TZ = 4; w.TY = 4; w.TX = 8;
     w.tz = (w.pb->d + 3) / 4; w.ty = (w.pb->h + 3) / 4; w.tx = (w.pb->w + 7) / 8;
-    w.tiles = w.tz * w.ty * w.tx * x->n;
+    w.tiles = w.tz * w.ty * w.tx * w.ips;
     w.CGp = 128;
     w.CDp = roundup(w.pb->c, 32);
     // slabs: one volume in flight 256 / 512 / 768 / 1024 -> 56 / 46 / 57 / 57 us per launch at 128^3; two in flight
@@ -1428,7 +1467,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     w.colsum_blocks = 0;
     const bool bias_from_p = (w.pb == dy);           // P carries the output channels
     if (bias_from_p) w.db_floats = (int64_t)w.nsl * w.CDp;
-    else { w.colsum_blocks = (int64_t)dy->n * channel_partial_rows(dy); w.db_floats = w.colsum_blocks * 2 * dy->c; }
+    else { w.colsum_blocks = (int64_t)w.ips * channel_partial_rows(dy); w.db_floats = w.colsum_blocks * 2 * dy->c; }
     return MMTTA_OK;
   }
   // bf16 operands: the transposed-read kernel, for operand pairs that admit its 16-byte items; anything else (ragged
@@ -1445,7 +1484,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.tz = (w.dn->d + w.TZ - 1) / w.TZ;
   w.ty = (w.dn->h + w.TY - 1) / w.TY;
   w.tx = (w.dn->w + w.TX - 1) / w.TX;
-  w.tiles = w.tz * w.ty * w.tx * x->n;
+  w.tiles = w.tz * w.ty * w.tx * w.ips;
   w.CGp = roundup(w.g->c, 32);
   w.CDp = roundup(w.dn->c, 32);
   const int blocks_cc = (w.CGp / 32) * (w.CDp / 32);
@@ -1464,7 +1503,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.pre_floats = (int64_t)w.pre_chunks * w.ntaps * w.CGp * w.CDp;
   w.colsum_blocks = 0;
   if (w.convt) {
-    w.colsum_blocks = (int64_t)dy->n * channel_partial_rows(dy);
+    w.colsum_blocks = (int64_t)w.ips * channel_partial_rows(dy);
     w.db_floats = w.colsum_blocks * 2 * dy->c;
   } else {
     w.db_floats = (int64_t)w.nsl * w.CDp;
@@ -1500,16 +1539,21 @@ static int launch_wgrad(const WArgs& a, int S, hipStream_t s) {
 
 using namespace mmtta;
 
+extern "C" int64_t mmtta_conv_wgrad_workspace_bytes_sets(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* dy,
+                                                         const mmtta_param_sets* sets) {
+  WGeo w;
+  if (wgeometry(d, x, dy, sets, w)) return -1;
+  return (w.slab_floats + w.db_floats + w.pre_floats) * w.nsets * (int64_t)sizeof(float);
+}
+
 extern "C" int64_t mmtta_conv_wgrad_workspace_bytes(const mmtta_conv_desc* d, const mmtta_tensor* x,
                                                     const mmtta_tensor* dy) {
-  WGeo w;
-  if (wgeometry(d, x, dy, w)) return -1;
-  return (w.slab_floats + w.db_floats + w.pre_floats) * (int64_t)sizeof(float);
+  return mmtta_conv_wgrad_workspace_bytes_sets(d, x, dy, nullptr);
 }
 
 extern "C" int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* dy) {
   WGeo w;
-  const int st = wgeometry(d, x, dy, w);
+  const int st = wgeometry(d, x, dy, nullptr, w);
   if (st) return st < 0 ? st : -st;
   if (w.tiny) return 6;
   if (w.small) return 3;
@@ -1521,12 +1565,14 @@ extern "C" int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* d, const mmtta_ten
 
 static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
                            const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
-                           int64_t workspace_bytes, void* stream) {
+                           int64_t workspace_bytes, const mmtta_param_sets* sets, void* stream) {
   WGeo w;
-  int st = wgeometry(d, x, dy, w);
+  int st = wgeometry(d, x, dy, sets, w);
   if (st) return st;
+  const PSets ps = psets(sets);
+  const int Q = w.nsets;                 // the workspace regions below hold Q sets back to back (set-major)
   MMTTA_CHECK(dw != nullptr, MMTTA_ERR_INVALID, "wgrad: null dw");
-  const int64_t need = (w.slab_floats + w.db_floats + w.pre_floats) * 4;
+  const int64_t need = (w.slab_floats + w.db_floats + w.pre_floats) * Q * 4;
   MMTTA_CHECK(workspace != nullptr && workspace_bytes >= need, MMTTA_ERR_WORKSPACE, "wgrad: workspace %lld bytes, need %lld",
               (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
@@ -1535,14 +1581,15 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
     WTArgs t;
     t.x = tv(x); t.tx = nl(x_norm); t.dy = tv(dy);
     t.part = (float*)workspace; t.ld = 27 * d->cin * d->cout;
-    t.dbpart = db != nullptr ? (float*)workspace + w.slab_floats : nullptr;
-    if (t.tx.mean != nullptr || t.tx.scale != nullptr) launch_tiny<true>(t, d->cin, d->cout, w.tiny_blocks, s);
-    else launch_tiny<false>(t, d->cin, d->cout, w.tiny_blocks, s);
+    t.dbpart = db != nullptr ? (float*)workspace + w.slab_floats * Q : nullptr;
+    t.B = w.tiny_blocks; t.ips = w.ips;
+    if (t.tx.mean != nullptr || t.tx.scale != nullptr) launch_tiny<true>(t, d->cin, d->cout, w.tiny_blocks * Q, s);
+    else launch_tiny<false>(t, d->cin, d->cout, w.tiny_blocks * Q, s);
     st = launch_status("wgrad tiny");
     if (st || g_profile_main_only) return st;
-    hipLaunchKernelGGL(db_reduce_kernel, dim3(t.ld), dim3(64), 0, s, t.part, dw, w.tiny_blocks, t.ld, t.ld, accumulate);
+    hipLaunchKernelGGL(db_reduce_kernel, dim3(t.ld, Q), dim3(64), 0, s, t.part, dw, w.tiny_blocks, t.ld, t.ld, accumulate, ps, 1);
     if (db != nullptr)
-      hipLaunchKernelGGL(db_reduce_kernel, dim3(d->cout), dim3(64), 0, s, t.dbpart, db, w.tiny_blocks, d->cout, 4, accumulate);
+      hipLaunchKernelGGL(db_reduce_kernel, dim3(d->cout, Q), dim3(64), 0, s, t.dbpart, db, w.tiny_blocks, d->cout, 4, accumulate, ps, 0);
     return launch_status("wgrad tiny reduce");
   }
   if (w.small) {
@@ -1555,10 +1602,11 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
     b.tp = w.q_is_x ? nl(nullptr) : nl(x_norm);
     b.si = w.si; b.ntaps = w.ntaps;
     b.slab = (float*)workspace;
-    float* dbws2 = (float*)workspace + w.slab_floats;
+    float* dbws2 = (float*)workspace + w.slab_floats * Q;
     const bool bias_from_p = (w.pb == dy);
     b.dbpart = (db != nullptr && bias_from_p) ? dbws2 : nullptr;
-    b.tz = w.tz; b.ty = w.ty; b.tx = w.tx; b.tiles = w.tiles; b.tiles_per_split = w.tps; b.CBp = w.CDp;
+    b.tz = w.tz; b.ty = w.ty; b.tx = w.tx; b.tiles = w.tiles * Q; b.tiles_per_split = w.tps; b.CBp = w.CDp;
+    b.S = w.S; b.tiles_set = w.tiles;
     auto al4 = [](const mmtta_tensor* t) {
       return ((((uintptr_t)t->ptr) % 16 == 0) && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0) ? 1 : 0;
     };
@@ -1572,7 +1620,7 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
     const size_t lds = ((size_t)BZ * BY * BX * 4 + 128 * 32) * sizeof(float);
     MMTTA_CHECK((w.ntaps == 27 && (w.si == 1 || w.si == 2)) || (w.ntaps == 1 && w.si == 1), MMTTA_ERR_UNSUPPORTED,
                 "wgrad (thin layer): %d taps with stride %d", w.ntaps, w.si);
-    const dim3 sg(w.S, w.CDp / 32);
+    const dim3 sg(w.S * Q, w.CDp / 32);
     if (w.ntaps == 1) {
       if (b.p_bf) hipLaunchKernelGGL((wgrad_small_kernel<true, 1, false>), sg, dim3(256), lds, s, b);
       else hipLaunchKernelGGL((wgrad_small_kernel<false, 1, false>), sg, dim3(256), lds, s, b);
@@ -1589,26 +1637,26 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
     const float* rsrc = b.slab;
     int rn = w.nsl;
     if (w.pre_chunks > 0) {
-      float* pre = (float*)workspace + w.slab_floats + w.db_floats;
+      float* pre = (float*)workspace + (w.slab_floats + w.db_floats) * Q;
       const long long elems = (long long)128 * w.CDp;
-      hipLaunchKernelGGL(slab_prereduce_kernel, dim3((unsigned)((elems + 255) / 256), w.pre_chunks), dim3(256), 0, s, b.slab,
+      hipLaunchKernelGGL(slab_prereduce_kernel, dim3((unsigned)((elems + 255) / 256), w.pre_chunks, Q), dim3(256), 0, s, b.slab,
                          pre, w.nsl, elems);
       st = launch_status("wgrad small prereduce");
       if (st) return st;
       rsrc = pre; rn = w.pre_chunks;
     }
-    hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, rsrc, dw, rn, w.ntaps, b.Cs,
-                       b.Cb, w.CDp, w.small_is_cd, accumulate);
+    hipLaunchKernelGGL(wgrad_small_reduce_kernel, dim3((total + 255) / 256, Q), dim3(256), 0, s, rsrc, dw, rn, w.ntaps, b.Cs,
+                       b.Cb, w.CDp, w.small_is_cd, accumulate, ps);
     st = launch_status("wgrad small reduce");
     if (st) return st;
     if (db != nullptr) {
       if (bias_from_p) {
-        hipLaunchKernelGGL(db_reduce_kernel, dim3(b.Cb), dim3(64), 0, s, dbws2, db, w.nsl, b.Cb, w.CDp, accumulate);
+        hipLaunchKernelGGL(db_reduce_kernel, dim3(b.Cb, Q), dim3(64), 0, s, dbws2, db, w.nsl, b.Cb, w.CDp, accumulate, ps, 0);
       } else {
-        st = launch_channel_sums(dy, dbws2, s);
+        st = launch_channel_sums(dy, dbws2, s);          // rows are n-major: a set's rows are contiguous
         if (st) return st;
-        hipLaunchKernelGGL(db_reduce_kernel, dim3(dy->c), dim3(64), 0, s, dbws2, db, (int)w.colsum_blocks, dy->c, 2 * dy->c,
-                           accumulate);
+        hipLaunchKernelGGL(db_reduce_kernel, dim3(dy->c, Q), dim3(64), 0, s, dbws2, db, (int)w.colsum_blocks, dy->c, 2 * dy->c,
+                           accumulate, ps, 0);
       }
       st = launch_status("bias reduce");
     }
@@ -1625,26 +1673,28 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
   a.N = x->n;
   a.si = w.si; a.ntaps = w.ntaps;
   a.slab = (float*)workspace;
-  float* dbws = (float*)workspace + w.slab_floats;
+  float* dbws = (float*)workspace + w.slab_floats * Q;
   a.dbpart = (db != nullptr && !w.convt) ? dbws : nullptr;
-  a.tz = w.tz; a.ty = w.ty; a.tx = w.tx; a.tiles = w.tiles; a.tiles_per_split = w.tps;
+  a.tz = w.tz; a.ty = w.ty; a.tx = w.tx; a.tiles = w.tiles * Q; a.tiles_per_split = w.tps;
+  a.S = w.S; a.tiles_set = w.tiles;
   a.CGp = w.CGp; a.CDp = w.CDp;
   a.g_bf = is_bf16(w.g) ? 1 : 0;
   a.d_bf = is_bf16(w.dn) ? 1 : 0;
   a.convt = w.convt ? 1 : 0;
   a.gvec4 = wvec_ok(w.g) ? 1 : 0;
   a.dvec4 = wvec_ok(w.dn) ? 1 : 0;
-  if (w.tr1) st = launch_wgrad_tr1(a, w.S, s);
-  else if (w.tr) st = (w.si == 1) ? launch_wgrad_tr<4, 8, 1>(a, w.S, s) : launch_wgrad_tr<2, 4, 2>(a, w.S, s);
-  else if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, w.S, s);
-  else st = (w.si == 1) ? launch_wgrad<4, 4, 8, 7>(a, w.S, s) : launch_wgrad<2, 2, 8, 7>(a, w.S, s);
+  const int SQ = w.S * Q;                // slabs of the launch
+  if (w.tr1) st = launch_wgrad_tr1(a, SQ, s);
+  else if (w.tr) st = (w.si == 1) ? launch_wgrad_tr<4, 8, 1>(a, SQ, s) : launch_wgrad_tr<2, 4, 2>(a, SQ, s);
+  else if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, SQ, s);
+  else st = (w.si == 1) ? launch_wgrad<4, 4, 8, 7>(a, SQ, s) : launch_wgrad<2, 2, 8, 7>(a, SQ, s);
   if (st || g_profile_main_only) return st;
   const float* rsrc = a.slab;
   int rn = w.nsl;
   if (w.pre_chunks > 0) {
-    float* pre = (float*)workspace + w.slab_floats + w.db_floats;
+    float* pre = (float*)workspace + (w.slab_floats + w.db_floats) * Q;
     const long long elems = (long long)w.ntaps * w.CGp * w.CDp;
-    hipLaunchKernelGGL(slab_prereduce_kernel, dim3((unsigned)((elems + 255) / 256), w.pre_chunks), dim3(256), 0, s, a.slab, pre,
+    hipLaunchKernelGGL(slab_prereduce_kernel, dim3((unsigned)((elems + 255) / 256), w.pre_chunks, Q), dim3(256), 0, s, a.slab, pre,
                        w.nsl, elems);
     st = launch_status("wgrad prereduce");
     if (st) return st;
@@ -1652,23 +1702,23 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
   }
   const bool db_here = db != nullptr && !w.convt;      // bias partials written by the main kernel: [nsl][CDp]
   if (w.ntaps == 27)
-    hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3(a.Cg + (db_here ? 1 : 0), (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
-                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, dbws, db, w.nsl);
+    hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3(a.Cg + (db_here ? 1 : 0), (a.Cd + 31) / 32, Q), dim3(256), 0, s, rsrc, dw, rn,
+                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, dbws, db_here ? db : nullptr, w.nsl, ps);
   else
-    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((a.Cg + 31) / 32, (a.Cd + 31) / 32), dim3(256), 0, s, rsrc, dw, rn,
-                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((a.Cg + 31) / 32, (a.Cd + 31) / 32, Q), dim3(256), 0, s, rsrc, dw, rn,
+                       a.Cg, a.Cd, w.CGp, w.CDp, accumulate, ps);
   st = launch_status("wgrad reduce");
   if (st) return st;
   if (db != nullptr) {
     if (!w.convt) {
       if (w.ntaps != 27)
-        hipLaunchKernelGGL(db_reduce_kernel, dim3(a.Cd), dim3(64), 0, s, dbws, db, w.nsl, a.Cd, w.CDp, accumulate);
+        hipLaunchKernelGGL(db_reduce_kernel, dim3(a.Cd, Q), dim3(64), 0, s, dbws, db, w.nsl, a.Cd, w.CDp, accumulate, ps, 0);
     } else {
       // ConvTranspose3d bias gradient = per-channel sum of dy over the fine grid
       st = launch_channel_sums(dy, dbws, s);
       if (st) return st;
-      hipLaunchKernelGGL(db_reduce_kernel, dim3(dy->c), dim3(64), 0, s, dbws, db, (int)w.colsum_blocks, dy->c,
-                         2 * dy->c, accumulate);
+      hipLaunchKernelGGL(db_reduce_kernel, dim3(dy->c, Q), dim3(64), 0, s, dbws, db, (int)w.colsum_blocks, dy->c,
+                         2 * dy->c, accumulate, ps, 0);
     }
     st = launch_status("bias reduce");
   }
@@ -1678,5 +1728,11 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
 extern "C" int mmtta_conv_wgrad(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
                                 const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
                                 int64_t workspace_bytes, void* stream) {
-  return conv_wgrad_impl(d, x, x_norm, dy, dw, db, accumulate, workspace, workspace_bytes, stream);
+  return conv_wgrad_impl(d, x, x_norm, dy, dw, db, accumulate, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int mmtta_conv_wgrad_sets(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_norm_on_load* x_norm,
+                                     const mmtta_tensor* dy, float* dw, float* db, int accumulate, void* workspace,
+                                     int64_t workspace_bytes, const mmtta_param_sets* sets, void* stream) {
+  return conv_wgrad_impl(d, x, x_norm, dy, dw, db, accumulate, workspace, workspace_bytes, sets, stream);
 }

@@ -20,8 +20,13 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   return t;  // valid on thread 0
 }
 
-__global__ __launch_bounds__(256) void entropy_bernoulli_kernel(TV z, TV dz, double* partial, float inv_count) {
+__global__ __launch_bounds__(256) void entropy_bernoulli_kernel(TV z, TV dz, double* partial, float inv_count, int per_item) {
   __shared__ double sh[4];
+  if (per_item) {      // N independent volumes: this workgroup column works on batch item blockIdx.y alone
+    z.p += (long long)blockIdx.y * z.sn; dz.p += (long long)blockIdx.y * dz.sn;
+    z.n = 1; dz.n = 1;
+    partial += (long long)blockIdx.y * gridDim.x;
+  }
   const int C = z.c;
   const long long total = (long long)z.n * z.d * z.h * z.w * C;
   double acc = 0.0;
@@ -46,8 +51,13 @@ __global__ __launch_bounds__(256) void entropy_bernoulli_kernel(TV z, TV dz, dou
 
 // Fast path of the Bernoulli objective: <= 4 regions in 16-byte voxel rows, dense voxel order.  A thread owns a
 // voxel: one 16-byte load, one 16-byte store (the gradient tensor owns its pad lane), no index arithmetic.
-__global__ __launch_bounds__(256) void entropy_bernoulli_vec_kernel(TV z, TV dz, double* partial, float inv_count) {
+__global__ __launch_bounds__(256) void entropy_bernoulli_vec_kernel(TV z, TV dz, double* partial, float inv_count, int per_item) {
   __shared__ double sh[4];
+  if (per_item) {      // N independent volumes: this workgroup column works on batch item blockIdx.y alone
+    z.p += (long long)blockIdx.y * z.sn; dz.p += (long long)blockIdx.y * dz.sn;
+    z.n = 1; dz.n = 1;
+    partial += (long long)blockIdx.y * gridDim.x;
+  }
   const int C = z.c;
   const long long dhw = (long long)z.d * z.h * z.w;
   const long long total = (long long)z.n * dhw;
@@ -78,8 +88,13 @@ __global__ __launch_bounds__(256) void entropy_bernoulli_vec_kernel(TV z, TV dz,
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(256) void entropy_categorical_kernel(TV z, TV dz, double* partial, float inv_count) {
+__global__ __launch_bounds__(256) void entropy_categorical_kernel(TV z, TV dz, double* partial, float inv_count, int per_item) {
   __shared__ double sh[4];
+  if (per_item) {      // N independent volumes: this workgroup column works on batch item blockIdx.y alone
+    z.p += (long long)blockIdx.y * z.sn; dz.p += (long long)blockIdx.y * dz.sn;
+    z.n = 1; dz.n = 1;
+    partial += (long long)blockIdx.y * gridDim.x;
+  }
   const int R = z.c;
   const long long total = (long long)z.n * z.d * z.h * z.w;
   double acc = 0.0;
@@ -121,10 +136,11 @@ __global__ __launch_bounds__(256) void entropy_categorical_kernel(TV z, TV dz, d
 
 __global__ __launch_bounds__(64) void entropy_finish_kernel(const double* partial, int nblocks, double inv_count,
                                                             float* loss) {
+  partial += (long long)blockIdx.x * nblocks;      // one workgroup per independent item (a single one otherwise)
   double s = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 64) s += partial[i];
   s = wave_sum_d(s);
-  if (threadIdx.x == 0) *loss = (float)(s * inv_count);
+  if (threadIdx.x == 0) loss[blockIdx.x] = (float)(s * inv_count);
 }
 
 static int entropy_blocks(const mmtta_tensor* z) {
@@ -145,8 +161,14 @@ static int entropy_blocks(const mmtta_tensor* z) {
 template <int KIND>
 __global__ __launch_bounds__(256) void optim_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long long n,
-                                                    long long n_decay, OptimArgs a, const int* __restrict__ step) {
+                                                    long long n_decay, OptimArgs a, const int* __restrict__ step,
+                                                    long long set_stride) {
   __shared__ float s_step_size, s_bc2_sqrt;
+  {  // replica blockIdx.y of the arena (a group of volumes, each with its own parameters and optimizer state)
+    const long long o = (long long)blockIdx.y * set_stride;
+    p += o; g += o; m += o;
+    if (v != nullptr) v += o;
+  }
   const int t0 = *step;
   if (threadIdx.x == 0) optim_scalars(KIND, a, t0, s_step_size, s_bc2_sqrt);
   __syncthreads();
@@ -372,8 +394,8 @@ extern "C" int64_t mmtta_entropy_partials(const mmtta_tensor* logits) {
   return entropy_blocks(logits);
 }
 
-extern "C" int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits, double* partial,
-                                  float* loss, void* stream) {
+static int entropy_launch(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits, double* partial, float* loss,
+                          int per_item, void* stream) {
   MMTTA_CHECK(logits == nullptr || logits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_entropy_loss: `logits` must be fp32-stored");
   MMTTA_CHECK(dlogits == nullptr || dlogits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_entropy_loss: `dlogits` must be fp32-stored");
   MMTTA_CHECK(logits && dlogits && partial && loss && logits->ptr && dlogits->ptr, MMTTA_ERR_INVALID, "entropy: null argument");
@@ -381,8 +403,14 @@ extern "C" int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const
                   logits->w == dlogits->w, MMTTA_ERR_INVALID, "entropy: shape mismatch");
   MMTTA_CHECK(is_cl(logits) && is_cl(dlogits), MMTTA_ERR_UNSUPPORTED, "entropy: channels-last only");
   hipStream_t s = (hipStream_t)stream;
-  const int blocks = entropy_blocks(logits);
-  const long long nvox = (long long)logits->n * logits->d * logits->h * logits->w;
+  // per_item: every batch item is its own objective - the launch geometry, block partials and scale of ONE item, repeated
+  // along gridDim.y (bit-identical to N separate calls)
+  mmtta_tensor one = *logits;
+  if (per_item) one.n = 1;
+  const int items = per_item ? logits->n : 1;
+  const int blocks = entropy_blocks(&one);
+  const long long nvox = (long long)one.n * logits->d * logits->h * logits->w;
+  const dim3 grid(blocks, items);
   if (!softmax) {
     const double cnt = (double)nvox * logits->c;
     auto dense16 = [](const mmtta_tensor* t) {
@@ -390,25 +418,44 @@ extern "C" int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const
              ((uintptr_t)t->ptr) % 16 == 0;
     };
     if (logits->c <= 4 && dense16(logits) && dense16(dlogits) && (dlogits->flags & MMTTA_TENSOR_OWNS_PAD))
-      hipLaunchKernelGGL(entropy_bernoulli_vec_kernel, dim3(blocks), dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt));
+      hipLaunchKernelGGL(entropy_bernoulli_vec_kernel, grid, dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt), per_item);
     else
-      hipLaunchKernelGGL(entropy_bernoulli_kernel, dim3(blocks), dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt));
+      hipLaunchKernelGGL(entropy_bernoulli_kernel, grid, dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt), per_item);
     int st = launch_status("entropy bernoulli");
     if (st) return st;
-    hipLaunchKernelGGL(entropy_finish_kernel, dim3(1), dim3(64), 0, s, partial, blocks, 1.0 / cnt, loss);
+    hipLaunchKernelGGL(entropy_finish_kernel, dim3(items), dim3(64), 0, s, partial, blocks, 1.0 / cnt, loss);
   } else {
     MMTTA_CHECK(logits->c <= ENT_MAX_R, MMTTA_ERR_UNSUPPORTED, "entropy softmax: more than %d classes", ENT_MAX_R);
     const double cnt = (double)nvox;
-    hipLaunchKernelGGL(entropy_categorical_kernel, dim3(blocks), dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt));
+    hipLaunchKernelGGL(entropy_categorical_kernel, grid, dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt), per_item);
     int st = launch_status("entropy categorical");
     if (st) return st;
-    hipLaunchKernelGGL(entropy_finish_kernel, dim3(1), dim3(64), 0, s, partial, blocks, 1.0 / cnt, loss);
+    hipLaunchKernelGGL(entropy_finish_kernel, dim3(items), dim3(64), 0, s, partial, blocks, 1.0 / cnt, loss);
   }
   return launch_status("entropy finish");
 }
 
+extern "C" int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits, double* partial,
+                                  float* loss, void* stream) {
+  return entropy_launch(logits, softmax, dlogits, partial, loss, 0, stream);
+}
+
+extern "C" int64_t mmtta_entropy_partials_items(const mmtta_tensor* logits) {
+  if (logits == nullptr) return -1;
+  mmtta_tensor one = *logits;
+  one.n = 1;
+  return (int64_t)entropy_blocks(&one) * logits->n;
+}
+
+extern "C" int mmtta_entropy_loss_items(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits, double* partial,
+                                        float* loss, void* stream) {
+  return entropy_launch(logits, softmax, dlogits, partial, loss, 1, stream);
+}
+
 static int optim_launch(int kind, float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, const OptimArgs& a,
-                        int32_t* step, hipStream_t s) {
+                        int32_t* step, hipStream_t s, int sets = 1, int64_t set_stride = 0) {
+  MMTTA_CHECK(sets >= 1 && set_stride >= 0 && set_stride % 4 == 0 && (sets == 1 || set_stride >= n), MMTTA_ERR_INVALID,
+              "optimizer: %d sets with stride %lld (n = %lld)", sets, (long long)set_stride, (long long)n);
   MMTTA_CHECK(p && g && m && step && n >= 0 && n_decay >= 0 && n_decay <= n, MMTTA_ERR_INVALID, "optimizer: bad argument");
   MMTTA_CHECK(kind == MMTTA_OPTIM_SGD || v != nullptr, MMTTA_ERR_INVALID, "optimizer: Adam/AdamW need the second-moment buffer");
   MMTTA_CHECK(kind >= MMTTA_OPTIM_ADAM && kind <= MMTTA_OPTIM_SGD, MMTTA_ERR_INVALID, "optimizer: kind %d", kind);
@@ -417,13 +464,14 @@ static int optim_launch(int kind, float* p, const float* g, float* m, float* v, 
   MMTTA_CHECK(al, MMTTA_ERR_UNSUPPORTED, "optimizer: buffers must be 16-byte aligned and n_decay a multiple of 4");
   long long blocks = ((n + 3) / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  const dim3 grid((unsigned)blocks), blk(256);
+  const dim3 grid((unsigned)blocks, (unsigned)sets), blk(256);
+  const long long ss = (long long)set_stride;
   if (kind == MMTTA_OPTIM_ADAM)
-    hipLaunchKernelGGL(optim_kernel<0>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step);
+    hipLaunchKernelGGL(optim_kernel<0>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step, ss);
   else if (kind == MMTTA_OPTIM_ADAMW)
-    hipLaunchKernelGGL(optim_kernel<1>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step);
+    hipLaunchKernelGGL(optim_kernel<1>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step, ss);
   else
-    hipLaunchKernelGGL(optim_kernel<2>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step);
+    hipLaunchKernelGGL(optim_kernel<2>, grid, blk, 0, s, p, g, m, v, (long long)n, (long long)n_decay, a, step, ss);
   int st = launch_status("optimizer");
   if (st) return st;
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
@@ -444,6 +492,16 @@ extern "C" int mmtta_optim_step(const mmtta_optim_desc* d, float* p, const float
     MMTTA_CHECK(!(d->nesterov && (d->momentum <= 0.f || d->dampening != 0.f)), MMTTA_ERR_INVALID,
                 "optimizer: nesterov needs momentum > 0 and zero dampening (torch.optim.SGD raises the same)");
   return optim_launch(d->kind, p, g, m, v, n, n_decay, a, step, (hipStream_t)stream);
+}
+
+extern "C" int mmtta_optim_step_sets(const mmtta_optim_desc* d, float* p, const float* g, float* m, float* v, int64_t n,
+                                     int64_t n_decay, int sets, int64_t set_stride, int32_t* step, void* stream) {
+  MMTTA_CHECK(d != nullptr, MMTTA_ERR_INVALID, "optimizer: null desc");
+  OptimArgs a{d->lr, d->beta1, d->beta2, d->eps, d->weight_decay, d->momentum, d->dampening, d->nesterov};
+  if (d->kind == MMTTA_OPTIM_SGD)
+    MMTTA_CHECK(!(d->nesterov && (d->momentum <= 0.f || d->dampening != 0.f)), MMTTA_ERR_INVALID,
+                "optimizer: nesterov needs momentum > 0 and zero dampening (torch.optim.SGD raises the same)");
+  return optim_launch(d->kind, p, g, m, v, n, n_decay, a, step, (hipStream_t)stream, sets, set_stride);
 }
 
 extern "C" int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label, float threshold, int64_t* counts,

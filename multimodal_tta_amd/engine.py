@@ -49,10 +49,15 @@ class ParamRef:
 
 
 class Arena:
-    """Flat fp32 storage [decay | no-decay | frozen] for parameters, gradients and Adam moments."""
+    """Flat fp32 storage [decay | no-decay | frozen] for parameters, gradients and Adam moments.
 
-    def __init__(self, refs: Sequence[ParamRef], device: torch.device):
+    ``replicas`` > 1 (a group of volumes adapting side by side, ``method.group``): the four buffers are ``[replicas, total]``;
+    replica 0 is the one the nn.Parameters view (the source weights), replica g holds volume g's adapted copy.  ``params`` /
+    ``grads`` / ``exp_avg`` / ``exp_avg_sq`` stay the flat views of replica 0; the ``*_all`` tensors are the whole thing."""
+
+    def __init__(self, refs: Sequence[ParamRef], device: torch.device, replicas: int = 1):
         self.device = device
+        self.replicas = max(1, int(replicas))
         order = sorted(range(len(refs)), key=lambda i: (refs[i].group, i))
         off = 0
         self.n_decay = self.n_train = 0
@@ -67,10 +72,13 @@ class Arena:
         self.n_decay = min(self.n_decay, self.n_train) if self.n_train else 0
         self.total = off
         self.refs = list(refs)
-        self.params = torch.zeros(max(off, 4), dtype=torch.float32, device=device)
-        self.grads = torch.zeros_like(self.params)
-        self.exp_avg = torch.zeros_like(self.params)
-        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.total = max(off, 4)
+        self.params_all = torch.zeros((self.replicas, self.total), dtype=torch.float32, device=device)
+        self.grads_all = torch.zeros_like(self.params_all)
+        self.exp_avg_all = torch.zeros_like(self.params_all)
+        self.exp_avg_sq_all = torch.zeros_like(self.params_all)
+        self.params, self.grads = self.params_all[0], self.grads_all[0]
+        self.exp_avg, self.exp_avg_sq = self.exp_avg_all[0], self.exp_avg_sq_all[0]
         self.step = torch.zeros(1, dtype=torch.int32, device=device)
         for r in self.refs:
             view = self.params[r.offset:r.offset + r.numel].view(r.shape)
@@ -91,16 +99,20 @@ class Arena:
         self.source = self.params.clone()
 
     def restore_source(self) -> None:
-        """Episodic reset: source weights back, optimizer state cleared."""
+        """Episodic reset: source weights back in every replica, optimizer state cleared."""
         if self.source is None:
             raise MmttaError("no source snapshot taken")
-        self.params.copy_(self.source)
-        self.exp_avg.zero_()
-        self.exp_avg_sq.zero_()
+        self.params_all.copy_(self.source.unsqueeze(0).expand_as(self.params_all))
+        self.exp_avg_all.zero_()
+        self.exp_avg_sq_all.zero_()
         self.step.zero_()
 
     def zero_grad(self) -> None:
-        self.grads.zero_()
+        self.grads_all.zero_()
+
+    def replica_data(self, ref: ParamRef, g: int) -> torch.Tensor:
+        """Parameter ``ref`` of replica ``g`` (a view)."""
+        return self.params_all[g, ref.offset:ref.offset + ref.numel].view(ref.shape)
 
     def publish_grads(self) -> None:
         """Expose gradients as ``param.grad`` for external torch optimizers (drop-in run_step path)."""
@@ -192,12 +204,35 @@ class NormLayer:
 
 
 class ConvLayer:
-    def __init__(self, op: ConvOp, weight: ParamRef, bias: Optional[ParamRef], rt: Optional["Runtime"] = None):
+    """One convolution module - or a FAMILY of identical modules with different weights (``members``: the M modality
+    encoders of the deep-fusion network) that run as the batch items of one launch."""
+
+    def __init__(self, op: ConvOp, weight: ParamRef, bias: Optional[ParamRef], rt: Optional["Runtime"] = None,
+                 members: Optional[List[Tuple[ParamRef, Optional[ParamRef]]]] = None, items_per_set: int = 1):
         self.op, self.weight, self.bias, self.rt = op, weight, bias, rt
+        self.members = members if members is not None else [(weight, bias)]      # member 0 = (weight, bias)
+        self.items_per_set = int(items_per_set)      # consecutive batch items sharing a set (the fusion layer: M)
         self.side_index = 0          # which side stream takes this layer's weight gradient (Runtime.make_conv)
 
     def pack(self) -> None:
-        self.op.pack(self.weight.data)
+        for m, (w, _) in enumerate(self.members):
+            self.op.pack(w.data, m)
+
+    def bind_sets(self, arena: "Arena") -> None:
+        """Tell the op which batch item uses which parameter set: replica stride = the arena's, member stride = the
+        distance between the members' parameters (must be uniform: the members are registered in one order)."""
+        inner = len(self.members)
+        if self.op.n_sets != arena.replicas * inner:
+            return                     # an op without per-item sets (built before the group size was known)
+        wi = bi = 0
+        if inner > 1:
+            wd = {self.members[m + 1][0].offset - self.members[m][0].offset for m in range(inner - 1)}
+            bd = ({self.members[m + 1][1].offset - self.members[m][1].offset for m in range(inner - 1)}
+                  if self.bias is not None else {0})
+            if len(wd) != 1 or len(bd) != 1:
+                raise MmttaError("the members of a layer family must sit at a uniform stride in the arena")
+            wi, bi = wd.pop(), bd.pop()
+        self.op.set_param_sets(self.items_per_set, inner, arena.total, wi, arena.total, bi, self.rt)
 
     def bias_data(self):
         return self.bias.data if self.bias is not None else None
@@ -332,9 +367,14 @@ class ResidualUnitBlock(Block):
 class Runtime:
     """Owns the arena, the buffer pool and the conv layers of one model instance on one device."""
 
-    def __init__(self, device: torch.device, conv_dtype: int = ops.F32):
+    def __init__(self, device: torch.device, conv_dtype: int = ops.F32, group: int = 1):
         self.device = device
         self.conv_dtype = conv_dtype   # ops.F32: exact fp32 MFMA; ops.BF16: bf16 operands / fp32 accumulate
+        # `group` volumes adapt side by side as the batch items of every launch, each with its own parameter replica
+        # (method.group; Arena.replicas, mmtta_param_sets).  `use_sets` is switched on by the adaptation plugin around its
+        # launches; the nn.Module facade (plain batched forward, one weight set) leaves it off
+        self.group = max(1, int(group))
+        self.use_sets = False
         self.pool = Pool(device)
         # forward activations of more than 4 channels stored as bf16 (torch-autocast style): set by runtimes whose every
         # layer kind has storage-agnostic kernels (models/unet.py); gradients, logits, statistics, weights stay fp32
@@ -364,7 +404,7 @@ class Runtime:
         k = module.kernel_size[0]
         s = module.stride[0]
         cin, cout = module.in_channels, module.out_channels
-        op = ConvOp(cin, cout, k, s, transposed, self.device, dtype=self.conv_dtype)
+        op = ConvOp(cin, cout, k, s, transposed, self.device, dtype=self.conv_dtype, n_sets=self.group)
         w = self.make_ref(name + ".weight", module.weight)
         b = self.make_ref(name + ".bias", module.bias) if module.bias is not None else None
         layer = ConvLayer(op, w, b, self)
@@ -398,7 +438,17 @@ class Runtime:
                 r.group = GROUP_DECAY
 
     def build_arena(self) -> Arena:
-        self.arena = Arena(self.refs, self.device)
+        if self.group > 1:
+            # a volume group needs every parameter to be per-item: convolution weights and biases are (mmtta_param_sets);
+            # norm affines and BatchNorm's cross-item statistics are not
+            bad = [r.name for r in self.refs if ".adn.N." in r.name]
+            if bad or self.buffers:
+                raise NotImplementedError(
+                    f"method.group = {self.group} needs per-volume norms without parameters (INSTANCE, the shipped configs); "
+                    f"this model has {bad[:2] or 'BatchNorm running statistics'}: use method.lanes with method.group = 1")
+        self.arena = Arena(self.refs, self.device, replicas=self.group)
+        for c in self.convs:
+            c.bind_sets(self.arena)
         for mod in self.buffers:                    # BatchNorm running statistics follow the parameters
             for name, buf in list(mod.named_buffers(recurse=False)):
                 if buf is not None and buf.device != self.device:
@@ -414,9 +464,13 @@ class Runtime:
                 if id(c.op) in seen:
                     continue
                 seen.add(id(c.op))
-                items.append((c.op.d_fwd, c.weight.data, c.op.packed_fwd))
-                if c.op.need_dgrad:
-                    items.append((c.op.d_dgrad, c.weight.data, c.op.packed_dgrad))
+                inner = len(c.members)
+                for g in range(self.arena.replicas if c.op.n_sets == self.arena.replicas * inner else 1):
+                    for m, (w, _) in enumerate(c.members):
+                        wd = self.arena.replica_data(w, g)
+                        items.append((c.op.d_fwd, wd, c.op.packed_image(False, g * inner + m)))
+                        if c.op.need_dgrad:
+                            items.append((c.op.d_dgrad, wd, c.op.packed_image(True, g * inner + m)))
             self._packer = ops.BatchedPacker(items, self.device)
             self._packer_base = self.arena.params.data_ptr()
         self._packer.run()

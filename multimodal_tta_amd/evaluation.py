@@ -317,10 +317,13 @@ class SegmentationEvaluationStrategy:
             losses = (self.loss_fn.values_per_volume(self.loss_fn.launch(logits.float(), y)) if self.report_loss
                       else [0.0] * x.size(0))
             idx = batch.get("index", None)
+            if idx is None:
+                raise KeyError("[seg_eval] a sharded evaluation needs batch['index'] (the volume's position in the whole split): "
+                               "rank-local counters collide across ranks")
             for i in range(x.size(0)):
                 if domains[i] not in domain_names:
                     domain_names.append(domains[i])
-                parts = [torch.tensor([int(idx[i]) if idx is not None else n_local, domain_names.index(domains[i]),
+                parts = [torch.tensor([int(idx[i]), domain_names.index(domains[i]),
                                        losses[i]], dtype=torch.float64),
                          dice[i].double(), iou[i].double(), valid[i].double()]
                 if self.enable_surface:
@@ -362,8 +365,51 @@ def gather_table(rows: torch.Tensor, n_items: int, world: int, group=None) -> to
         allrows = torch.cat(bufs, dim=0)
     allrows = allrows.cpu()
     allrows = allrows[allrows[:, 0] >= 0]
-    order = torch.argsort(allrows[:, 0])
-    return allrows[order]
+    order = torch.argsort(allrows[:, 0], stable=True)
+    allrows = allrows[order]
+    if allrows.shape[0] > 1:          # a sampler that pads the last shard repeats volumes: keep the first row per index
+        keep = torch.ones(allrows.shape[0], dtype=torch.bool)
+        keep[1:] = allrows[1:, 0] != allrows[:-1, 0]
+        allrows = allrows[keep]
+    return allrows
+
+
+def gather_masks(local: Sequence[Tuple[int, torch.Tensor]], device, group=None) -> Dict[int, torch.Tensor]:
+    """The optional second collective of a sharded evaluation (north star: "all-gather final
+    Dice/logits"): every rank's thresholded masks uint8 [R,D,H,W], keyed by volume index, gathered to every rank.
+    One ``all_reduce(MAX)`` agrees on the pad shape (ranks may hold unequal shares and ragged extents), one ``all_gather``
+    moves the index / extent rows, one the padded masks (6 MB per 128^3 BraTS volume).  Single process: the local dict."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return {int(i): m for i, m in local}
+    world = dist.get_world_size()
+    dev = device if dist.get_backend() == "nccl" else "cpu"
+    ext = torch.zeros(5, dtype=torch.int64)                   # rows, R, D, H, W: the maxima over ranks
+    ext[0] = len(local)
+    for _, m in local:
+        ext[1:] = torch.maximum(ext[1:], torch.tensor(list(m.shape), dtype=torch.int64))
+    ext = ext.to(dev)
+    dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=group)
+    per, R, D, H, W = (int(v) for v in ext.tolist())
+    meta = torch.full((max(per, 1), 5), -1, dtype=torch.int64)
+    buf = torch.zeros((max(per, 1), R, D, H, W), dtype=torch.uint8)
+    for k, (i, m) in enumerate(local):
+        meta[k] = torch.tensor([int(i), *m.shape], dtype=torch.int64)
+        buf[k, :m.shape[0], :m.shape[1], :m.shape[2], :m.shape[3]] = m
+    meta, buf = meta.to(dev), buf.to(dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    dist.all_gather(bufs, buf, group=group)
+    out: Dict[int, torch.Tensor] = {}
+    for mt, bf in zip(metas, bufs):
+        mt, bf = mt.cpu(), bf.cpu()
+        for k in range(mt.shape[0]):
+            i, r, d, h, w = (int(v) for v in mt[k].tolist())
+            if i >= 0 and i not in out:
+                out[i] = bf[k, :r, :d, :h, :w].clone()
+    return out
 
 
 def metrics_from_table(table: torch.Tensor, region_order: Sequence[str], domain_names: Sequence[str],
@@ -426,6 +472,14 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
         # adaptation has no cross-volume state, and one volume alone leaves most CUs waiting at the lower U-Net levels
         # (measured, unet 4x128^3, S = 10: 29.6 / 39.7 / 35.7 volumes/s for 1 / 2 / 3 lanes)
         self.lanes = max(1, int(get_config(self.config, "method.lanes", 1)))
+        # volumes that adapt TOGETHER as the batch items of one launch sequence, each on its own replica of the weights
+        # (the plugin's `method.group`); lanes x group volumes are in flight per GPU
+        self.group = max(1, int(get_config(self.config, "method.group", 1)))
+        # north star: "RCCL ... used only to all-gather final Dice/logits": with `evaluation.gather_masks` the thresholded
+        # uint8 masks [R,D,H,W] of every volume are gathered to every rank as well (a second all_gather, off by default)
+        self.gather_masks = bool(get_config(self.config, "evaluation.gather_masks", False))
+        self.local_masks: List[Tuple[int, torch.Tensor]] = []
+        self.last_masks: Dict[int, torch.Tensor] = {}
         self.plugin = None
         self.plugins: List[Any] = []
         self.streams: List[Any] = []
@@ -446,36 +500,47 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
                 self.plugins.append(p.setup(twin, device))
                 self.streams.append(pool[lane])
 
-    def _submit(self, lane: int, x1: torch.Tensor, y1: torch.Tensor) -> Dict[str, Any]:
-        """Queue adaptation + scoring of one volume on the lane's stream; nothing here waits for the GPU."""
-        R = y1.shape[1]
-        res = self.plugins[lane].adapt_volume(x1)
-        counts = torch.empty((1, R, 3), dtype=torch.int64, device=y1.device)
-        mask = torch.empty(tuple(y1.shape), dtype=torch.uint8, device=y1.device) if self.enable_surface else None
-        ops.mask_dice_counts(res["logits_cl"], y1, self.threshold, counts, mask, logits_channels_last=True)
-        job: Dict[str, Any] = {"counts": counts, "shape": tuple(y1.shape[2:]), "keep": (x1, y1, mask, res)}
+    def _submit(self, lane: int, xb: torch.Tensor, yb: torch.Tensor) -> Dict[str, Any]:
+        """Queue adaptation + scoring of one volume - or of one GROUP of volumes (``method.group``, batch items that adapt
+        independently) - on the lane's stream; nothing here waits for the GPU."""
+        B, R = yb.shape[0], yb.shape[1]
+        res = self.plugins[lane].adapt_volume(xb)
+        counts = torch.empty((B, R, 3), dtype=torch.int64, device=yb.device)
+        mask = torch.empty(tuple(yb.shape), dtype=torch.uint8, device=yb.device) if (self.enable_surface or self.gather_masks) else None
+        ops.mask_dice_counts(res["logits_cl"], yb, self.threshold, counts, mask, logits_channels_last=True)
+        job: Dict[str, Any] = {"counts": counts, "shape": tuple(yb.shape[2:]), "keep": (xb, yb, mask, res), "mask": mask}
         if self.report_loss:
-            job["loss"] = self.loss_fn.launch(res["logits_cl"], y1, channels_last=True)
+            job["loss"] = self.loss_fn.launch(res["logits_cl"], yb, channels_last=True)
         if self.enable_surface:
-            job["surface"] = self.surface_launch(mask, y1)
+            job["surface"] = self.surface_launch(mask, yb)
         return job
 
-    def _finish(self, job: Dict[str, Any]) -> torch.Tensor:
-        """First host read of a queued volume -> its table row."""
+    def _finish(self, job: Dict[str, Any]) -> List[torch.Tensor]:
+        """First host read of a queued group -> the table rows of its volumes."""
         counts = job["counts"].cpu()
         dice, iou, valid = dice_iou_from_counts(counts)
-        loss = self.loss_fn.value(job["loss"]) if self.report_loss else 0.0
-        parts = [torch.tensor([job["index"], job["domain_id"], loss], dtype=torch.float64),
-                 dice[0].double(), iou[0].double(), valid[0].double()]
+        B = counts.shape[0]
+        losses = self.loss_fn.values_per_volume(job["loss"]) if self.report_loss else [0.0] * B
         if self.enable_surface:
             hd, asd = self.surface_fix(job["surface"][0], job["surface"][1], counts, job["shape"])
-            parts += [hd[0].double(), asd[0].double()]
-        return torch.cat(parts)
+        rows = []
+        for b in range(B):
+            parts = [torch.tensor([job["index"][b], job["domain_id"][b], losses[b]], dtype=torch.float64),
+                     dice[b].double(), iou[b].double(), valid[b].double()]
+            if self.enable_surface:
+                parts += [hd[b].double(), asd[b].double()]
+            rows.append(torch.cat(parts))
+        if self.gather_masks:
+            mk = job["mask"].cpu()
+            for b in range(B):
+                self.local_masks.append((int(job["index"][b]), mk[b]))
+        return rows
 
     @torch.no_grad()
     def evaluate_epoch(self, model: torch.nn.Module, data_loader: Iterable, device) -> Dict[str, float]:
-        """``data_loader`` yields this rank's shard (any batch size).  Volumes adapt one at a time per lane;
-        ``method.lanes`` of them are in flight, results are read back when a lane is needed again."""
+        """``data_loader`` yields this rank's shard (any batch size).  ``method.group`` volumes adapt together in one launch
+        sequence (each on its own replica of the weights), ``method.lanes`` such groups are in flight on their own streams;
+        results are read back when a lane is needed again."""
         import torch.distributed as dist
 
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -485,39 +550,60 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
         done: List[Tuple[int, torch.Tensor]] = []          # (submission order, row)
         pending: List[Optional[Dict[str, Any]]] = [None] * self.lanes
         domain_names: List[str] = []
+        self.local_masks = []
         n_local = 0
+        n_groups = 0
+        group: List[Tuple[torch.Tensor, torch.Tensor, int, int, int]] = []      # (x1, y1, order, index, domain id)
+        keep_alive: List[torch.Tensor] = []
 
         def flush(lane: int) -> None:
             job = pending[lane]
             if job is not None:
                 if self.streams[lane] is not None:
                     self.streams[lane].synchronize()         # host reads below are issued from the main stream
-                done.append((job["order"], self._finish(job)))
+                for order, row in zip(job["order"], self._finish(job)):
+                    done.append((order, row))
                 pending[lane] = None
+
+        def dispatch() -> None:
+            nonlocal n_groups
+            lane = n_groups % self.lanes
+            flush(lane)                                      # the lane's buffers are about to be reused
+            xb = torch.cat([g[0] for g in group]) if len(group) > 1 else group[0][0]
+            yb = torch.cat([g[1] for g in group]) if len(group) > 1 else group[0][1]
+            stream = self.streams[lane]
+            if stream is None:
+                job = self._submit(lane, xb, yb)
+            else:
+                stream.wait_stream(torch.cuda.current_stream(device))      # inputs were prepared on the main stream
+                with torch.cuda.stream(stream):
+                    job = self._submit(lane, xb, yb)
+                for t in (xb, yb, *keep_alive):
+                    t.record_stream(stream)
+            job.update(order=[g[2] for g in group], index=[g[3] for g in group], domain_id=[g[4] for g in group])
+            pending[lane] = job
+            n_groups += 1
+            group.clear()
+            keep_alive.clear()
 
         for batch in data_loader:
             x, y = self.check_batch(batch, device)
             domains = as_list_str(batch.get("domain", None), batch_size=x.size(0))
             idx = batch.get("index", None)
+            if idx is None and world > 1:
+                raise KeyError("[seg_tta_eval] a sharded evaluation needs batch['index'] (the volume's position in the whole "
+                               "split): rank-local counters collide across ranks")
+            keep_alive += [x, y]
             for i in range(x.size(0)):
-                lane = n_local % self.lanes
-                flush(lane)                                  # the lane's buffers are about to be reused
                 if domains[i] not in domain_names:
                     domain_names.append(domains[i])
-                x1, y1 = x[i:i + 1], y[i:i + 1]
-                stream = self.streams[lane]
-                if stream is None:
-                    job = self._submit(lane, x1, y1)
-                else:
-                    stream.wait_stream(torch.cuda.current_stream(device))      # inputs were prepared on the main stream
-                    with torch.cuda.stream(stream):
-                        job = self._submit(lane, x1, y1)
-                    x.record_stream(stream)
-                    y.record_stream(stream)
-                job.update(order=n_local, index=int(idx[i]) if idx is not None else n_local,
-                           domain_id=domain_names.index(domains[i]))
-                pending[lane] = job
+                group.append((x[i:i + 1], y[i:i + 1], n_local, int(idx[i]) if idx is not None else n_local,
+                              domain_names.index(domains[i])))
                 n_local += 1
+                if len(group) == self.group:
+                    dispatch()
+        if group:
+            dispatch()
         for lane in range(self.lanes):
             flush(lane)
         rows = [row for _, row in sorted(done, key=lambda t: t[0])]
@@ -525,4 +611,6 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
         if world > 1:
             table, domain_names = merge_rank_tables(table, domain_names, device)
         self.last_table = table
+        if self.gather_masks:
+            self.last_masks = gather_masks(self.local_masks, device)
         return metrics_from_table(table, self.region_order, domain_names, self.report_loss, self.enable_surface)

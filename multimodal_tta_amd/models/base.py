@@ -54,6 +54,15 @@ class HipSegModel(nn.Module):
         self._no_decay_keys: Sequence[str] = DEFAULT_NO_DECAY_KEYS
         self._treat_1d = True
         self.conv_dtype = ops.F32
+        self.group = 1
+
+    def set_group(self, group: int) -> None:
+        """``group`` volumes adapt side by side through one launch sequence, each with its own parameter replica
+        (``method.group``; takes effect at the next runtime build)."""
+        group = max(1, int(group))
+        if group != self.group:
+            self.group = group
+            self._rt = None
 
     # ---- engine binding
     def set_precision(self, precision: str, storage: Optional[str] = None) -> None:

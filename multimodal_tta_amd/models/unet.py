@@ -26,7 +26,7 @@ class UNetRuntime(Runtime):
     """Flat execution plan of the recursive ``down / skip(sub) / up`` structure."""
 
     def __init__(self, model: "UNet", device: torch.device):
-        super().__init__(device, model.conv_dtype)
+        super().__init__(device, model.conv_dtype, group=getattr(model, "group", 1))
         self.channels, self.strides = list(model.channels), list(model.strides)
         self.nru = model.num_res_units
         self.in_channels, self.out_channels = model.in_channels, model.out_channels

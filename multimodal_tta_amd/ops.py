@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import (BF16, CONV_DGRAD, CONV_FWD, CONVT_DGRAD, CONVT_FWD, F32, NORM_BATCH, NORM_GROUP, NORM_INSTANCE,
-                   ConvDesc, ConvEpilogue, ConvPlan, MmttaError, check, desc_cl, desc_ncdhw, ptr, stream_ptr)
+                   ConvDesc, ConvEpilogue, ConvPlan, MmttaError, ParamSets, check, desc_cl, desc_ncdhw, ptr, stream_ptr)
 
 NORM_KINDS = {"INSTANCE": NORM_INSTANCE, "BATCH": NORM_BATCH, "GROUP": NORM_GROUP}
 PRECISIONS = {"fp32": F32, "f32": F32, "bf16": BF16}
@@ -246,7 +246,11 @@ class ConvOp:
     ``pack`` after every optimizer step.
     """
 
-    def __init__(self, cin: int, cout: int, ksize: int, stride: int, transposed: bool, device, dtype: int = F32):
+    def __init__(self, cin: int, cout: int, ksize: int, stride: int, transposed: bool, device, dtype: int = F32,
+                 n_sets: int = 1):
+        """``n_sets`` > 1: the op holds that many packed weight images back to back - one per parameter set of a group of
+        volumes (x the members of a set family, e.g. the M modality encoders); which batch item reads which image is said by
+        ``set_param_sets`` (mmtta_param_sets)."""
         _require_cuda()
         self.cin, self.cout, self.k, self.stride, self.transposed = cin, cout, ksize, stride, transposed
         self.device = torch.device(device)
@@ -258,23 +262,52 @@ class ConvOp:
         nb_d = lib.mmtta_conv_packed_bytes(C.byref(self.d_dgrad))
         if nb_f < 0 or nb_d < 0:
             check(-2, "conv_packed_bytes")
-        self.packed_fwd = torch.empty(nb_f, dtype=torch.uint8, device=self.device)
-        self.packed_dgrad = torch.empty(nb_d, dtype=torch.uint8, device=self.device)
+        self.n_sets = max(1, int(n_sets))
+        self.nb_fwd, self.nb_dgrad = int(nb_f), int(nb_d)        # bytes of ONE image (multiples of 16)
+        self.packed_fwd = torch.empty(nb_f * self.n_sets, dtype=torch.uint8, device=self.device)
+        self.packed_dgrad = torch.empty(nb_d * self.n_sets, dtype=torch.uint8, device=self.device)
         self._plans: Dict[Tuple, ConvPlan] = {}
         self.need_dgrad = True
+        # per-item parameter sets (None: one set for the whole batch).  `sets_ctl.use_sets` (the owning runtime) switches
+        # them on for the launches of a volume group and off for the plain batched forward of the nn.Module facade
+        self.sets_fwd: Optional[ParamSets] = None
+        self.sets_dgrad: Optional[ParamSets] = None
+        self.sets_ctl = None
+
+    def set_param_sets(self, items_per_set: int, inner: int, weight_outer: int, weight_inner: int, bias_outer: int,
+                       bias_inner: int, ctl) -> None:
+        """Batch item n uses set q = n // items_per_set, stored (q // inner) outer + (q % inner) inner strides behind set 0;
+        the packed images of the op are laid out [outer][inner]."""
+        if self.n_sets % inner:
+            raise MmttaError(f"{self.n_sets} packed images cannot hold families of {inner} sets")
+        mk = lambda nb: ParamSets(int(items_per_set), int(inner), nb * int(inner), nb, int(weight_outer), int(weight_inner),
+                                  int(bias_outer), int(bias_inner))
+        self.sets_fwd, self.sets_dgrad, self.sets_ctl = mk(self.nb_fwd), mk(self.nb_dgrad), ctl
+
+    def _sets(self, desc) -> Optional[ParamSets]:
+        if self.sets_ctl is None or not getattr(self.sets_ctl, "use_sets", False):
+            return None
+        return self.sets_dgrad if int(desc.op) in (CONV_DGRAD, CONVT_DGRAD) else self.sets_fwd
+
+    def packed_image(self, dgrad: bool, index: int) -> torch.Tensor:
+        """The packed image of parameter set ``index`` (a view)."""
+        nb, buf = (self.nb_dgrad, self.packed_dgrad) if dgrad else (self.nb_fwd, self.packed_fwd)
+        return buf[index * nb:(index + 1) * nb]
 
     def weight_shape(self) -> Tuple[int, ...]:
         k = self.k
         return (self.cin, self.cout, k, k, k) if self.transposed else (self.cout, self.cin, k, k, k)
 
-    def pack(self, weight: torch.Tensor) -> None:
+    def pack(self, weight: torch.Tensor, index: int = 0) -> None:
+        """Refresh the packed images of parameter set ``index`` from its master weight."""
         if tuple(weight.shape) != self.weight_shape() or weight.dtype != torch.float32 or not weight.is_contiguous():
             raise MmttaError(f"weight must be contiguous fp32 {self.weight_shape()}, got {tuple(weight.shape)}")
         lib = _lib.load()
         s = stream_ptr()
-        check(lib.mmtta_conv_pack_weights(C.byref(self.d_fwd), ptr(weight), ptr(self.packed_fwd), s), "pack fwd")
+        check(lib.mmtta_conv_pack_weights(C.byref(self.d_fwd), ptr(weight), ptr(self.packed_image(False, index)), s), "pack fwd")
         if self.need_dgrad:
-            check(lib.mmtta_conv_pack_weights(C.byref(self.d_dgrad), ptr(weight), ptr(self.packed_dgrad), s), "pack dgrad")
+            check(lib.mmtta_conv_pack_weights(C.byref(self.d_dgrad), ptr(weight), ptr(self.packed_image(True, index)), s),
+                  "pack dgrad")
 
     def out_shape(self, x: torch.Tensor) -> Tuple[int, int, int, int, int]:
         n, d, h, w, _ = x.shape
@@ -285,7 +318,10 @@ class ConvOp:
         return (n, (d + 1) // 2, (h + 1) // 2, (w + 1) // 2, self.cout)
 
     def plan(self, desc: ConvDesc, x: torch.Tensor, y: torch.Tensor) -> ConvPlan:
-        key = (desc.op, tuple(x.shape), tuple(y.shape), _OPTION_EPOCH)
+        # the planned geometry (tile form, statistics rows) also depends on storage type, strides and pointer alignment
+        # (class-fused / lean / row-loader gates): all of it is part of the key
+        key = (desc.op, tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, x.stride(), y.stride(), x.data_ptr() % 16,
+               y.data_ptr() % 16, _OPTION_EPOCH)
         p = self._plans.get(key)
         if p is None:
             p = ConvPlan()
@@ -307,11 +343,13 @@ class ConvOp:
         if add is not None:
             keep = desc_cl(add)
             epi = ConvEpilogue(C.pointer(keep), add_nl.struct() if add_nl is not None else _lib.norm_on_load())
+        sets = self._sets(desc)
         def launch():
             check(
-                _lib.load().mmtta_conv_run(
+                _lib.load().mmtta_conv_run_sets(
                     C.byref(desc), C.byref(dx), nlr, ptr(packed), ptr(bias), C.byref(epi) if epi is not None else None,
-                    C.byref(dy), 1 if accumulate else 0, ptr(stats), ptr(ws), int(p.workspace_bytes), stream_ptr()),
+                    C.byref(dy), 1 if accumulate else 0, ptr(stats), ptr(ws), int(p.workspace_bytes),
+                    C.byref(sets) if sets is not None else None, stream_ptr()),
                 "conv_run")
 
         launch()
@@ -372,14 +410,16 @@ class ConvOp:
               db: Optional[torch.Tensor], accumulate: bool = False) -> None:
         lib = _lib.load()
         tx, tdy = desc_cl(x), desc_cl(dy)
-        need = lib.mmtta_conv_wgrad_workspace_bytes(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy))
+        sets = self._sets(self.d_fwd)
+        sref = C.byref(sets) if sets is not None else None
+        need = lib.mmtta_conv_wgrad_workspace_bytes_sets(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy), sref)
         if need < 0:
             check(-1, "conv_wgrad_workspace_bytes")
         ws = Workspace.get(int(need), x.device)
         nls, nlr = _nl_ref(x_nl)
         def launch():
-            check(lib.mmtta_conv_wgrad(C.byref(self.d_fwd), C.byref(tx), nlr, C.byref(tdy), ptr(dw), ptr(db),
-                                       1 if accumulate else 0, ptr(ws), int(need), stream_ptr()), "conv_wgrad")
+            check(lib.mmtta_conv_wgrad_sets(C.byref(self.d_fwd), C.byref(tx), nlr, C.byref(tdy), ptr(dw), ptr(db),
+                                            1 if accumulate else 0, ptr(ws), int(need), sref, stream_ptr()), "conv_wgrad")
 
         launch()
         if PROFILER is not None:
@@ -387,8 +427,9 @@ class ConvOp:
             for _ in range(PROFILER.reps):
                 launch()
             kid = lib.mmtta_conv_wgrad_kernel(C.byref(self.d_fwd), C.byref(tx), C.byref(tdy))
-            PROFILER.end(WGRAD_KERNELS[kid], PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0,
-                         self._detail(-1, x), self.io_bytes(x, dy, dw) * PROFILER.reps)
+            nsets = x.shape[0] // int(sets.items_per_set) if sets is not None else 1
+            PROFILER.end(WGRAD_KERNELS[kid], PROFILER.reps, self.flops(x, dy) * PROFILER.reps, e0, self._detail(-1, x),
+                         (self.io_bytes(x, dy, dw) + (nsets - 1) * dw.numel() * 4.0) * PROFILER.reps)
 
 
 
@@ -526,6 +567,21 @@ def entropy_loss(logits: torch.Tensor, dlogits: torch.Tensor, partial: torch.Ten
                                          stream_ptr()), "entropy_loss")
 
 
+def entropy_partials_items(logits: torch.Tensor) -> int:
+    t = desc_cl(logits)
+    return int(_lib.load().mmtta_entropy_partials_items(C.byref(t)))
+
+
+def entropy_loss_items(logits: torch.Tensor, dlogits: torch.Tensor, partial: torch.Tensor, loss: torch.Tensor,
+                       softmax: bool = False) -> None:
+    """The objective of every batch item on its own (N independent volumes in one launch): loss [N]."""
+    if loss.numel() < logits.shape[0]:
+        raise MmttaError("entropy_loss_items: one loss slot per batch item")
+    tz, tg = desc_cl(logits), desc_cl(dlogits)
+    check(_lib.load().mmtta_entropy_loss_items(C.byref(tz), 1 if softmax else 0, C.byref(tg), ptr(partial), ptr(loss),
+                                               stream_ptr()), "entropy_loss_items")
+
+
 def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, n_decay: int, lr: float,
               beta1: float, beta2: float, eps: float, weight_decay: float, step: torch.Tensor) -> None:
     n = p.numel()
@@ -573,6 +629,22 @@ def optim_step(spec: OptimSpec, p: torch.Tensor, g: torch.Tensor, m: torch.Tenso
     d = spec.struct()
     check(_lib.load().mmtta_optim_step(C.byref(d), ptr(p), ptr(g), ptr(m), ptr(v), n, int(n_decay), ptr(step),
                                        stream_ptr()), "optim_step")
+
+
+def optim_step_sets(spec: OptimSpec, p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: Optional[torch.Tensor], n: int,
+                    n_decay: int, sets: int, step: torch.Tensor) -> None:
+    """One optimizer step over the first ``sets`` replicas of the arena ([replica][total], the first ``n`` elements of a
+    replica train, its first ``n_decay`` decay) in one launch; one shared step counter."""
+    for t in (p, g, m) + ((v,) if v is not None else ()):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 2 or t.shape != p.shape:
+            raise MmttaError("optimizer: p, g, m, v must be contiguous fp32 [replicas, total] of equal shape")
+    if not (1 <= sets <= p.shape[0] and 0 <= n_decay <= n <= p.shape[1]):
+        raise MmttaError(f"optimizer: {sets} sets of {n} ({n_decay} decaying) elements do not fit {tuple(p.shape)}")
+    if step.dtype != torch.int32:
+        raise MmttaError("optimizer: step must be a device int32 scalar")
+    d = spec.struct()
+    check(_lib.load().mmtta_optim_step_sets(C.byref(d), ptr(p), ptr(g), ptr(m), ptr(v), int(n), int(n_decay), int(sets),
+                                            int(p.shape[1]), ptr(step), stream_ptr()), "optim_step_sets")
 
 
 def _desc_any(t: torch.Tensor, channels_last: bool):

@@ -82,6 +82,9 @@ class EntropyMinimizationTTA:
         self.moddrop_p = float(get_config(md, "p", 0.0)) if bool(get_config(md, "enabled", False)) else 0.0
         self.moddrop_seed = int(get_config(md, "seed", 0))
         self.use_graph = bool(get_config(m, "use_graph", True))
+        # volumes adapted side by side as the batch items of ONE launch sequence, each with its own replica of the weights
+        # and optimizer state (mmtta_param_sets): a volume alone fills a quarter of the chip or less at the lower levels
+        self.group = max(1, int(get_config(m, "group", 1)))
         self.side_streams = int(get_config(m, "side_streams", 0))   # 0: weight gradients stay on the main stream
         tr = get_config(cfg, "training", {}) or {}
         # the reference's factory (src/core/experiment_manager.py:199-237): `training.optimizer` names the class
@@ -130,6 +133,7 @@ class EntropyMinimizationTTA:
         self.model = model
         names = select_params(model, self.params_spec)
         model.set_precision(self.precision, self.storage)
+        model.set_group(self.group)
         model.configure_training(set(names), self.no_decay_keys, self.treat_1d)
         model.to(device)
         self.rt = model.runtime(device)
@@ -145,20 +149,34 @@ class EntropyMinimizationTTA:
         rt, ar = self.rt, self.rt.arena
         ops.Workspace.lane = self.lane
         rt.training = True
-        rt.pack_all()
-        logits = rt.forward_cl(x_cl) if present is None else rt.forward_cl(x_cl, present=present)
-        n, d, h, w, r = logits.shape
-        dlogits = rt.pool.cl("dlogits", n, d, h, w, r, ldc=(r + 3) // 4 * 4)
-        partial = rt.pool.flat("ent_partial", ops.entropy_partials(logits), dtype=torch.float64)
-        loss = rt.pool.flat("ent_loss", 1)
-        ops.entropy_loss(logits, dlogits, partial, loss, softmax=self.softmax)
-        if ar.n_train > 0:
-            rt.run_backward(dlogits)
-            self.optimizer_step()
+        rt.use_sets = rt.group > 1          # batch item g reads / writes parameter replica g
+        try:
+            rt.pack_all()
+            logits = rt.forward_cl(x_cl) if present is None else rt.forward_cl(x_cl, present=present)
+            n, d, h, w, r = logits.shape
+            dlogits = rt.pool.cl("dlogits", n, d, h, w, r, ldc=(r + 3) // 4 * 4)
+            if rt.group > 1:
+                # every volume of the group is its own objective (own mean, own gradient scale): loss [group]
+                partial = rt.pool.flat("ent_partial", ops.entropy_partials_items(logits), dtype=torch.float64)
+                loss = rt.pool.flat("ent_loss", rt.group)
+                ops.entropy_loss_items(logits, dlogits, partial, loss, softmax=self.softmax)
+            else:
+                partial = rt.pool.flat("ent_partial", ops.entropy_partials(logits), dtype=torch.float64)
+                loss = rt.pool.flat("ent_loss", 1)
+                ops.entropy_loss(logits, dlogits, partial, loss, softmax=self.softmax)
+            if ar.n_train > 0:
+                rt.run_backward(dlogits)
+                self.optimizer_step(n)
+        finally:
+            rt.use_sets = False
 
-    def optimizer_step(self) -> None:
-        """The arena optimizer: ONE launch over [decay | no-decay] (+ the device step counter)."""
+    def optimizer_step(self, volumes: int = 1) -> None:
+        """The arena optimizer: ONE launch over [decay | no-decay] of every replica in use (+ the device step counter)."""
         ar = self.rt.arena
+        if ar.replicas > 1:
+            ops.optim_step_sets(self.optim, ar.params_all, ar.grads_all, ar.exp_avg_all, ar.exp_avg_sq_all, ar.n_train, ar.n_decay,
+                                min(volumes, ar.replicas), ar.step)
+            return
         ops.optim_step(self.optim, ar.params[:ar.n_train], ar.grads[:ar.n_train], ar.exp_avg[:ar.n_train],
                        ar.exp_avg_sq[:ar.n_train], ar.n_decay, ar.step)
 
@@ -207,11 +225,16 @@ class EntropyMinimizationTTA:
     # ------------------------------------------------------------------ per volume
     @torch.no_grad()
     def adapt_volume(self, x: torch.Tensor, steps: Optional[int] = None) -> Dict[str, Any]:
-        """x: [1,C,D,H,W] fp32 on the plugin's device.  Returns final logits (NCDHW) and per-step losses."""
+        """x: [1,C,D,H,W] fp32 on the plugin's device - or, with ``method.group`` = G > 1, up to G volumes [B,C,D,H,W]
+        that adapt independently (volume b on parameter replica b).  Returns the final logits (channels-last view
+        [B,D,H,W,R]) and the per-step losses ([steps], or [steps, B] for a group)."""
         if self.rt is None:
             raise MmttaError("call setup(model, device) first")
         rt, ar = self.rt, self.rt.arena
         steps = self.steps if steps is None else int(steps)
+        B = int(x.shape[0])
+        if rt.group > 1 and B > rt.group:
+            raise ValueError(f"method.group = {rt.group}: at most {rt.group} volumes per call, got {B}")
         if self.episodic:
             ar.restore_source()
             rt.restore_buffers()
@@ -221,8 +244,11 @@ class EntropyMinimizationTTA:
         base_present = modality_mask(C, self.missing, 0.0, None)
         x = x.float()
         x_cl = rt.stage_input(drop_modality(x, base_present) if masked else x)
-        loss_hist = rt.pool.flat("loss_hist", max(steps, 1))
-        loss_buf = rt.pool.flat("ent_loss", 1)
+        grouped = rt.group > 1
+        loss_hist = rt.pool.flat("loss_hist", max(steps, 1) * (B if grouped else 1))
+        loss_buf = rt.pool.flat("ent_loss", rt.group if grouped else 1)
+        if grouped:
+            loss_hist = loss_hist.view(max(steps, 1), B)
         wants_present = masked and getattr(rt, "supports_present", False)
         for t in range(steps):
             present = None
@@ -232,14 +258,22 @@ class EntropyMinimizationTTA:
                     rt.stage_input(drop_modality(x, p))
                 present = p if wants_present else None
             self._step(x_cl, present)
-            loss_hist[t:t + 1].copy_(loss_buf)
+            if grouped:
+                loss_hist[t].copy_(loss_buf[:B])
+            else:
+                loss_hist[t:t + 1].copy_(loss_buf)
         if masked and self.moddrop_p > 0.0:
             rt.stage_input(drop_modality(x, base_present))
         rt.training = False
         ops.Workspace.lane = self.lane
-        rt.pack_all()
-        logits_cl = (rt.forward_cl(x_cl, present=base_present) if wants_present else rt.forward_cl(x_cl))
-        return {"logits_cl": logits_cl, "losses": loss_hist[:steps]}
+        rt.use_sets = grouped
+        try:
+            rt.pack_all()
+            logits_cl = (rt.forward_cl(x_cl, present=base_present) if wants_present else rt.forward_cl(x_cl))
+        finally:
+            rt.use_sets = False
+        losses = loss_hist[:steps]
+        return {"logits_cl": logits_cl, "losses": losses[:, 0] if (grouped and B == 1) else losses}
 
     def logits(self, result: Dict[str, Any]) -> torch.Tensor:
         return ops.from_cl(result["logits_cl"])

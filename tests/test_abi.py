@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mmtta.h but not exported by libmmtta.so"
-    assert lib.mmtta_abi_version() == 1
+    assert lib.mmtta_abi_version() == 2
 
 
 def test_binding_table_matches_header():
