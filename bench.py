@@ -92,6 +92,8 @@ def build_cfg(args):
         ov += [f"method.side_streams={args.side_streams}"]
     if getattr(args, "group", None) is not None:
         ov += [f"method.group={args.group}"]
+    if getattr(args, "lanes", None) is not None:
+        ov += [f"method.lanes={args.lanes}"]
     if getattr(args, "storage", None) or os.environ.get("MMTTA_STORAGE"):
         ov += [f"method.storage={getattr(args, 'storage', None) or os.environ['MMTTA_STORAGE']}"]
     cfg = compose(overrides=ov)
@@ -346,15 +348,20 @@ def main():
         # grouped, multi-lane headline run produced the SAME results for the same volumes), (b) in fp32 mode: the reference's
         # own arithmetic
         variants = {}
-        for name, prec, nl, ng in (("one_volume", args.precision, 1, 1), ("fp32", "fp32", lanes, group)):
+        # (the equality check runs one volume at a time under the HEADLINE's launch geometry - the geometry fixes the summation
+        # order, method.tune_volumes -; the latency figure under the geometry tuned for one volume in flight)
+        for name, prec, nl, ng, tune in (("one_volume_same_geometry", args.precision, 1, 1, lanes * group),
+                                         ("one_volume", args.precision, 1, 1, None), ("fp32", "fp32", lanes, group, None)):
             if (prec, nl, ng) == (args.precision, lanes, group):
                 continue
             a2 = argparse.Namespace(**vars(args))
-            a2.precision, a2.group = prec, ng
+            a2.precision, a2.group, a2.lanes = prec, ng, nl
             cfg2, _ = build_cfg(a2)
+            if tune is not None:
+                cfg2["method"]["tune_volumes"] = tune
             pl2, st2 = make_lanes(cfg2, nl, lane0=8 if name == "fp32" else 6, streams_=streams)      # the same queues
             c2 = torch.zeros_like(counts)
-            nv = min(args.steps, max(8, 2 * nl * ng))         # steady state: at least two rounds of every lane
+            nv = min(args.steps, 4 if tune is not None else max(8, 2 * nl * ng))   # steady state: two rounds of every lane
             run_volumes(pl2, st2, args.warmup, args.warmup + nv, c2, group_=ng)      # untimed: graphs of this schedule
             torch.cuda.synchronize()
             tv = time.perf_counter()
@@ -362,10 +369,11 @@ def main():
             torch.cuda.synchronize()
             tv = time.perf_counter() - tv
             variants[name] = {"value": nv / tv, "unit": "volumes/s", "precision": prec, "lanes": nl, "group": ng, "volumes": nv}
+            if name == "one_volume_same_geometry":
+                # Dice counts of the grouped / multi-lane headline run == the same volumes one at a time, exactly
+                out["lanes_equal"] = bool(torch.equal(c2[args.warmup:args.warmup + nv], counts[args.warmup:args.warmup + nv]))
             if name == "one_volume":
-                same = bool(torch.equal(c2[args.warmup:args.warmup + nv], counts[args.warmup:args.warmup + nv]))
                 variants[name]["latency_ms"] = 1000.0 * tv / nv
-                out["lanes_equal"] = same      # Dice counts of the grouped / multi-lane run == one volume at a time, exactly
             del pl2, st2
         out["variants"] = variants
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -15,7 +15,22 @@ import os as _os
 # 4) queues.  8 is the measured optimum for 3-4 lanes (42.0 -> 50.1 volumes/s; 16 is slower).  The variable is read when
 # HIP starts up, i.e. this only takes effect when the package is imported before the first CUDA call of the process
 # (bench.py and main.py set it first thing).
+def _hip_already_started() -> bool:
+    import sys as _sys
+    t = _sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+# what the HIP runtime of THIS process saw (or will see) when it started: the value in the environment before this import if
+# HIP was already running (then setting the variable now changes nothing), else the value set here
+HIP_STARTED_BEFORE_IMPORT = _hip_already_started()
+HW_QUEUES_AT_HIP_START = _os.environ.get("GPU_MAX_HW_QUEUES") if HIP_STARTED_BEFORE_IMPORT else None
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if not HIP_STARTED_BEFORE_IMPORT:
+    HW_QUEUES_AT_HIP_START = _os.environ["GPU_MAX_HW_QUEUES"]
 
 from . import registry  # noqa: F401,E402
 from .config import Cfg, compose, get_config, require_config  # noqa: F401,E402

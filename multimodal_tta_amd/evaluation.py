@@ -487,6 +487,7 @@ class TTASegmentationEvaluationStrategy(SegmentationEvaluationStrategy):
     def _setup_lanes(self, model: torch.nn.Module, device) -> None:
         from .registry import get_model
         self.plugin = get_plugin(self.plugin_name)(self.config).setup(model, device)
+        self.group = int(getattr(self.plugin, "group", 1))       # what the plugin settled on (1 for models whose norms carry parameters)
         self.plugins, self.streams = [self.plugin], [None]
         if self.lanes > 1:
             pool = ops.lane_streams(self.lanes, device)          # one hardware queue per lane

@@ -75,6 +75,29 @@ def helper_stream(device) -> "torch.cuda.Stream":
     return _HELPER_STREAMS[idx]
 
 
+_QUEUE_WARNED = False
+
+
+def hw_queue_status() -> dict:
+    """How many hardware queues the HIP runtime of this process multiplexes its streams over, as far as the package can
+    know: GPU_MAX_HW_QUEUES is read when HIP starts, so a host that initialised the GPU BEFORE importing this package runs
+    with whatever the environment held then (the runtime's default is 4)."""
+    import multimodal_tta_amd as pkg
+    raw = pkg.HW_QUEUES_AT_HIP_START
+    try:
+        queues = int(raw) if raw is not None else 4
+    except ValueError:
+        queues = 4
+    return {"queues": queues, "hip_started_before_import": bool(pkg.HIP_STARTED_BEFORE_IMPORT), "env_at_hip_start": raw}
+
+
+def lanes_effective(count: int) -> int:
+    """Lanes that can be expected to run on their own hardware queue: with the runtime's default of 4 queues the lanes beyond
+    the second have been measured sharing a queue with an earlier stream (profiles/r02_hw_queues.txt)."""
+    q = hw_queue_status()["queues"]
+    return int(count) if q >= 8 else min(int(count), 2)
+
+
 def lane_streams(count: int, device) -> list:
     """`count` streams for volumes adapted concurrently on one GPU, each bound to its OWN hardware queue.
 
@@ -83,6 +106,19 @@ def lane_streams(count: int, device) -> list:
     existing one, and two lanes on one queue serialise (measured, 4 lanes: 36 vs 53 volumes/s for the same code,
     depending only on which streams had been touched first).  So the lanes' streams are created AND given their first
     command here, before any other stream of the process does work."""
+    global _QUEUE_WARNED
+    st = hw_queue_status()
+    if int(count) > 2 and st["queues"] < 8 and not _QUEUE_WARNED:
+        _QUEUE_WARNED = True
+        import warnings
+        warnings.warn(
+            f"{count} lanes requested but the HIP runtime of this process started with GPU_MAX_HW_QUEUES="
+            f"{st['env_at_hip_start'] or 'unset (4 queues)'}"
+            + (" (the GPU was initialised before multimodal_tta_amd was imported, so the package could not set it)"
+               if st["hip_started_before_import"] else "")
+            + ": lanes beyond the second share a hardware queue and serialise - measured 42 instead of 50 volumes/s for four "
+              "lanes (profiles/r02_hw_queues.txt).  Export GPU_MAX_HW_QUEUES=8 before the first CUDA call, or use "
+              "method.group (volumes batched into one launch sequence) with method.lanes <= 2.", RuntimeWarning)
     device = torch.device(device)
     streams = [torch.cuda.Stream(device=device) for _ in range(int(count))]
     for s in streams:
@@ -105,6 +141,28 @@ def set_option(key: int, value: int) -> int:
     prev = int(_lib.load().mmtta_set_option(int(key), int(value)))
     _OPTION_EPOCH += 1
     return prev
+
+
+# launch-geometry knobs (include/mmtta.h: per batch item) measured best for 4 volumes in flight on one GPU; the optimum
+# scales inversely with the volumes in flight (lanes x group): one volume alone wants 384 / 512 / 512 / 1024 (round 1), sixteen
+# want 24 / 32 / 32 / 64 (profiles/r03_tuning_sweep.txt) - the launches of all volumes together should fill the chip about once
+TUNE_AT_4 = {2: 96, 3: 128, 4: 128, 5: 256}      # SPLITK_BELOW, SPLITK_TARGET, WGRAD_WORKGROUPS, WGRAD_THIN_SLABS
+_TUNED_FOR: Optional[int] = None
+
+
+def tune_for_volumes_in_flight(volumes: int) -> Dict[int, int]:
+    """Set the four launch-geometry knobs for `volumes` volumes in flight on this GPU (method.lanes x method.group).  Process
+    wide, like the knobs themselves; call before the first adaptation step (cached plans are dropped, captured graphs keep the
+    geometry they were captured with).  MMTTA_NO_AUTOTUNE=1 leaves the knobs alone (sweeps set them by hand)."""
+    global _TUNED_FOR
+    volumes = max(1, int(volumes))
+    vals = {k: max(1, (v * 4 + volumes - 1) // volumes) for k, v in TUNE_AT_4.items()}
+    if os.environ.get("MMTTA_NO_AUTOTUNE", "0") == "1" or _TUNED_FOR == volumes:
+        return vals
+    for k, v in vals.items():
+        set_option(k, v)
+    _TUNED_FOR = volumes
+    return vals
 
 
 # ----------------------------------------------------------------------------- norm on load

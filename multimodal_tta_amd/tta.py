@@ -85,6 +85,12 @@ class EntropyMinimizationTTA:
         # volumes adapted side by side as the batch items of ONE launch sequence, each with its own replica of the weights
         # and optimizer state (mmtta_param_sets): a volume alone fills a quarter of the chip or less at the lower levels
         self.group = max(1, int(get_config(m, "group", 1)))
+        self.lanes = max(1, int(get_config(m, "lanes", 1)))      # the evaluator's lanes: volumes in flight = lanes x group
+        # launch geometry (split-K, weight-gradient slabs) is chosen for this many volumes in flight; `auto` = lanes x group.
+        # Two runs agree BIT FOR BIT when they use the same figure (the geometry fixes the summation order), whatever their
+        # lanes / group are - which is how the grouped arrangement is checked against one volume at a time
+        tv = get_config(m, "tune_volumes", "auto")
+        self.tune_volumes = None if tv in (None, "auto") else max(1, int(tv))
         self.side_streams = int(get_config(m, "side_streams", 0))   # 0: weight gradients stay on the main stream
         tr = get_config(cfg, "training", {}) or {}
         # the reference's factory (src/core/experiment_manager.py:199-237): `training.optimizer` names the class
@@ -131,12 +137,24 @@ class EntropyMinimizationTTA:
                             "'unet_multimodal_deepfusion', 'unet_multimodal_midfusion')")
         device = torch.device(device)
         self.model = model
+        ops.tune_for_volumes_in_flight(self.tune_volumes or self.lanes * self.group)      # launch geometry for that many volumes
         names = select_params(model, self.params_spec)
         model.set_precision(self.precision, self.storage)
         model.set_group(self.group)
         model.configure_training(set(names), self.no_decay_keys, self.treat_1d)
         model.to(device)
-        self.rt = model.runtime(device)
+        try:
+            self.rt = model.runtime(device)
+        except NotImplementedError as exc:
+            if self.group == 1:
+                raise
+            # norm layers with parameters (BatchNorm / affine norms) are per-model, not per-volume: such a model adapts one
+            # volume per launch sequence; the lanes still keep several volumes in flight
+            warnings.warn(f"method.group = {self.group} -> 1: {exc}")
+            self.group = 1
+            model.set_group(1)
+            self.rt = model.runtime(device)
+        self.group = int(self.rt.group)          # what the runtime supports (a runtime without per-volume sets reports 1)
         self.rt.overlap_wgrad = self.side_streams > 0
         self.rt.n_side = max(1, self.side_streams)
         self.rt.arena.snapshot_source()

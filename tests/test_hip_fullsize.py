@@ -144,3 +144,151 @@ def test_full_size_graph_equals_eager_and_episodic_reset(shape, precision):
         torch.cuda.empty_cache()
     assert torch.equal(outs[True][0], outs[False][0]), "graph replay and eager launches differ"
     assert torch.equal(outs[True][1], outs[False][1])
+
+
+# ----------------------------------------------------------------------------- round 3: the shapes that are actually benchmarked
+def _compare(tag, z, losses, want, thr, tol, y):
+    """Shared checks of a full-size adaptation result against the oracle's: per-step losses, final logits, mask flips only
+    near the threshold, Dice."""
+    import oracle
+    for t, (a, b) in enumerate(zip(losses, want["losses"])):
+        assert abs(a - b) <= tol["loss"] * abs(b), f"{tag} step {t}: loss {a!r} vs oracle {b!r}"
+    z_ref = want["logits"]
+    scale = z_ref.abs().max().item()
+    err = (z - z_ref).abs().max().item() / scale
+    m_hip, m_ref = torch.sigmoid(z) >= thr, torch.sigmoid(z_ref) >= thr
+    flips = m_hip != m_ref
+    near = (z_ref - math.log(thr / (1.0 - thr))).abs() <= tol["logits"] * scale
+    gt = (y > 0.5).to(torch.uint8)
+    d_hip, _, _ = oracle.binary_dice_iou(m_hip.to(torch.uint8), gt)
+    d_ref, _, _ = oracle.binary_dice_iou(m_ref.to(torch.uint8), gt)
+    dd = (d_hip - d_ref).abs().max().item()
+    print(f"[fullsize {tag}] loss rel err {max(abs(a - b) / abs(b) for a, b in zip(losses, want['losses'])):.2e} "
+          f"logits err {err:.2e} mask flips {flips.float().mean().item():.2e} dice diff {dd:.2e}")
+    assert err <= tol["logits"], f"{tag}: logits differ by {err:.3e} of max|logits|"
+    assert not bool((flips & ~near).any()), f"{tag}: a mask voxel flipped away from the threshold"
+    assert dd <= tol["dice"], f"{tag}: Dice differs by {dd:.3e}"
+
+
+def test_ten_step_bf16_adaptation_at_the_headline_shape():
+    """the headline number is S = 10 steps of bf16-operand arithmetic at 4x128^3; here exactly that (the real
+    `unet`, reference learning rate, bf16 operands AND bf16 activation storage) meets the fp32 CPU oracle after all ten
+    steps: every step's loss within 1e-2, final logits within 3e-2 of max|logits|, Dice within 2e-2, masks flip only where
+    the oracle logit sits within that tolerance of the threshold (about 45 s of host time)."""
+    import oracle
+    from multimodal_tta_amd.models import UNet
+    from multimodal_tta_amd.registry import get_plugin
+
+    S = 10
+    torch.manual_seed(42)
+    ref = oracle.UNet(FULL)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    x, y = volume(0, (128, 128, 128), 4, 3)
+    cfg = root_cfg(FULL, S, "bf16")
+    want = oracle.adapt_volume(ref, x, cfg["training"], steps=S)
+    hip = UNet(FULL)
+    hip.load_state_dict(state)
+    plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    res = plug.adapt_volume(x.cuda())
+    _compare("unet 4x128^3 bf16 S=10", plug.logits(res).cpu(), res["losses"].cpu().tolist(), want, 0.5, TOL["bf16"], y)
+
+
+DEEP = dict(name="unet_multimodal_deepfusion", num_modalities=4, num_classes=3, spatial_dims=3, channels=[32, 64, 128, 256, 512],
+            strides=[2, 2, 2, 2], num_res_units=2, norm="INSTANCE", act="RELU", dropout=0.0)
+_DEEP_ORACLE = {}
+
+
+def deep_oracle(key, **kw):
+    if key not in _DEEP_ORACLE:
+        import oracle
+        torch.manual_seed(42)
+        ref = oracle.MultimodalUNetDeepFusion(DEEP)
+        state = {k: v.clone() for k, v in ref.state_dict().items()}
+        x, y = volume(0, (128, 128, 128), 4, 3)
+        cfg = root_cfg(DEEP, 1)
+        out = oracle.adapt_volume(ref, x, cfg["training"], steps=1, **kw)
+        _DEEP_ORACLE[key] = dict(state=state, x=x, y=y, logits=out["logits"], losses=out["losses"])
+    return _DEEP_ORACLE[key]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_width_deepfusion_matches_the_oracle(precision):
+    """the 83 M-parameter deep-fusion network at the width and size it is benchmarked at (channels
+    [32..512], M = 4, 4x128^3): one adaptation step + the final forward against the CPU oracle, both precisions - the
+    1024 -> 512 fusion convolution with its shared weight gradient, the 2048 -> 512 1x1x1, the 33 -> 32 decoder at 128^3 and
+    the one-channel stems as a network."""
+    from multimodal_tta_amd.models import MultimodalUNetDeepFusion
+    from multimodal_tta_amd.registry import get_plugin
+
+    want = deep_oracle("plain")
+    hip = MultimodalUNetDeepFusion(DEEP)
+    hip.load_state_dict(want["state"])
+    plug = get_plugin("entmin_tta")(root_cfg(DEEP, 1, precision)).setup(hip, "cuda")
+    res = plug.adapt_volume(want["x"].cuda())
+    losses = res["losses"].cpu().reshape(-1).tolist()
+    _compare(f"deepfusion 4x128^3 {precision}", plug.logits(res).cpu(), losses, want, 0.5, TOL[precision], want["y"])
+
+
+def test_config5_missing_modality_with_dropout_at_full_size_unet():
+    """VERDICT r2 P5 / BASELINE configs[4]: T1ce (channel 1) missing for the whole run plus seeded per-step modality dropout,
+    at 4x128^3 in bf16 precision, `unet`: two steps + final forward against the oracle."""
+    import oracle
+    from multimodal_tta_amd.models import UNet
+    from multimodal_tta_amd.registry import get_plugin
+
+    torch.manual_seed(42)
+    ref = oracle.UNet(FULL)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    x, y = volume(3, (128, 128, 128), 4, 3)
+    cfg = root_cfg(FULL, 2, "bf16", missing_modalities=[1], moddrop={"enabled": True, "p": 0.5, "seed": 0})
+    want = oracle.adapt_volume(ref, x, cfg["training"], steps=2, missing=[1], moddrop_p=0.5, moddrop_seed=0)
+    hip = UNet(FULL)
+    hip.load_state_dict(state)
+    plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    res = plug.adapt_volume(x.cuda())
+    _compare("config 5 unet 4x128^3 bf16", plug.logits(res).cpu(), res["losses"].cpu().reshape(-1).tolist(), want, 0.5,
+             TOL["bf16"], y)
+
+
+def test_config5_missing_modality_with_dropout_at_full_size_deepfusion():
+    """The same for the deep-fusion network (means over present modalities only, an absent branch feeds the shared mean;
+    SURVEY.md Appendix C), bf16 precision, one step + final forward."""
+    from multimodal_tta_amd.models import MultimodalUNetDeepFusion
+    from multimodal_tta_amd.registry import get_plugin
+
+    want = deep_oracle("config5", missing=[1], moddrop_p=0.5, moddrop_seed=0, masked_means=True)
+    hip = MultimodalUNetDeepFusion(DEEP)
+    hip.load_state_dict(want["state"])
+    cfg = root_cfg(DEEP, 1, "bf16", missing_modalities=[1], moddrop={"enabled": True, "p": 0.5, "seed": 0})
+    plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    res = plug.adapt_volume(want["x"].cuda())
+    _compare("config 5 deepfusion 4x128^3 bf16", plug.logits(res).cpu(), res["losses"].cpu().reshape(-1).tolist(), want, 0.5,
+             TOL["bf16"], want["y"])
+
+
+def test_grouped_lanes_equal_one_volume_at_a_time_at_full_width():
+    """the benchmarked arrangement (lanes x group volumes in flight, full width, 4x128^3, bf16) reports
+    bit for bit what one lane adapting one volume at a time reports - the evaluator's per-volume table and metrics."""
+    from multimodal_tta_amd.registry import get_dataset_builder, get_evaluation_strategy
+    from multimodal_tta_amd.models import UNet
+
+    results = []
+    for lanes, group in ((1, 1), (2, 2), (1, 4)):
+        cfg = root_cfg(FULL, 2, "bf16", lr=1e-3, group=group, tune_volumes=4)      # one launch geometry for all three
+        cfg["method"]["lanes"] = lanes
+        cfg["dataset"]["synthetic"]["num_volumes"] = 5          # a partial last group for both grouped arrangements
+        cfg["dataset"]["synthetic"]["shape"] = [128, 128, 128]
+        cfg["training"]["eval_batch_size"] = 2
+        torch.manual_seed(42)
+        hip = UNet(FULL)
+        loader = get_dataset_builder("brats")(cfg).get_loader("test")
+        strat = get_evaluation_strategy("seg_tta_eval")(cfg)
+        m = strat.evaluate_epoch(hip, loader, torch.device("cuda"))
+        assert strat.group == group and strat.lanes == lanes
+        results.append((m, strat.last_table.clone()))
+        del strat, hip
+        torch.cuda.empty_cache()
+    for m, t in results[1:]:
+        assert torch.equal(t, results[0][1]), "per-volume table differs from the one-volume-at-a-time run"
+        assert m == results[0][0]
+    assert results[0][1].shape[0] == 5

@@ -257,12 +257,15 @@ def test_group_of_volumes_equals_one_volume_at_a_time(model_cfg, shape, precisio
         assert torch.equal(outs[1][g][0], part[0][:, g]) and torch.equal(outs[1][g][1][0], part[1][g]), f"partial group, volume {g}"
 
 
-def test_group_rejects_models_with_norm_parameters():
+def test_models_with_norm_parameters_fall_back_to_one_volume_per_launch():
+    """BatchNorm statistics run across the batch and norm affines are per-model parameters: such a model cannot adapt a group
+    of volumes in one launch sequence - the plugin says so and falls back to method.group = 1 (lanes still apply)."""
     from multimodal_tta_amd.registry import get_plugin
     from test_hip_tta import build_pair, root_cfg
 
     cfg_m = dict(SMALL, norm="BATCH")
     cfg = root_cfg(cfg_m, steps=1, group=2)
     _, hip = build_pair(cfg_m)
-    with pytest.raises(NotImplementedError, match="method.group"):
-        get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    with pytest.warns(UserWarning, match="method.group = 2 -> 1"):
+        plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
+    assert plug.group == 1 and plug.rt.group == 1 and plug.rt.arena.replicas == 1

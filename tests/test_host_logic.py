@@ -238,3 +238,36 @@ def test_surface_columns_travel_through_the_gather_table():
     acc = RegionAccumulator(regions, surface=False)
     acc.add_row([.9, .8, .7], [.8, .7, .6], [True, True, False], "a")
     assert not any("hd95" in k or "asd" in k for k in acc.metrics(False))
+
+
+def test_hardware_queue_dependency_is_loud(monkeypatch):
+    """more than two lanes only overlap when the HIP runtime was started with GPU_MAX_HW_QUEUES >= 8; a host
+    that initialised the GPU before importing the package gets a warning (once) with the measured cost, and
+    `lanes_effective` says what to expect."""
+    import warnings
+
+    import multimodal_tta_amd as pkg
+    from multimodal_tta_amd import ops
+
+    class _FakeStream:
+        def __init__(self, device=None):
+            pass
+
+    monkeypatch.setattr(torch.cuda, "Stream", _FakeStream)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: __import__("contextlib").nullcontext())
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch, "zeros", lambda *a, **k: None)
+    monkeypatch.setattr(pkg, "HIP_STARTED_BEFORE_IMPORT", True)
+    monkeypatch.setattr(pkg, "HW_QUEUES_AT_HIP_START", None)
+    monkeypatch.setattr(ops, "_QUEUE_WARNED", False)
+    assert ops.hw_queue_status()["queues"] == 4 and ops.lanes_effective(4) == 2 and ops.lanes_effective(2) == 2
+    with pytest.warns(RuntimeWarning, match="GPU_MAX_HW_QUEUES"):
+        ops.lane_streams(4, "cpu")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ops.lane_streams(4, "cpu")                       # once per process
+        monkeypatch.setattr(ops, "_QUEUE_WARNED", False)
+        ops.lane_streams(2, "cpu")                       # two lanes fit the default queues
+        monkeypatch.setattr(pkg, "HW_QUEUES_AT_HIP_START", "8")
+        ops.lane_streams(4, "cpu")
+    assert ops.lanes_effective(4) == 4

@@ -216,3 +216,87 @@ def test_bench_table_assembly_two_processes_gloo(tmp_path):
     valid = want[:, 3 + 2 * R:3 + 3 * R] > 0.5
     assert int((~valid).sum()) == world              # the two empty-GT regions are excluded
     assert abs(bench.post_dice_from_table(want, R) - float(want[:, 3:3 + R][valid].mean())) < 1e-12
+
+
+# ----------------------------------------------------------------------------- optional mask gather (north star: "Dice/logits")
+def _mask_of(i):
+    g = torch.Generator().manual_seed(1000 + i)
+    shape = (R, 4 + i % 2, 6, 5 + i % 3)                 # ragged extents across volumes (HECKTOR-style crops)
+    return (torch.rand(shape, generator=g) > 0.5).to(torch.uint8)
+
+
+def _mask_worker(rank, world, port, shards, out_dir):
+    import torch.distributed as dist
+    from multimodal_tta_amd.evaluation import gather_masks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = gather_masks([(i, _mask_of(i)) for i in shards[rank]], "cpu")
+    torch.save({int(k): v for k, v in got.items()}, os.path.join(out_dir, f"mk{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shards", [[[0, 2, 4], [1, 3]], [[0, 1, 2, 3, 4], []]])
+def test_gather_masks_two_processes_gloo(tmp_path, shards):
+    """`evaluation.gather_masks`: the second collective of a sharded evaluation - every rank ends up with the uint8 mask of
+    EVERY volume, equal to the single-process masks; unequal and empty shards, ragged extents."""
+    from multimodal_tta_amd.evaluation import gather_masks
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    single = gather_masks([(i, _mask_of(i)) for i in range(5)], "cpu")
+    assert sorted(single) == list(range(5))
+    mp.spawn(_mask_worker, args=(2, port, shards, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), f"mk{r}.pt"), weights_only=True)
+        assert sorted(got) == list(range(5)), f"rank {r}"
+        for i in range(5):
+            assert got[i].dtype == torch.uint8 and torch.equal(got[i], single[i]), f"rank {r}, volume {i}"
+
+
+def test_gather_table_drops_repeated_volumes():
+    """A sampler that pads the last shard repeats volumes: the merged table keeps one row per index."""
+    rows = fake_rows(4)
+    dup = torch.cat([rows, rows[1:2]])
+    assert torch.equal(gather_table(dup, 5, 1), rows)
+
+
+# ----------------------------------------------------------------------------- 8 ranks (the first real 8-GPU run must need no debugging)
+def _bench8_worker(rank, world, port, n_total, out_dir):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_indices(n_total, rank, world)           # N = 5: ranks 5..7 hold nothing
+    counts = _bench_counts(rank, max(len(mine), 1))[:len(mine)]
+    rows = bench.bench_rows(counts, rank, world) if mine else torch.empty((0, table_width(R)), dtype=torch.float64)
+    table = gather_table(rows, n_total, world)
+    torch.save(table, os.path.join(out_dir, f"e{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [5, 64])
+def test_eight_rank_table_assembly_gloo(tmp_path, n_total):
+    """BASELINE configs 4 / 5 shard the test split over 8 ranks: N = 5 (empty ranks) and N = 64 (8 volumes per rank = 2 lanes
+    x a group of 4) produce the same index-sorted table on every rank, equal to the single-process assembly."""
+    import bench
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 8
+    mp.spawn(_bench8_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    parts = []
+    for r in range(world):
+        mine = shard_indices(n_total, r, world)
+        if mine:
+            parts.append(bench.bench_rows(_bench_counts(r, len(mine)), r, world))
+    want = torch.cat(parts)
+    want = want[torch.argsort(want[:, 0])]
+    assert want[:, 0].tolist() == [float(i) for i in range(n_total)]
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f"e{r}.pt"), weights_only=True)
+        assert torch.equal(got, want), f"rank {r}"
