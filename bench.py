@@ -56,7 +56,7 @@ def mfma_peak(kernel_name: str) -> float:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24, help="timed adapted volumes per rank")
+    ap.add_argument("--steps", type=int, default=32, help="timed adapted volumes per rank")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="unet", choices=["unet", "unet_multimodal_deepfusion"])
     ap.add_argument("--task", default="brats", choices=["brats", "hecktor21"])
@@ -102,10 +102,12 @@ def build_cfg(args):
     return cfg, tuple(shape)
 
 
-def cpu_baseline(cfg, shape, tta_steps):
-    """Oracle on the host cores: 1 adaptation step + 1 final forward of one full-size volume, extrapolated to
-    S steps (a bounded sample: a whole 10-step volume is ~1 min of CPU work).  Also returns what the step produced
-    (loss before the update, logits after it) so that the GPU path can be checked against it at full size."""
+def cpu_baseline(cfg, shape, tta_steps, timed_steps=2):
+    """Oracle on the host cores, a bounded sample of the same workload (a whole 10-step volume is ~1 min of CPU work):
+    one DISCARDED warm-up step (first call of the process: allocator, oneDNN primitive caches), then `timed_steps`
+    adaptation steps timed per phase (forward / backward / optimizer) and one timed final forward + masks + Dice,
+    extrapolated to S steps.  Also returns what the FIRST step produced (loss before the update, logits after it) so that
+    the GPU path can be checked against it at full size."""
     import oracle
     from multimodal_tta_amd.synth import synth_volume
 
@@ -118,27 +120,44 @@ def cpu_baseline(cfg, shape, tta_steps):
     v = synth_volume(0, C, shape, R)
     x = v["image"].unsqueeze(0)
     opt = oracle.build_optimizer(list(model.named_parameters()), cfg["training"])
-    model.train()
-    t0 = time.perf_counter()
-    opt.zero_grad()
-    loss = oracle.entropy_loss(model(x))
-    loss.backward()
-    opt.step()
-    t_step = time.perf_counter() - t0
-    model.eval()
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        z = model(x)
-        pred, gt = oracle.masks_from_logits(z, v["label"].unsqueeze(0), thr)
-        dice, _, valid = oracle.binary_dice_iou(pred, gt)
-    t_fwd = time.perf_counter() - t0
-    per_volume = tta_steps * t_step + t_fwd
+
+    def step():
+        model.train()
+        t = [time.perf_counter()]
+        opt.zero_grad()
+        loss = oracle.entropy_loss(model(x))
+        t.append(time.perf_counter())
+        loss.backward()
+        t.append(time.perf_counter())
+        opt.step()
+        t.append(time.perf_counter())
+        return float(loss.item()), (t[1] - t[0], t[2] - t[1], t[3] - t[2])
+
+    def evaluate():
+        model.eval()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            z = model(x)
+            pred, gt = oracle.masks_from_logits(z, v["label"].unsqueeze(0), thr)
+            dice, _, _ = oracle.binary_dice_iou(pred, gt)
+        return z, pred, dice, time.perf_counter() - t0
+
+    loss0, warm = step()                               # discarded timing; its results are the parity reference
+    z, pred, dice, _ = evaluate()                      # logits after exactly one step (also warms the eval path)
+    phases = [step()[1] for _ in range(timed_steps)]
+    _, _, _, t_eval = evaluate()
+    t_fwd, t_bwd, t_opt = (sum(p[i] for p in phases) / timed_steps for i in range(3))
+    t_step = t_fwd + t_bwd + t_opt
+    per_volume = tta_steps * t_step + t_eval
     base = {
         "value": 1.0 / per_volume, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"1 adaptation step ({t_step:.2f} s, first call of the process: no warm-up) + 1 final forward+Dice "
-                  f"({t_fwd:.2f} s) of one {C}x{shape[0]}x{shape[1]}x{shape[2]} volume, extrapolated to S={tta_steps} steps",
+        "phases_s": {"forward": t_fwd, "backward": t_bwd, "optimizer": t_opt, "eval_forward_dice": t_eval,
+                     "warmup_step_discarded": sum(warm)},
+        "sample": f"1 discarded warm-up step ({sum(warm):.2f} s), then {timed_steps} timed adaptation steps (mean {t_step:.2f} s = "
+                  f"forward {t_fwd:.2f} + backward {t_bwd:.2f} + optimizer {t_opt:.2f}) and 1 timed final forward+masks+Dice "
+                  f"({t_eval:.2f} s) of one {C}x{shape[0]}x{shape[1]}x{shape[2]} volume, extrapolated to S={tta_steps} steps",
     }
-    return base, {"state": state, "x": x, "label": v["label"].unsqueeze(0), "loss0": float(loss.item()), "logits": z,
+    return base, {"state": state, "x": x, "label": v["label"].unsqueeze(0), "loss0": loss0, "logits": z,
                   "pred": pred, "dice": dice, "thr": thr}
 
 
@@ -239,12 +258,22 @@ def main():
         v = synth_volume(rank * nvol + i, C, shape, R)
         vols.append((v["image"].unsqueeze(0).to(device), v["label"].unsqueeze(0).to(device)))
 
-    def schedule(first, last, group_):
-        """[(lane, [volume indices])]: consecutive volumes form groups of `group_` (the last one may be partial), groups go
-        round-robin over the lanes."""
-        out_ = []
-        for k, a in enumerate(range(first, last, group_)):
-            out_.append((k, list(range(a, min(a + group_, last)))))
+    def schedule(first, last, group_, lanes_=None):
+        """[(k, [volume indices])]: the volumes [first, last) as lanes x rounds groups of (nearly) EQUAL size <= `group_`,
+        dealt round-robin over the lanes - so every lane gets the same number of groups whatever the volume count (20 volumes,
+        2 lanes, groups of up to 8: four groups of 5, not 8 + 8 + 4 with one lane idle for the third)."""
+        lanes_ = lanes if lanes_ is None else lanes_
+        nv_ = last - first
+        if nv_ <= 0:
+            return []
+        rounds = -(-nv_ // (lanes_ * group_))
+        ngroups = min(nv_, lanes_ * rounds)
+        base, extra = divmod(nv_, ngroups)
+        out_, a = [], first
+        for k in range(ngroups):
+            size = base + (1 if k < extra else 0)
+            out_.append((k, list(range(a, a + size))))
+            a += size
         return out_
 
     # the timed volumes as resident group tensors (inputs are in HBM before the timed region starts)
@@ -274,7 +303,7 @@ def main():
 
     def run_volumes(plugs_, streams_, first, last, counts_, group_=None):
         group_ = group if group_ is None else group_
-        for k, idx in schedule(first, last, group_):
+        for k, idx in schedule(first, last, group_, len(plugs_)):
             lane = k % len(plugs_)
             x, y = group_tensors(idx)
             with torch.cuda.stream(streams_[lane]):
@@ -335,6 +364,9 @@ def main():
             "graph": bool(plug.use_graph), "lanes": lanes, "group": group,
             "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
         },
+        # how far two runs of this line differ (measured): the timed region is short
+        "repeatability": {"same_box_rel": 0.005, "cross_box_rel": 0.03,
+                          "timed_region_s": elapsed, "note": "same command twice on one box / on different boxes of the pool"},
         "ranks": {"volumes_per_s_min": args.steps / t_local_max, "volumes_per_s_max": args.steps / t_local_min,
                   "gather_ms": 1000.0 * t_gather},
     }
@@ -441,6 +473,15 @@ def roofline_block(args, cfg, plug, x0, s_per_volume):
         t = json.load(open(tpath)).get(name)
         if t:
             traffic = t["fetch_bytes"] + t["write_bytes"]
+    # the same kernel's average launch duration in the committed rocprofv3 kernel trace of this build's bench command
+    # (scripts/trace_summary.py --json -> profiles/trace_avg_us.json): in situ, lanes interleaving - beside the event figure
+    trace_us = None
+    kpath = os.path.join(ROOT, "profiles", "trace_avg_us.json")
+    if os.path.exists(kpath):
+        tr = json.load(open(kpath))
+        hits = [v for k, v in tr.get("kernels", {}).items() if k.replace(" ", "").startswith(name.replace("bf16", "true").replace(" ", "").split(">")[0])]
+        if hits:
+            trace_us = sum(h["total_us"] for h in hits) / max(1, sum(h["calls"] for h in hits))
     hbm = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
            "bytes_per_launch": d["bytes"] / d["launches"]}
     mfma = {"bound": "mfma", "achieved": tflops, "peak": mfma_peak(name), "unit": "TFLOP/s", "frac": tflops / mfma_peak(name),
@@ -449,6 +490,7 @@ def roofline_block(args, cfg, plug, x0, s_per_volume):
     block = dict(first)
     block.update({
         "kernel": name, "traffic": traffic, "avg_launch_us": 1000.0 * d["ms"] / d["launches"], "launches": d["launches"],
+        "trace_avg_launch_us": trace_us, "volumes_per_launch": B,
         "share_of_conv_time": d["ms"] / total_ms,
         ("mfma" if bf else "hbm"): {k: v for k, v in second.items() if k != "bound"},
         "all_conv_kernels": {k: {"tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,

@@ -443,7 +443,7 @@ int mmtta_optim_step_sets(const mmtta_optim_desc* desc, float* p, const float* g
 int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label, float threshold,
                            int64_t* counts, uint8_t* mask, void* stream);
 
-/* Sums behind monai DiceCELoss(sigmoid=True) as the reference evaluator builds it for
+/* Sums behind monai DiceCELoss as the reference builds it - evaluator: sigmoid=True, hard-coded, for
  * ``evaluation.loss.report_loss`` (reference src/evaluation/seg_eval.py:209-220,395-400; SURVEY.md
  * Appendix A.5).  out fp64 [N][R*3+1] (block partials go through `scratch`, mmtta_dice_ce_scratch_bytes; they are
  * summed in a fixed order: reproducible): per region (sum p*y, sum p, sum y) with
@@ -451,15 +451,17 @@ int mmtta_mask_dice_counts(const mmtta_tensor* logits, const mmtta_tensor* label
  * pos_weight = weight[0] when R == 1, soft-label softmax cross entropy with class weights otherwise.
  * The few scalar operations that turn the sums into the loss value are host arithmetic. */
 int64_t mmtta_dice_ce_scratch_bytes(const mmtta_tensor* logits);
+/* softmax != 0 (a `training.criterion.softmax: true` head, reference src/core/trainers/seg_trainer.py:41-54): the Dice
+ * probabilities are softmax over the channels instead of per-channel sigmoids (R > 1; the CE term is softmax CE either way). */
 int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight,
-                       int squared_pred, double* out, void* scratch, void* stream);
+                       int squared_pred, int softmax, double* out, void* scratch, void* stream);
 
 /* d(lambda_dice * Dice + lambda_ce * CE)/d(logits) of the same loss (reduction mean), from the sums above (left
  * on the device): the supervised step of reference src/core/trainers/seg_trainer.py:141-142 without autograd.
  * Class weights scale the Dice terms only when more than one Dice channel exists (monai); include_background == 0
  * drops channel 0 from the Dice mean when R > 1. */
 int mmtta_dice_ce_grad(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight, int squared_pred,
-                       int jaccard, int include_background, float lambda_dice, float lambda_ce, float smooth_nr,
+                       int softmax, int jaccard, int include_background, float lambda_dice, float lambda_ce, float smooth_nr,
                        float smooth_dr, const double* sums, const mmtta_tensor* dlogits, void* stream);
 
 /* Surface metrics of the evaluation tail: percentile Hausdorff distance and average surface distance per

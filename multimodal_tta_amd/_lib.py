@@ -134,8 +134,8 @@ _SIGNATURES = {
                                         C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "mmtta_mask_dice_counts": (C.c_int, [_P(Tensor), _P(Tensor), C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmtta_dice_ce_scratch_bytes": (C.c_int64, [_P(Tensor)]),
-    "mmtta_dice_ce_sums": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mmtta_dice_ce_grad": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+    "mmtta_dice_ce_sums": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmtta_dice_ce_grad": (C.c_int, [_P(Tensor), _P(Tensor), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_void_p, _P(Tensor), C.c_void_p]),
     "mmtta_surface_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "mmtta_surface_distances": (C.c_int, [C.c_void_p, _P(Tensor), _P(C.c_double), C.c_double, C.c_int, C.c_void_p,

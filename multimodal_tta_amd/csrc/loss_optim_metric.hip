@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void dice_counts_kernel(TV z, TV lab, float th
 // Block partials [N][blocks_per_n][R*3 + 1] in the scratch buffer, summed in block order by dice_ce_finish_kernel:
 // no atomics, the sums (and the gradient built from them) are bitwise reproducible.
 constexpr int DCE_MAX_R = 8;
-__global__ __launch_bounds__(256) void dice_ce_sums_kernel(TV z, TV lab, const float* weight, int squared,
+__global__ __launch_bounds__(256) void dice_ce_sums_kernel(TV z, TV lab, const float* weight, int squared, int softmax,
                                                            double* out, int blocks_per_n) {
   __shared__ double sh[4];
   const int R = z.c;
@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256) void dice_ce_sums_kernel(TV z, TV lab, const f
     for (int r = 0; r < DCE_MAX_R; ++r)
       if (r < R) {
         const float e = expf(-fabsf(lg[r]));
-        const float p = lg[r] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        // Dice probability: sigmoid (multilabel heads) or softmax over the channels (softmax heads with more than one channel)
+        const float p = (softmax && R > 1) ? expf(lg[r] - lse) : (lg[r] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e));
         acc[r * 3 + 0] += (double)(p * yv[r]);
         acc[r * 3 + 1] += (double)(squared ? p * p : p);
         acc[r * 3 + 2] += (double)(squared ? yv[r] * yv[r] : yv[r]);
@@ -321,7 +322,7 @@ struct DceGradArgs {
   TV z, lab, dz;
   const float* weight;
   const double* sums;       // [N][R*3+1]
-  int squared, jaccard, include_background;
+  int squared, jaccard, include_background, softmax;
   float lambda_dice, lambda_ce, smooth_nr, smooth_dr;
 };
 
@@ -352,11 +353,16 @@ __global__ __launch_bounds__(256) void dice_ce_grad_kernel(DceGradArgs a) {
 #pragma unroll
     for (int r = 0; r < DCE_MAX_R; ++r)
       if (r < R) { se += expf(lg[r] - m); S += (a.weight ? a.weight[r] : 1.f) * yv[r]; }
+    const bool smx = a.softmax && R > 1;
+    // softmax heads: dDice/dz_k = p_k (dLdp_k - sum_r dLdp_r p_r) (the softmax Jacobian); first pass: dLdp_r and their p-weighted sum
+    float dldp[DCE_MAX_R], dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < DCE_MAX_R; ++r) dldp[r] = 0.f;
 #pragma unroll
     for (int r = 0; r < DCE_MAX_R; ++r)
       if (r < R) {
         const float e = expf(-fabsf(lg[r]));
-        const float p = lg[r] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        const float p = smx ? expf(lg[r] - m) / se : (lg[r] >= 0.f ? 1.f / (1.f + e) : e / (1.f + e));
         float gd = 0.f;
         if (r >= r0) {
           const double* sm = a.sums + (long long)n * (R * 3 + 1) + r * 3;
@@ -369,8 +375,9 @@ __global__ __launch_bounds__(256) void dice_ce_grad_kernel(DceGradArgs a) {
           const float dfdp = -(2.f * yv[r] * Dn - A * dden) / (Dn * Dn);
           // class weights scale the Dice terms only when there is more than one Dice channel (monai)
           const float cw = (a.weight != nullptr && Rd != 1) ? a.weight[r] : 1.f;
-          gd = dice_scale * cw * dfdp * p * (1.f - p);
+          gd = dice_scale * cw * dfdp * (smx ? 1.f : p * (1.f - p));
         }
+        if (smx) { dldp[r] = gd; dot += gd * p; continue; }
         float gc;
         if (R == 1) {
           const float pw = a.weight ? a.weight[0] : 1.f;
@@ -382,6 +389,16 @@ __global__ __launch_bounds__(256) void dice_ce_grad_kernel(DceGradArgs a) {
         g[r] = gd + ce_scale * gc;
         a.dz.p[n * a.dz.sn + (long long)r * a.dz.sc + zz * a.dz.sd + y * a.dz.sh + x * a.dz.sw] = g[r];
       }
+    if (smx) {
+#pragma unroll
+      for (int r = 0; r < DCE_MAX_R; ++r)
+        if (r < R) {
+          const float sp = expf(lg[r] - m) / se;
+          const float gc = sp * S - (a.weight ? a.weight[r] : 1.f) * yv[r];
+          g[r] = sp * (dldp[r] - dot) + ce_scale * gc;
+          a.dz.p[n * a.dz.sn + (long long)r * a.dz.sc + zz * a.dz.sd + y * a.dz.sh + x * a.dz.sw] = g[r];
+        }
+    }
   }
 }
 
@@ -541,7 +558,7 @@ extern "C" int64_t mmtta_dice_ce_scratch_bytes(const mmtta_tensor* logits) {
 }
 
 extern "C" int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight,
-                                  int squared_pred, double* out, void* scratch, void* stream) {
+                                  int squared_pred, int softmax, double* out, void* scratch, void* stream) {
   MMTTA_CHECK(logits == nullptr || logits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_dice_ce_sums: `logits` must be fp32-stored");
   MMTTA_CHECK(label == nullptr || label->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_dice_ce_sums: `label` must be fp32-stored");
   MMTTA_CHECK(logits && label && out && scratch && logits->ptr && label->ptr, MMTTA_ERR_INVALID, "dice_ce: null argument");
@@ -552,7 +569,7 @@ extern "C" int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor
   const long long bpn = dice_ce_blocks_per_n(logits);
   const int cols = logits->c * 3 + 1;
   hipLaunchKernelGGL(dice_ce_sums_kernel, dim3((unsigned)(bpn * logits->n)), dim3(256), 0, s, tv(logits), tv(label), weight,
-                     squared_pred, (double*)scratch, (int)bpn);
+                     squared_pred, softmax, (double*)scratch, (int)bpn);
   int st = launch_status("dice_ce sums");
   if (st) return st;
   hipLaunchKernelGGL(dice_ce_finish_kernel, dim3(logits->n * cols), dim3(64), 0, s, (const double*)scratch, (int)bpn, cols, out);
@@ -560,7 +577,7 @@ extern "C" int mmtta_dice_ce_sums(const mmtta_tensor* logits, const mmtta_tensor
 }
 
 extern "C" int mmtta_dice_ce_grad(const mmtta_tensor* logits, const mmtta_tensor* label, const float* weight, int squared_pred,
-                                  int jaccard, int include_background, float lambda_dice, float lambda_ce, float smooth_nr,
+                                  int softmax, int jaccard, int include_background, float lambda_dice, float lambda_ce, float smooth_nr,
                                   float smooth_dr, const double* sums, const mmtta_tensor* dlogits, void* stream) {
   MMTTA_CHECK(logits == nullptr || logits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_dice_ce_grad: `logits` must be fp32-stored");
   MMTTA_CHECK(label == nullptr || label->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_dice_ce_grad: `label` must be fp32-stored");
@@ -573,7 +590,7 @@ extern "C" int mmtta_dice_ce_grad(const mmtta_tensor* logits, const mmtta_tensor
   MMTTA_CHECK(logits->c <= DCE_MAX_R, MMTTA_ERR_UNSUPPORTED, "dice_ce grad: more than %d regions", DCE_MAX_R);
   DceGradArgs a;
   a.z = tv(logits); a.lab = tv(label); a.dz = tv(dlogits); a.weight = weight; a.sums = sums;
-  a.squared = squared_pred; a.jaccard = jaccard; a.include_background = include_background;
+  a.squared = squared_pred; a.jaccard = jaccard; a.include_background = include_background; a.softmax = softmax;
   a.lambda_dice = lambda_dice; a.lambda_ce = lambda_ce; a.smooth_nr = smooth_nr; a.smooth_dr = smooth_dr;
   const long long total = (long long)logits->n * logits->d * logits->h * logits->w;
   long long blocks = (total + 255) / 256;

@@ -412,6 +412,27 @@ class Runtime:
         self.convs.append(layer)
         return layer
 
+    def make_conv_family(self, names: Sequence[str], modules: Sequence[torch.nn.Module], items_per_set: int = 1) -> ConvLayer:
+        """ONE layer object for a family of identical convolution modules with different weights (``modules``: the same layer
+        of the M modality encoders) - they run as consecutive batch items of one launch (item n uses member n % M of volume
+        n // M).  ``items_per_set`` > 1 with a single module: consecutive batch items share that module's weights (the fusion
+        convolution the reference applies M times)."""
+        m0 = modules[0]
+        transposed = isinstance(m0, torch.nn.ConvTranspose3d)
+        k, s = m0.kernel_size[0], m0.stride[0]
+        for mod in modules[1:]:
+            if (type(mod), mod.in_channels, mod.out_channels, mod.kernel_size, mod.stride, mod.bias is None) != \
+                    (type(m0), m0.in_channels, m0.out_channels, m0.kernel_size, m0.stride, m0.bias is None):
+                raise MmttaError("the members of a layer family must be identical modules")
+        op = ConvOp(m0.in_channels, m0.out_channels, k, s, transposed, self.device, dtype=self.conv_dtype,
+                    n_sets=self.group * len(modules))
+        ws = [self.make_ref(n + ".weight", mod.weight) for n, mod in zip(names, modules)]
+        bs = [self.make_ref(n + ".bias", mod.bias) if mod.bias is not None else None for n, mod in zip(names, modules)]
+        layer = ConvLayer(op, ws[0], bs[0], self, members=list(zip(ws, bs)), items_per_set=items_per_set)
+        layer.side_index = len(self.convs)
+        self.convs.append(layer)
+        return layer
+
     def side_stream(self, index: int = 0) -> Optional[torch.cuda.Stream]:
         if not self.overlap_wgrad or ops.PROFILER is not None:
             return None
@@ -543,6 +564,35 @@ def build_convolution(rt: Runtime, prefix: str, cont: torch.nn.Module) -> Convol
     adn = getattr(cont, "adn", None)
     norm = build_norm(rt, prefix + ".adn", adn, cont.conv.out_channels)
     return ConvolutionBlock(rt, conv, norm)
+
+
+def _family_norm(rt: Runtime, prefix: str, cont: torch.nn.Module) -> Optional[NormLayer]:
+    """The norm of a layer family: one NormLayer serves every member, so it must carry no parameters and no cross-item
+    statistics (InstanceNorm3d without affine: statistics per batch item and channel - the shipped configs)."""
+    adn = getattr(cont, "adn", None)
+    if adn is None:
+        return None
+    nmod = dict(adn.named_children()).get("N")
+    if not isinstance(nmod, torch.nn.InstanceNorm3d) or nmod.affine or nmod.track_running_stats:
+        raise NotImplementedError("a layer family (modality encoders in one launch) needs parameter-free per-item norms (INSTANCE)")
+    return build_norm(rt, prefix + ".adn", adn, cont.conv.out_channels)
+
+
+def build_convolution_family(rt: Runtime, prefixes: Sequence[str], conts: Sequence[torch.nn.Module],
+                             items_per_set: int = 1) -> ConvolutionBlock:
+    conv = rt.make_conv_family([p + ".conv" for p in prefixes], [c.conv for c in conts], items_per_set)
+    return ConvolutionBlock(rt, conv, _family_norm(rt, prefixes[0], conts[0]))
+
+
+def build_residual_unit_family(rt: Runtime, prefixes: Sequence[str], conts: Sequence[torch.nn.Module]) -> ResidualUnitBlock:
+    """monai ResidualUnit for a family of identical units (same layer of every modality encoder)."""
+    names = [name for name, _ in conts[0].conv.named_children()]
+    units = [build_convolution_family(rt, [f"{p}.conv.{name}" for p in prefixes], [getattr(c.conv, name) for c in conts])
+             for name in names]
+    residual = None
+    if isinstance(conts[0].residual, torch.nn.Conv3d):
+        residual = rt.make_conv_family([p + ".residual" for p in prefixes], [c.residual for c in conts])
+    return ResidualUnitBlock(rt, units, residual)
 
 
 def build_residual_unit(rt: Runtime, prefix: str, cont: torch.nn.Module) -> ResidualUnitBlock:

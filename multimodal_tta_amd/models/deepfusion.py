@@ -25,7 +25,8 @@ import torch.nn as nn
 
 from .. import ops
 from ..config import as_cfg, get_config
-from ..engine import (ConvolutionBlock, Runtime, build_convolution, build_residual_unit)
+from ..engine import (ConvolutionBlock, Runtime, build_convolution, build_convolution_family, build_residual_unit,
+                      build_residual_unit_family)
 from ..registry import register_model
 from .base import HipSegModel
 from .containers import Convolution, Holder, ResidualUnit, UpSample
@@ -56,7 +57,10 @@ class DecoderStage(Holder):
                                  subunits=num_res_units, act=act, norm=norm, dropout=dropout)
 
 
-class DeepFusionRuntime(Runtime):
+class DeepFusionLoopRuntime(Runtime):
+    """One modality encoder after another, the way the reference runs them (:214-218).  Kept for models whose norm layers
+    carry parameters or cross-item statistics (BATCH / GROUP / affine norms): those cannot share one norm object across a
+    family of encoders.  The shipped INSTANCE-norm configs run on :class:`DeepFusionRuntime`."""
     supports_present = True
 
     def __init__(self, model: "MultimodalUNetDeepFusion", device: torch.device):
@@ -259,10 +263,217 @@ class DeepFusionRuntime(Runtime):
                 dout = dx
 
 
+class DeepFusionRuntime(Runtime):
+    """The M modality encoders as ONE launch sequence: layer i of every encoder is a layer *family* (engine.ConvLayer
+    members, mmtta_param_sets ``inner`` = M) whose batch items are (volume, modality) pairs, so a launch at the 8^3 / 16^3 /
+    32^3 levels carries M (x ``method.group``) times the workgroups of the reference's one-encoder-at-a-time loop
+    (reference src/models/unet_multimodal_midfusion.py:214-218; SURVEY.md row a2 "batchable as grouped conv").  The fusion
+    convolution the reference applies M times with shared weights (:222) is one launch over the same batch with
+    ``items_per_set`` = M: its weight gradient sums over the M items of a volume inside the launch.
+
+    Batch layout of every encoder-side tensor: [n * M, ...], item v * M + m = (volume v, modality m).  An ABSENT modality
+    (``present``, missing-modality configs) still runs through its encoder - its input is all zeros - but is left out of
+    every mean, feeds the shared mean to ``bottleneck_reduce`` and receives zero gradients, which is exactly what skipping
+    it gives (its weight gradients come out as exact zeros)."""
+    supports_present = True
+
+    def __init__(self, model: "MultimodalUNetDeepFusion", device: torch.device):
+        super().__init__(device, model.conv_dtype, group=getattr(model, "group", 1))
+        self.M = model.num_modalities
+        self.in_channels = self.M
+        self.channels = list(model.channels)
+        self.out_channels = model.num_classes
+        M, nlev = self.M, len(self.channels)
+        encs = list(model.specific_encoders)
+        self.encf = [build_residual_unit_family(self, [f"specific_encoders.{m}.layers.{i}" for m in range(M)],
+                                                [e.layers[i] for e in encs]) for i in range(nlev)]
+        self.fusion = build_convolution_family(self, ["fusion_layer.fusion_conv"], [model.fusion_layer.fusion_conv],
+                                               items_per_set=M)
+        self.bott = self.make_conv("bottleneck_reduce", model.bottleneck_reduce)
+        self.pre, self.dec = [], []
+        for j, st in enumerate(model.decoder_stages):
+            if not hasattr(st.upsample, "preconv"):
+                raise NotImplementedError("decoder stage without preconv (in_channels == out_channels)")
+            self.pre.append(self.make_conv(f"decoder_stages.{j}.upsample.preconv", st.upsample.preconv))
+            self.dec.append(build_residual_unit(self, f"decoder_stages.{j}.conv", st.conv))
+        self.final = self.make_conv("final_conv", model.final_conv)
+        self.nstage = len(self.dec)
+
+    # ---------------------------------------------------------------- input
+    def stage_input(self, x: torch.Tensor) -> torch.Tensor:
+        """x [n, M, D, H, W] -> the channels-last volume (decoder skip: the mean over modalities) AND the family batch
+        [n * M, D, H, W, 1] the encoders read (one one-channel item per (volume, modality))."""
+        x_cl = super().stage_input(x)
+        n, M, D, H, W = x.shape
+        xm = self.pool.cl("xm", n * M, D, H, W, 1, ldc=4, zero=True)
+        ops.to_cl(x.contiguous().view(n * M, 1, D, H, W), out=xm)
+        return x_cl
+
+    @staticmethod
+    def _member(t: torch.Tensor, M: int, m: int) -> torch.Tensor:
+        """[n * M, ...] family batch -> the [n, ...] view of member m (batch stride M items)."""
+        return t.view(t.shape[0] // M, M, *t.shape[1:])[:, m]
+
+    # ---------------------------------------------------------------- forward
+    def forward_cl(self, x_cl: torch.Tensor, present: Optional[Sequence[bool]] = None) -> torch.Tensor:
+        n, D, H, W, M = x_cl.shape
+        if M != self.M:
+            raise ValueError(f"model has {self.M} modality encoders but the input has {M} channels "
+                             "(reference: zip() would silently truncate, unet_multimodal_midfusion.py:214)")
+        f = 2 ** (len(self.channels) - 1)
+        if D % f or H % f or W % f:
+            raise ValueError(f"input extent {(D, H, W)} is not divisible by {f}")
+        keep = [m for m in range(M) if present is None or present[m]]
+        if not keep:
+            raise ValueError("at least one modality must be present")
+        K = len(keep)
+        c, pool = self.channels, self.pool
+        nlev = len(c)
+        dims = [(D, H, W)]
+        for i in range(nlev - 1):
+            d, h, w = dims[-1]
+            dims.append((d // 2, h // 2, w // 2))
+        bd = dims[nlev - 1]
+        mem = lambda t, m: self._member(t, M, m)
+        xm = pool.cl("xm", n * M, D, H, W, 1, ldc=4, zero=True)          # filled by stage_input
+        self.state = dict(n=n, dims=dims, keep=keep, x=x_cl)
+        # encoders: every layer ONE launch sequence over the n * M (volume, modality) items -------------------
+        skips: List[torch.Tensor] = []
+        catf = pool.cl("catf", n * M, *bd, 2 * c[-1])
+        cur = xm
+        for i in range(nlev - 1):
+            out = pool.cl(("skip", i), n * M, *dims[i + 1], c[i])
+            self.encf[i].fwd(cur, None, out)
+            skips.append(out)
+            cur = out
+        self.encf[nlev - 1].fwd(cur, None, catf[..., c[-1]:])
+        # fusion -----------------------------------------------------------------------------------------------
+        shared = pool.cl("shared", n, *bd, c[-1])
+        ops.lincomb([mem(catf, m)[..., c[-1]:] for m in keep], [1.0 / K] * K, shared)
+        for m in range(M):
+            ops.lincomb([shared], [1.0], mem(catf, m)[..., :c[-1]])
+        y, nl = self.fusion.fwd(catf, None)                               # shared weights: one set per volume, M items each
+        fused = pool.cl("fused", n * M, *bd, c[-1])
+        ops.combine(y, nl, catf[..., :c[-1]], None, fused)                # shared + relu(norm(conv(cat[shared, feat_m])))
+        bcat = pool.cl("bcat", n, *bd, M * c[-1])
+        for m in range(M):
+            src = mem(fused, m) if m in keep else shared                  # an absent branch feeds the shared mean
+            ops.lincomb([src], [1.0], bcat[..., m * c[-1]:(m + 1) * c[-1]])
+        xdec = pool.cl(("xdec", -1), n, *bd, c[-1])
+        self.bott.op.forward(bcat, None, None, xdec)
+        # decoder ----------------------------------------------------------------------------------------------
+        skip_src = [2, 1, 0, None]                     # fused_skips[2], [1], [0], input mean
+        cur = xdec
+        self.cats = []
+        for j in range(self.nstage):
+            cin, cout = c[nlev - 1 - j], c[nlev - 2 - j]
+            lo, hi = dims[nlev - 1 - j], dims[nlev - 2 - j]
+            p = pool.cl(("pre", j), n, *lo, cout)
+            self.pre[j].op.forward(cur, None, self.pre[j].bias_data(), p)
+            sc = c[skip_src[j]] if skip_src[j] is not None else 1
+            cat = pool.cl(("dcat_in", j), n, *hi, cout + sc, ldc=(cout + sc + 3) // 4 * 4)
+            ops.upsample2x_fwd(p, cat[..., :cout])
+            if skip_src[j] is not None:
+                ops.lincomb([mem(skips[skip_src[j]], m) for m in keep], [1.0 / K] * K, cat[..., cout:])
+            else:
+                ops.lincomb([x_cl[..., m:m + 1] for m in keep], [1.0 / K] * K, cat[..., cout:])
+            out = pool.cl(("xdec", j), n, *hi, cout)
+            self.dec[j].fwd(cat, None, out)
+            self.cats.append((cur, p, cat))
+            cur = out
+        logits = pool.cl("logits", n, D, H, W, self.out_channels, ldc=(self.out_channels + 3) // 4 * 4)
+        self.final.op.forward(cur, None, self.final.bias_data(), logits)
+        self.state.update(catf=catf, shared=shared, bcat=bcat, xdec=xdec, last=cur, skips=skips, fused=fused)
+        return logits
+
+    # ---------------------------------------------------------------- auxiliary outputs
+    _global_mean = DeepFusionLoopRuntime._global_mean
+    domain_logits = DeepFusionLoopRuntime.domain_logits
+
+    def global_features(self):
+        """(specific_globals_flat: list of M [B, C_b], shared global [B, C_b]) of the last forward."""
+        st, cb, M = self.state, self.channels[-1], self.M
+        spec_all = self._global_mean("spec", st["catf"][..., cb:]).clone()          # [n * M, C_b], item v * M + m
+        n = spec_all.shape[0] // M
+        spec = [spec_all.view(n, M, cb)[:, m].contiguous() for m in range(M)]
+        shared = self._global_mean("sharedg", st["shared"]).clone()
+        return spec, shared
+
+    # ---------------------------------------------------------------- backward
+    def backward_cl(self, dlogits: torch.Tensor) -> None:
+        st, pool, c = self.state, self.pool, self.channels
+        n, dims, keep = st["n"], st["dims"], st["keep"]
+        K, M, nlev = len(keep), self.M, len(c)
+        mem = lambda t, m: self._member(t, M, m)
+        last = st["last"]
+        self.final.wgrad(last, None, dlogits)
+        d = pool.cl(("dxdec", self.nstage - 1), *last.shape)
+        self.final.op.dgrad(dlogits, d)
+        dskips = {}
+        for j in range(self.nstage - 1, -1, -1):
+            src, p, cat = self.cats[j]
+            cout = p.shape[-1]
+            dcat = pool.cl(("dcat", j), *cat.shape[:4], cat.shape[-1], ldc=(cat.shape[-1] + 3) // 4 * 4)
+            self.dec[j].bwd(d, dcat, accumulate=False, need_dx=True)
+            dskips[j] = dcat[..., cout:]
+            dp = pool.cl(("dpre", j), *p.shape)
+            ops.upsample2x_bwd(dcat[..., :cout], dp)
+            self.pre[j].wgrad(src, None, dp)
+            d = pool.cl(("dxdec", j - 1), *src.shape)
+            self.pre[j].op.dgrad(dp, d)
+        bcat = st["bcat"]
+        self.bott.wgrad(bcat, None, d)
+        dbcat = pool.cl("dbcat", *bcat.shape)
+        self.bott.op.dgrad(d, dbcat)
+        # fusion: fused_m = shared + T(conv(cat[shared, feat_m])); absent members get a ZERO output gradient
+        fused = st["fused"]
+        dfused = pool.cl("dfused", *fused.shape)
+        for m in range(M):
+            ops.lincomb([dbcat[..., m * c[-1]:(m + 1) * c[-1]]], [1.0 if m in keep else 0.0], mem(dfused, m))
+        dcatf = pool.cl("dcatf", *st["catf"].shape)
+        self.fusion.bwd(dfused, dcatf, accumulate=False, need_dx=True)
+        terms = []
+        for m in keep:
+            terms += [dbcat[..., m * c[-1]:(m + 1) * c[-1]], mem(dcatf, m)[..., :c[-1]]]
+        for m in range(M):
+            if m not in keep:
+                terms.append(dbcat[..., m * c[-1]:(m + 1) * c[-1]])
+        dshared = pool.cl("dshared", *st["shared"].shape)
+        for k0 in range(0, len(terms), 8):
+            chunk = terms[k0:k0 + 8]
+            ops.lincomb(chunk, [1.0] * len(chunk), dshared, accumulate=k0 > 0)
+        for m in keep:
+            ops.lincomb([dshared], [1.0 / K], mem(dcatf, m)[..., c[-1]:], accumulate=True)
+        # encoders: the family backward, every layer one launch sequence over the n * M items
+        skip_src = [2, 1, 0, None]
+        dout = dcatf[..., c[-1]:]
+        for i in range(nlev - 1, -1, -1):
+            if i == 0:
+                self.encf[0].bwd(dout, None, need_dx=False)
+                break
+            dx = pool.cl(("dskip", i - 1), *st["skips"][i - 1].shape)
+            stage = skip_src.index(i - 1) if (i - 1) in skip_src else None
+            if stage is not None:
+                for m in range(M):
+                    ops.lincomb([dskips[stage]], [1.0 / K if m in keep else 0.0], mem(dx, m))
+                self.encf[i].bwd(dout, dx, accumulate=True, need_dx=True)
+            else:
+                self.encf[i].bwd(dout, dx, accumulate=False, need_dx=True)
+            dout = dx
+
+
+def _parameter_free_norm(norm) -> bool:
+    name = norm[0] if isinstance(norm, (tuple, list)) else norm
+    args = norm[1] if isinstance(norm, (tuple, list)) and len(norm) > 1 else {}
+    return str(name).upper() == "INSTANCE" and not bool((args or {}).get("affine", False))
+
+
 @register_model("unet_multimodal_deepfusion")
 @register_model("unet_multimodal_midfusion")
 class MultimodalUNetDeepFusion(HipSegModel):
-    runtime_cls = DeepFusionRuntime
+    def runtime_cls(self, model, device):
+        """Encoders as one launch family for the shipped parameter-free norms; the modality loop otherwise."""
+        return (DeepFusionRuntime if _parameter_free_norm(self.norm) else DeepFusionLoopRuntime)(model, device)
 
     def __init__(self, cfg: Dict[str, Any]):
         super().__init__()
@@ -276,6 +487,7 @@ class MultimodalUNetDeepFusion(HipSegModel):
         nru = int(get_config(cfg, "num_res_units", 2))
         act = get_config(cfg, "act", "RELU")
         norm = get_config(cfg, "norm", "INSTANCE")
+        self.norm = norm
         dropout = float(get_config(cfg, "dropout", 0.0))
         if len(self.channels) != 5 or strides != [2, 2, 2, 2]:
             raise NotImplementedError("deep-fusion decoder is wired for 5 channel levels and strides [2,2,2,2] "

@@ -40,6 +40,7 @@ class Workspace:
 
     _buffers: Dict[Tuple[int, int, int], torch.Tensor] = {}
     _retired: list = []     # superseded buffers, kept alive for the graphs that reference them
+    captured: set = set()   # (device index, lane) pairs on which a hipGraph has been captured (the plugin records them)
     min_bytes = 1 << 20     # first allocation of a slot (tests lower it to provoke growth with small shapes)
     frozen = False
     slot = 0        # 0: main launch sequence; 1..: the side streams of the weight gradients (engine.ConvLayer.wgrad)
@@ -55,9 +56,12 @@ class Workspace:
         if buf is None or buf.numel() < nbytes:
             if cls.frozen:
                 raise MmttaError("workspace would have to grow during graph capture; run one eager warm-up step first")
-            if buf is not None:
-                cls._retired.append(buf)
-            buf = torch.empty(max(nbytes, cls.min_bytes), dtype=torch.uint8, device=device)
+            if buf is not None and (idx, cls.lane) in cls.captured:
+                cls._retired.append(buf)        # a captured graph may replay with the old address: keep the block alive
+            # grow geometrically: a run over volumes of many sizes retires O(log) buffers, not one per new size; a buffer no
+            # graph can reference is simply dropped (the allocator reuses it)
+            grown = 0 if buf is None else buf.numel() + buf.numel() // 2
+            buf = torch.empty(max(nbytes, grown, cls.min_bytes), dtype=torch.uint8, device=device)
             cls._buffers[key] = buf
         return buf
 
@@ -328,8 +332,8 @@ class ConvOp:
         self.need_dgrad = True
         # per-item parameter sets (None: one set for the whole batch).  `sets_ctl.use_sets` (the owning runtime) switches
         # them on for the launches of a volume group and off for the plain batched forward of the nn.Module facade
-        self.sets_fwd: Optional[ParamSets] = None
-        self.sets_dgrad: Optional[ParamSets] = None
+        self.sets_grouped: Optional[Tuple[ParamSets, ParamSets]] = None      # (forward image, input-gradient image)
+        self.sets_plain: Optional[Tuple[ParamSets, ParamSets]] = None        # a family of modules inside ONE weight set
         self.sets_ctl = None
 
     def set_param_sets(self, items_per_set: int, inner: int, weight_outer: int, weight_inner: int, bias_outer: int,
@@ -338,14 +342,20 @@ class ConvOp:
         the packed images of the op are laid out [outer][inner]."""
         if self.n_sets % inner:
             raise MmttaError(f"{self.n_sets} packed images cannot hold families of {inner} sets")
-        mk = lambda nb: ParamSets(int(items_per_set), int(inner), nb * int(inner), nb, int(weight_outer), int(weight_inner),
-                                  int(bias_outer), int(bias_inner))
-        self.sets_fwd, self.sets_dgrad, self.sets_ctl = mk(self.nb_fwd), mk(self.nb_dgrad), ctl
+        mk = lambda nb, outer: ParamSets(int(items_per_set), int(inner), nb * int(inner) * outer, nb, int(weight_outer) * outer,
+                                         int(weight_inner), int(bias_outer) * outer, int(bias_inner))
+        self.sets_grouped = (mk(self.nb_fwd, 1), mk(self.nb_dgrad, 1))
+        # without a volume group (the nn.Module facade: one weight set for the whole batch) a family of modules - the M
+        # modality encoders as the batch items of one launch - still selects its member's weights: outer strides 0
+        self.sets_plain = (mk(self.nb_fwd, 0), mk(self.nb_dgrad, 0)) if inner > 1 else None
+        self.sets_ctl = ctl
 
     def _sets(self, desc) -> Optional[ParamSets]:
-        if self.sets_ctl is None or not getattr(self.sets_ctl, "use_sets", False):
+        grouped = self.sets_ctl is not None and getattr(self.sets_ctl, "use_sets", False)
+        pair = self.sets_grouped if grouped else self.sets_plain
+        if pair is None:
             return None
-        return self.sets_dgrad if int(desc.op) in (CONV_DGRAD, CONVT_DGRAD) else self.sets_fwd
+        return pair[1] if int(desc.op) in (CONV_DGRAD, CONVT_DGRAD) else pair[0]
 
     def packed_image(self, dgrad: bool, index: int) -> torch.Tensor:
         """The packed image of parameter set ``index`` (a view)."""
@@ -721,7 +731,7 @@ _DCE_SCRATCH: Dict[Tuple, torch.Tensor] = {}     # block partials of dice_ce_sum
 
 
 def dice_ce_sums(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Optional[torch.Tensor], squared_pred: bool,
-                 out: torch.Tensor, logits_channels_last: bool = True) -> None:
+                 out: torch.Tensor, logits_channels_last: bool = True, softmax: bool = False) -> None:
     tz = _desc_any(logits, logits_channels_last)
     tl = desc_ncdhw(label_ncdhw)
     lib = _lib.load()
@@ -732,19 +742,19 @@ def dice_ce_sums(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Option
     scratch = _DCE_SCRATCH.get(key)
     if scratch is None:
         scratch = _DCE_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=logits.device)
-    check(lib.mmtta_dice_ce_sums(C.byref(tz), C.byref(tl), ptr(weight), 1 if squared_pred else 0, ptr(out), ptr(scratch),
-                                 stream_ptr()), "dice_ce_sums")
+    check(lib.mmtta_dice_ce_sums(C.byref(tz), C.byref(tl), ptr(weight), 1 if squared_pred else 0, 1 if softmax else 0, ptr(out),
+                                 ptr(scratch), stream_ptr()), "dice_ce_sums")
 
 
 def dice_ce_grad(logits: torch.Tensor, label_ncdhw: torch.Tensor, weight: Optional[torch.Tensor], squared_pred: bool,
                  jaccard: bool, include_background: bool, lambda_dice: float, lambda_ce: float, sums: torch.Tensor,
                  dlogits: torch.Tensor, logits_channels_last: bool = True, smooth_nr: float = 1e-5,
-                 smooth_dr: float = 1e-5) -> None:
+                 smooth_dr: float = 1e-5, softmax: bool = False) -> None:
     """d DiceCE / d logits from the device-resident sums of ``dice_ce_sums`` (same layouts as there)."""
     tz = _desc_any(logits, logits_channels_last)
     tg = _desc_any(dlogits, logits_channels_last)
     tl = desc_ncdhw(label_ncdhw)
-    check(_lib.load().mmtta_dice_ce_grad(C.byref(tz), C.byref(tl), ptr(weight), 1 if squared_pred else 0,
+    check(_lib.load().mmtta_dice_ce_grad(C.byref(tz), C.byref(tl), ptr(weight), 1 if squared_pred else 0, 1 if softmax else 0,
                                          1 if jaccard else 0, 1 if include_background else 0, float(lambda_dice),
                                          float(lambda_ce), float(smooth_nr), float(smooth_dr), ptr(sums), C.byref(tg),
                                          stream_ptr()), "dice_ce_grad")

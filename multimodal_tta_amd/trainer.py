@@ -7,7 +7,9 @@ backward and the optimizer are the ones the adaptation loop uses; no autograd gr
 are the reference TRAINER's (``training.criterion.{lambda_dice,lambda_ce,include_background,squared_pred,jaccard,
 ce_weight}`` with ``include_background`` defaulting to False, reference seg_trainer.py:33-48,59-79; the evaluator
 reads ``weight`` and defaults ``include_background`` to True instead, reference seg_eval.py:80,201 - that asymmetry
-is the reference's and is mirrored); ``sigmoid: true`` heads only (every shipped config).
+is the reference's and is mirrored).  Both heads of the reference's switch (:41-54): ``sigmoid: true`` (multilabel
+region masks, every shipped config) and ``softmax: true`` (Dice on softmax probabilities; labels are one-hot /
+probability maps [B,R,...], or class indices [B,1,...] with ``to_onehot_y``, the reference's default for softmax heads).
 """
 from __future__ import annotations
 
@@ -30,9 +32,16 @@ class SupervisedSegStep(EntropyMinimizationTTA):
 
     def __init__(self, config: Any = None):
         super().__init__(config)
+        self.group = 1          # a training batch shares ONE weight set (method.group is the adaptation plugin's: one replica per volume)
         crit = get_config(as_cfg(config), "training.criterion", {}) or {}
-        if not bool(get_config(crit, "sigmoid", True)) or bool(get_config(crit, "softmax", False)):
-            raise NotImplementedError("seg_supervised_step implements the sigmoid (multilabel) DiceCE of the shipped configs")
+        # mode switches exactly as the reference reads them (seg_trainer.py:41-54)
+        self.softmax = bool(get_config(crit, "softmax", False))
+        self.sigmoid = bool(get_config(crit, "sigmoid", not self.softmax))
+        self.to_onehot_y = bool(get_config(crit, "to_onehot_y", self.softmax))
+        if self.softmax and self.sigmoid:
+            raise ValueError("[SegTrainer] Invalid config: softmax=True and sigmoid=True cannot both be True.")
+        if (not self.softmax) and (not self.sigmoid):
+            raise ValueError("[SegTrainer] Invalid config: both softmax and sigmoid are False. Please set one True.")
         self.include_background = bool(get_config(crit, "include_background", False))       # seg_trainer.py:33
         self.squared_pred = bool(get_config(crit, "squared_pred", False))
         self.jaccard = bool(get_config(crit, "jaccard", False))
@@ -71,6 +80,12 @@ class SupervisedSegStep(EntropyMinimizationTTA):
         y = batch["label"].to(dev).float().contiguous()
         if y.ndim == 4:
             y = y.unsqueeze(0).expand(x.size(0), -1, -1, -1, -1).contiguous()
+        if self.to_onehot_y and y.shape[1] == 1 and self.rt.out_channels > 1:
+            # class-index labels [B,1,...] -> one-hot [B,R,...] (monai to_onehot_y).  With class weights monai's CE term then
+            # takes the index-target form, whose 'mean' divides by the summed weights of the targets - not built
+            if self.ce_weight is not None:
+                raise NotImplementedError("training.criterion.to_onehot_y with ce_weight (index-target weighted mean)")
+            y = torch.nn.functional.one_hot(y[:, 0].long(), self.rt.out_channels).permute(0, 4, 1, 2, 3).float().contiguous()
         ops.Workspace.lane = self.lane
         rt.training = True
         rt.pack_all()
@@ -83,10 +98,10 @@ class SupervisedSegStep(EntropyMinimizationTTA):
                 raise ValueError(f"criterion.ce_weight has {len(self.ce_weight)} entries for {r} channels")
             self._w_dev = torch.tensor(self.ce_weight, dtype=torch.float32, device=dev)
         sums = rt.pool.flat("dce_sums", n * (r * 3 + 1), dtype=torch.float64)
-        ops.dice_ce_sums(logits, y, self._w_dev, self.squared_pred, sums, logits_channels_last=True)
+        ops.dice_ce_sums(logits, y, self._w_dev, self.squared_pred, sums, logits_channels_last=True, softmax=self.softmax)
         dlogits = rt.pool.cl("dlogits", n, d, h, w, r, ldc=(r + 3) // 4 * 4)
         ops.dice_ce_grad(logits, y, self._w_dev, self.squared_pred, self.jaccard, self.include_background,
-                         self.lambda_dice, self.lambda_ce, sums, dlogits, logits_channels_last=True)
+                         self.lambda_dice, self.lambda_ce, sums, dlogits, logits_channels_last=True, softmax=self.softmax)
         if ar.n_train > 0:
             rt.run_backward(dlogits)
             self.optimizer_step()

@@ -110,7 +110,8 @@ class EntropyMinimizationTTA:
             lr=float(get_config(oc, "lr", get_config(tr, "learning_rate", 1e-3))),
             beta1=float(betas[0]), beta2=float(betas[1]),
             eps=float(get_config(oc, "eps", 1e-8)),
-            # torch defaults when the block names none: Adam / SGD 0, AdamW 1e-2
+            # the reference's parameter groups always carry a weight decay (`optimizers.<name>.weight_decay`, else
+            # `training.weight_decay`, else 0), so torch's own AdamW default of 1e-2 never applies
             weight_decay=float(get_config(oc, "weight_decay", get_config(tr, "weight_decay", 0.0))),
             momentum=float(get_config(oc, "momentum", get_config(tr, "momentum", 0.0))) if opt_name == "sgd" else 0.0,
             dampening=float(get_config(oc, "dampening", 0.0)) if opt_name == "sgd" else 0.0,
@@ -227,6 +228,8 @@ class EntropyMinimizationTTA:
             torch.cuda.synchronize()
             try:
                 ops.Workspace.frozen = True
+                ops.Workspace.captured.add((x_cl.device.index if x_cl.device.index is not None else torch.cuda.current_device(),
+                                            self.lane))
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=work):
                     self._step_launches(x_cl, present)

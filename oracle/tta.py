@@ -13,7 +13,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
 
-from .adam import build_adam, build_optimizer
+from .adam import build_optimizer
 from .losses import entropy_loss
 
 
@@ -73,10 +73,10 @@ def adapt_volume(
         if id(p) not in chosen and p.requires_grad:
             p.requires_grad_(False)
             frozen.append(p)
-    # `training.optimizer` selects the class through the reference's factory; configs that name none keep Adam (what
-    # every caller of this oracle before the factory existed got)
-    has_name = isinstance(train_cfg, dict) and "optimizer" in train_cfg or hasattr(train_cfg, "optimizer")
-    opt = (build_optimizer(named, train_cfg) if has_name else build_adam(named, train_cfg)) if named else None
+    # the reference's factory, unconditionally: `training.optimizer` selects the class and a config that names none gets the
+    # factory's own default (sgd, reference src/core/experiment_manager.py:199-210) - the same default the adaptation plugin
+    # applies, so oracle and product can never adapt with different optimizers
+    opt = build_optimizer(named, train_cfg) if named else None
     gen = torch.Generator().manual_seed(int(moddrop_seed)) if moddrop_p > 0.0 else None
     C = x.shape[1]
     losses: List[float] = []

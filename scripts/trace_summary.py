@@ -32,7 +32,7 @@ def rows(path: str):
                 yield r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 
 
-def main(path: str) -> None:
+def main(path: str, as_json: bool = False) -> None:
     tot = defaultdict(lambda: [0, 0])
     t_min, t_max = None, None
     for name, s, e in rows(path):
@@ -42,6 +42,11 @@ def main(path: str) -> None:
         t_min = s if t_min is None else min(t_min, s)
         t_max = e if t_max is None else max(t_max, e)
     busy = sum(v[1] for v in tot.values())
+    if as_json:      # per-kernel totals for bench.py's roofline block (profiles/trace_avg_us.json)
+        import json
+        print(json.dumps({"source": path, "kernels": {name: {"calls": n, "total_us": ns / 1e3, "avg_us": ns / n / 1e3}
+                                                      for name, (n, ns) in sorted(tot.items())}}, indent=1))
+        return
     print(f"kernels: {sum(v[0] for v in tot.values())}   GPU busy: {busy / 1e6:.2f} ms   "
           f"first start -> last end: {(t_max - t_min) / 1e6:.2f} ms\n")
     print("| kernel | calls | total ms | avg us | share |")
@@ -51,4 +56,4 @@ def main(path: str) -> None:
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main([a for a in sys.argv[1:] if a != "--json"][0], "--json" in sys.argv)

@@ -89,7 +89,8 @@ def model_fixture(name, cfg, shape, seed=42):
     model.train()
     logits = model(x)
     loss = oracle.entropy_loss(logits)
-    train_cfg = {"optimizers": {"adam": {"lr": 1e-3, "weight_decay": 5e-4, "betas": [0.9, 0.9999], "eps": 1e-8}},
+    train_cfg = {"optimizer": "adam",      # named explicitly: a config without the key gets the reference factory's sgd
+                 "optimizers": {"adam": {"lr": 1e-3, "weight_decay": 5e-4, "betas": [0.9, 0.9999], "eps": 1e-8}},
                  "param_groups": {"no_decay_keys": ["bias", "bn", "norm", "LayerNorm"], "treat_1d_as_no_decay": True}}
     res = oracle.adapt_volume(model, x, train_cfg, steps=1, episodic=True)
     arrays = {"x": x.numpy(), "logits": logits.detach().numpy(), "loss": np.float32(loss.item()),

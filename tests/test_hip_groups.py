@@ -235,7 +235,7 @@ def test_group_of_volumes_equals_one_volume_at_a_time(model_cfg, shape, precisio
     xs = [volume(i, shape)[0] for i in range(G)]
     outs = {}
     for group in (1, G):
-        cfg = root_cfg(model_cfg, steps=3, lr=1e-3, precision=precision, group=group)
+        cfg = root_cfg(model_cfg, steps=3, lr=1e-3, precision=precision, group=group, tune_volumes=4)      # one launch geometry
         _, hip = build_pair(model_cfg)
         plug = get_plugin("entmin_tta")(cfg).setup(hip, "cuda")
         if group == 1:

@@ -259,6 +259,12 @@ def test_concurrent_lanes_equal_sequential_runs():
           ce_weight=[50.0]), dict(in_channels=2, num_classes=1), (16, 48, 48)),
     # trainer defaults (reference seg_trainer.py:33-48): include_background False, no weight
     (dict(), {}, (32, 32, 32)),
+    # softmax heads (reference seg_trainer.py:41-54, SURVEY A.5 softmax branch): Dice on softmax probabilities, one-hot targets
+    (dict(softmax=True, to_onehot_y=False, include_background=True), {}, (32, 32, 32)),
+    (dict(softmax=True, to_onehot_y=False, lambda_dice=2.0, lambda_ce=0.5, include_background=False, squared_pred=True, jaccard=True,
+          ce_weight=[0.5, 2.0, 1.0]), {}, (32, 32, 32)),
+    # the reference's default for a softmax head: class-index labels [B,1,...] turned one-hot (to_onehot_y)
+    (dict(softmax=True), {}, (32, 32, 32)),
 ])
 def test_supervised_dicece_step_matches_autograd(crit, model_over, shape):
     """The reference's supervised step (reference src/core/trainers/seg_trainer.py:97-145) with the loss gradient
@@ -273,15 +279,25 @@ def test_supervised_dicece_step_matches_autograd(crit, model_over, shape):
     cfg = root_cfg(mcfg, steps=1, lr=1e-3)
     for k in ("weight", "ce_weight", "include_background", "lambda_dice", "lambda_ce", "squared_pred", "jaccard"):
         cfg["training"]["criterion"].pop(k, None)
+    for k in ("softmax", "sigmoid", "to_onehot_y"):
+        cfg["training"]["criterion"].pop(k, None)
     cfg["training"]["criterion"].update(crit)
-    cfg["training"]["criterion"]["sigmoid"] = True
+    softmax = bool(crit.get("softmax", False))
+    if not softmax:
+        cfg["training"]["criterion"]["sigmoid"] = True
     torch.manual_seed(42)
     ref = oracle.UNet(mcfg)
     hip = UNet(mcfg)
     hip.load_state_dict(ref.state_dict())
     x, y = volume(3, shape=shape, C=mcfg["in_channels"], R=mcfg["num_classes"])
+    y_in = y
+    if softmax:
+        # a softmax head partitions the voxels: class = number of nested regions a voxel lies in, capped at R - 1
+        cls = y.sum(dim=1).clamp(max=mcfg["num_classes"] - 1).long()
+        y = torch.nn.functional.one_hot(cls, mcfg["num_classes"]).permute(0, 4, 1, 2, 3).float()
+        y_in = cls.unsqueeze(1).float() if crit.get("to_onehot_y", True) else y
     w = torch.tensor(crit["ce_weight"]) if "ce_weight" in crit else None
-    loss_fn = oracle.DiceCELoss(include_background=crit.get("include_background", False), sigmoid=True,
+    loss_fn = oracle.DiceCELoss(include_background=crit.get("include_background", False), sigmoid=not softmax, softmax=softmax,
                                 squared_pred=crit.get("squared_pred", False), jaccard=crit.get("jaccard", False), weight=w,
                                 lambda_dice=crit.get("lambda_dice", 1.0), lambda_ce=crit.get("lambda_ce", 1.0))
     opt = oracle.build_adam(list(ref.named_parameters()), cfg["training"])
@@ -294,14 +310,19 @@ def test_supervised_dicece_step_matches_autograd(crit, model_over, shape):
         opt.step()
         ref_losses.append(float(loss.item()))
     plug = get_plugin("seg_supervised_step")(cfg).setup(hip, "cuda")
-    hip_losses = [plug.run_step({"image": x, "label": y})["loss"] for _ in range(2)]
+    hip_losses = [plug.run_step({"image": x, "label": y_in})["loss"] for _ in range(2)]
     for a, b in zip(hip_losses, ref_losses):
         assert abs(a - b) <= 2e-4 * abs(b) + 1e-6, (hip_losses, ref_losses)
     ref.eval(); hip.eval()
     with torch.no_grad():
         z_ref, z_hip = ref(x), hip(x.cuda()).cpu()
+    if softmax:
+        # a softmax head is invariant to a shift common to all channels of a voxel: the gradient along that direction is
+        # rounding noise, which Adam turns into +-lr steps whose sign depends on the summation order - the class
+        # probabilities are the observable quantity
+        z_ref, z_hip = torch.softmax(z_ref, dim=1), torch.softmax(z_hip, dim=1)
     err = (z_hip - z_ref).abs().max().item() / z_ref.abs().max().item()
-    assert err < 5e-3, f"logits after two supervised steps: rel err {err:.3e}"
+    assert err < 5e-3, f"{'probabilities' if softmax else 'logits'} after two supervised steps: rel err {err:.3e}"
 
 
 def test_dicece_sums_and_gradient_single_region_bce_pos_weight():
