@@ -70,7 +70,12 @@ def parse():
     ap.add_argument("--group", type=int, default=None,
                     help="volumes adapted TOGETHER as the batch items of one launch sequence, each on its own replica of the "
                          "weights and optimizer state (method.group); lanes x group volumes are in flight per GPU")
+    ap.add_argument("--tune-volumes", type=int, default=None,
+                    help="launch geometry for this many volumes in flight (method.tune_volumes; default lanes x group) - e.g. a "
+                         "one-lane counter run under the headline's geometry")
     ap.add_argument("--side-streams", type=int, default=None, help="side streams for the weight gradients (default: config)")
+    ap.add_argument("--grad-storage", default=None, choices=["bf16", "fp32"],
+                    help="bf16 precision: storage of the wide activation GRADIENTS (default: the method config, bf16)")
     ap.add_argument("--storage", default=None, choices=["bf16", "fp32"],
                     help="bf16 precision: storage of the wide forward activations (default: the method config, bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,6 +99,10 @@ def build_cfg(args):
         ov += [f"method.group={args.group}"]
     if getattr(args, "lanes", None) is not None:
         ov += [f"method.lanes={args.lanes}"]
+    if getattr(args, "tune_volumes", None) is not None:
+        ov += [f"method.tune_volumes={args.tune_volumes}"]
+    if getattr(args, "grad_storage", None):
+        ov += [f"method.grad_storage={args.grad_storage}"]
     if getattr(args, "storage", None) or os.environ.get("MMTTA_STORAGE"):
         ov += [f"method.storage={getattr(args, 'storage', None) or os.environ['MMTTA_STORAGE']}"]
     cfg = compose(overrides=ov)
@@ -354,8 +363,9 @@ def main():
             "tta_steps": args.tta_steps, "volume": [C, *shape], "adapted_params": str(cfg["method"]["params"]),
             "precision": ("bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulate, for forward, input-gradient "
                           "and 27-tap weight-gradient convs; forward activations with >= 32 channels stored as "
-                          f"{getattr(plug, 'storage', None) or 'fp32'}, gradients / statistics / norms / loss / 1x1 and thin "
-                          "weight gradients / optimizer / master weights fp32") if args.precision == "bf16"
+                          f"{getattr(plug, 'storage', None) or 'fp32'}, their gradients as "
+                          f"{'bf16' if getattr(plug.rt, 'grad_bf16', False) else 'fp32'}; statistics / norms / loss / reduced weight "
+                          "gradients / 1x1 and thin weight gradients / optimizer / master weights fp32") if args.precision == "bf16"
             else "fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32)", "weights": "seeded default init (no checkpoint offline)",
             "parallelism": f"{world} rank(s), one per GPU, volumes sharded round-robin, no data-path collective; the "
                            f"per-volume Dice table is merged by one all_gather; per GPU {lanes} lane(s) (own stream = "

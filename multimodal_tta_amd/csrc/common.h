@@ -114,6 +114,25 @@ __device__ __forceinline__ void oct8_f8(const Oct8<true>& o, float (&v)[8]) {
 }
 
 
+// 8 consecutive channels out: two 16-byte stores (fp32) or one (bf16); `base` points at the batch item, offsets in ELEMENTS
+template <bool BF>
+__device__ __forceinline__ void oct8_st(float* base, unsigned eoff, const float (&v)[8]) {
+  if constexpr (BF) {
+    uint4 q;
+    q.x = f32x2_to_bf16x2(v[0], v[1]); q.y = f32x2_to_bf16x2(v[2], v[3]);
+    q.z = f32x2_to_bf16x2(v[4], v[5]); q.w = f32x2_to_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(base) + eoff) = q;
+  } else {
+    *reinterpret_cast<float4*>(base + eoff) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(base + eoff + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+// base pointer of batch item n of a tensor whose elements are 2 (BF) or 4 bytes wide; `sn` in ELEMENTS
+template <bool BF>
+__device__ __forceinline__ const float* item_base(const float* p, long long n, long long sn) {
+  return BF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p) + n * sn) : p + n * sn;
+}
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) - the index is usable as a template argument
 // and an array subscript that never becomes a run-time value (register arrays stay in registers)
 template <int I, int N, class F>

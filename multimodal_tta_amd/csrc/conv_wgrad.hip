@@ -866,26 +866,29 @@ static int launch_wgrad_tr1_t(const WArgs& a, int S, hipStream_t s) {
 }
 
 static int launch_wgrad_tr1(const WArgs& a, int S, hipStream_t s) {
-  MMTTA_CHECK(!(a.g_bf && a.d_bf), MMTTA_ERR_UNSUPPORTED, "wgrad: both operands bf16-stored");
+  if (a.g_bf && a.d_bf) return launch_wgrad_tr1_t<true, true>(a, S, s);      // bf16-stored gradients (method.grad_storage)
   if (a.g_bf) return launch_wgrad_tr1_t<true, false>(a, S, s);
   if (a.d_bf) return launch_wgrad_tr1_t<false, true>(a, S, s);
   return launch_wgrad_tr1_t<false, false>(a, S, s);
 }
 
 // the module input (norm-on-load, possibly bf16-stored) is the gathered operand of a convolution and the dense one of a
-// transposed convolution (stride 2 only); the other operand is a gradient: fp32, read as is
+// transposed convolution (stride 2 only); the other operand is a gradient: read as is, fp32- or (method.grad_storage: bf16,
+// then next to a bf16-stored module input only) bf16-stored
 template <int TZ, int TY, int SI>
 static int launch_wgrad_tr(const WArgs& a, int S, hipStream_t s) {
   MMTTA_CHECK(a.gvec4 && a.dvec4, MMTTA_ERR_INVALID, "wgrad: transposed-read kernel selected for unaligned tensors");
   if (a.convt) {
-    MMTTA_CHECK(!a.g_bf, MMTTA_ERR_UNSUPPORTED, "wgrad: bf16-stored output gradient");
+    MMTTA_CHECK(!a.g_bf || a.d_bf, MMTTA_ERR_UNSUPPORTED, "wgrad: a bf16-stored gradient needs a bf16-stored module input");
     if constexpr (SI == 2) {
+      if (a.g_bf) return launch_wgrad_tr_t<TZ, TY, SI, true, true, true>(a, S, s);
       if (a.d_bf) return launch_wgrad_tr_t<TZ, TY, SI, false, true, true>(a, S, s);
       return launch_wgrad_tr_t<TZ, TY, SI, false, false, true>(a, S, s);
     }
     return MMTTA_ERR_UNSUPPORTED;
   }
-  MMTTA_CHECK(!a.d_bf, MMTTA_ERR_UNSUPPORTED, "wgrad: bf16-stored output gradient");
+  MMTTA_CHECK(!a.d_bf || a.g_bf, MMTTA_ERR_UNSUPPORTED, "wgrad: a bf16-stored gradient needs a bf16-stored module input");
+  if (a.d_bf) return launch_wgrad_tr_t<TZ, TY, SI, true, true, false>(a, S, s);
   if (a.g_bf) return launch_wgrad_tr_t<TZ, TY, SI, true, false, false>(a, S, s);
   return launch_wgrad_tr_t<TZ, TY, SI, false, false, false>(a, S, s);
 }
@@ -1201,6 +1204,7 @@ struct WTArgs {
   float* dbpart;    // [blocks][4] or null
   int ld;
   int B, ips;       // workgroups and batch items per parameter set
+  int BT;           // workgroups of the launch per kz plane (B x sets)
 };
 
 template <int CS, int CB, bool HAS_T>
@@ -1208,7 +1212,14 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
   __shared__ float red[4][9 * CS * CB + CB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int kz = blockIdx.y;
+  // The three kz planes of a unit range read the same dy rows and x rows one plane apart.  As grid rows (blockIdx.y = kz)
+  // they ran as three sweeps far apart in time: 3x the HBM traffic (PMC r03a: 206 MB per volume against 67 MB of tensors).
+  // Now the three workgroups of a range are neighbours in dispatch order ON ONE XCD (ids 8 apart: workgroups are dealt
+  // round-robin over the 8 XCDs), so two of them hit that XCD's L2.
+  const unsigned xcd = blockIdx.x & 7u, q3 = blockIdx.x >> 3;
+  const int kz = (int)(q3 % 3u);
+  const unsigned bv = (q3 / 3u) * 8u + xcd;              // this workgroup's id in a launch of BT workgroups
+  if (bv >= (unsigned)a.BT) return;
   const int chunks = (a.dy.w + 63) / 64;
   const int hp = (a.dy.h + 1) / 2;                     // a wave takes two adjacent rows per step
   const long long units = (long long)a.ips * a.dy.d * hp * chunks;       // of ONE parameter set
@@ -1228,7 +1239,7 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
 #pragma unroll
   for (int i = 0; i < CS; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
   long long ufirst, ulast;
-  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int sx = (int)xcd_contiguous_id(bv, (unsigned)a.BT);
   const int qset = sx / a.B;                            // workgroup sx = workgroup (sx % B) of parameter set (sx / B)
   unit_range(units, sx - qset * a.B, a.B, ufirst, ulast);
   ufirst += (long long)qset * units; ulast += (long long)qset * units;
@@ -1340,7 +1351,7 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WTArgs a) {
 
 template <int CS, bool HAS_T>
 static void launch_tiny_cb(const WTArgs& a, int cb, int blocks, hipStream_t s) {
-  const dim3 grid(blocks, 3), block(256);
+  const dim3 grid(3 * ((blocks + 7) / 8) * 8), block(256);      // (plane, workgroup) pairs, see the kernel's id decode
   switch (cb) {
     case 1: hipLaunchKernelGGL((wgrad_tiny_kernel<CS, 1, HAS_T>), grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL((wgrad_tiny_kernel<CS, 2, HAS_T>), grid, block, 0, s, a); break;
@@ -1442,7 +1453,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.small = false; w.bf16 = false; w.small_is_cd = 0; w.q = w.pb = nullptr; w.q_is_x = false;
   if (!w.convt && d->cin <= 4) { w.small = true; w.q = x; w.pb = dy; w.q_is_x = true; }
   else if (!w.convt && d->cout <= 4 && d->ksize == 1 &&
-           !(d->dtype == MMTTA_BF16 && d->cin >= 16 && wtr_ok(x) && wtr_ok(dy) && !is_bf16(dy) && g_wgrad_vec)) {
+           !(d->dtype == MMTTA_BF16 && d->cin >= 16 && wtr_ok(x) && wtr_ok(dy) && (!is_bf16(dy) || is_bf16(x)) && g_wgrad_vec)) {
     // (in bf16 precision the 1x1x1 streaming kernel below takes these heads too: N padded to 32 costs nothing there)
     w.small = true; w.q = dy; w.pb = x; w.small_is_cd = 1;
   }
@@ -1472,10 +1483,12 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   }
   // bf16 operands: the transposed-read kernel, for operand pairs that admit its 16-byte items; anything else (ragged
   // channel slices, MMTTA_OPT_WGRAD_VECTOR_STAGING = 0) computes on the fp32-operand kernel
-  w.tr = d->dtype == MMTTA_BF16 && w.ntaps == 27 && wtr_ok(w.g) && wtr_ok(w.dn) && !(w.convt && is_bf16(w.g)) &&
-         !(!w.convt && is_bf16(w.dn)) && g_wgrad_vec;
+  // (a gradient may be bf16-stored only next to a bf16-stored module input: x is the gathered operand of a convolution, the
+  // dense one of a transposed convolution)
+  const bool grad_bf_ok = !is_bf16(dy) || is_bf16(x);
+  w.tr = d->dtype == MMTTA_BF16 && w.ntaps == 27 && wtr_ok(w.g) && wtr_ok(w.dn) && grad_bf_ok && g_wgrad_vec;
   w.bf16 = w.tr;
-  w.tr1 = !w.convt && d->dtype == MMTTA_BF16 && w.ntaps == 1 && w.si == 1 && wtr_ok(w.g) && wtr_ok(w.dn) && !is_bf16(w.dn) &&
+  w.tr1 = !w.convt && d->dtype == MMTTA_BF16 && w.ntaps == 1 && w.si == 1 && wtr_ok(w.g) && wtr_ok(w.dn) && grad_bf_ok &&
           g_wgrad_vec;
   if ((w.tr && w.si == 1) || w.tr1) { w.TZ = 4; w.TY = 8; w.TX = 8; }
   else if (w.si == 1) { w.TZ = 4; w.TY = 4; w.TX = 8; }
@@ -1529,7 +1542,7 @@ static int launch_wgrad_t(const WArgs& a, int S, hipStream_t s) {
 
 template <int TZ, int TY, int TX, int NTW>
 static int launch_wgrad(const WArgs& a, int S, hipStream_t s) {
-  MMTTA_CHECK(!(a.g_bf && a.d_bf), MMTTA_ERR_UNSUPPORTED, "wgrad: both operands bf16-stored");
+  if (a.g_bf && a.d_bf) return launch_wgrad_t<TZ, TY, TX, NTW, true, true>(a, S, s);
   if (a.g_bf) return launch_wgrad_t<TZ, TY, TX, NTW, true, false>(a, S, s);
   if (a.d_bf) return launch_wgrad_t<TZ, TY, TX, NTW, false, true>(a, S, s);
   return launch_wgrad_t<TZ, TY, TX, NTW, false, false>(a, S, s);
@@ -1582,7 +1595,7 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
     t.x = tv(x); t.tx = nl(x_norm); t.dy = tv(dy);
     t.part = (float*)workspace; t.ld = 27 * d->cin * d->cout;
     t.dbpart = db != nullptr ? (float*)workspace + w.slab_floats * Q : nullptr;
-    t.B = w.tiny_blocks; t.ips = w.ips;
+    t.B = w.tiny_blocks; t.ips = w.ips; t.BT = w.tiny_blocks * Q;
     if (t.tx.mean != nullptr || t.tx.scale != nullptr) launch_tiny<true>(t, d->cin, d->cout, w.tiny_blocks * Q, s);
     else launch_tiny<false>(t, d->cin, d->cout, w.tiny_blocks * Q, s);
     st = launch_status("wgrad tiny");

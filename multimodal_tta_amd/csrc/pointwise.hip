@@ -47,7 +47,8 @@ struct RedArgs {
 
 // VEC = 4: every thread owns 4 consecutive channels (16-byte loads); VEC = 1: scalar fallback.
 // `regular` tensors (dense voxel order: sh == W*sw, sd == H*sh) are addressed as voxel*sw, no div/mod.
-template <int MODE, int VEC, bool XBF = false>
+// XBF / DBF: storage of x (the activation) and of dout (the gradient: bf16 when method.grad_storage stores gradients so)
+template <int MODE, int VEC, bool XBF = false, bool DBF = false>
 __global__ __launch_bounds__(256) void channel_reduce_kernel(RedArgs a) {
   __shared__ float red[2][VEC][256];
   const int C = a.x.c;
@@ -96,12 +97,12 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(RedArgs a) {
           const float4 t4 = ld4_t<XBF>(a.x.p, ax + c0);               // the pre-norm activation may be bf16-stored
           xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w;
           if (MODE == 1) {
-            const float4 d4 = *reinterpret_cast<const float4*>(a.dout.p + ad + c0);
+            const float4 d4 = ld4_t<DBF>(a.dout.p, ad + c0);
             dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
           }
         } else {
           xv[0] = ld1_t<XBF>(a.x.p, ax + c0);
-          if (MODE == 1) dv[0] = a.dout.p[ad + c0];
+          if (MODE == 1) dv[0] = ld1_t<DBF>(a.dout.p, ad + c0);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -370,25 +371,23 @@ struct Nb8Args {
   const float* mean; const float* rstd; const float* gamma; const float* beta; const float* m1; const float* m2;
 };
 
-template <bool YBF, int IT>
+template <bool YBF, int IT, bool DBF = false>
 __global__ __launch_bounds__(256) void norm_bwd_apply8_kernel(Nb8Args a) {
   const int n = blockIdx.y;
   const unsigned CG = (unsigned)a.C >> 3, nvl = 256u / CG;
   const unsigned cg = threadIdx.x & (CG - 1), vl = threadIdx.x / CG;   // CG is a power of two
   const unsigned c0 = cg * 8;
-  const float* dp = a.dout + (long long)n * a.dsn;
-  const float* yp = YBF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.y) + (long long)n * a.ysn)
-                        : a.y + (long long)n * a.ysn;
-  float* op = a.o + (long long)n * a.osn;
+  const float* dp = item_base<DBF>(a.dout, n, a.dsn);                 // gradient in / out share one storage type (DBF)
+  const float* yp = item_base<YBF>(a.y, n, a.ysn);
+  float* op = const_cast<float*>(item_base<DBF>(a.o, n, a.osn));
   const unsigned v0 = blockIdx.x * (nvl * IT) + vl;
   Oct8<YBF> yr[IT];
-  float4 d0[IT], d1[IT];
+  Oct8<DBF> dr[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const unsigned v = min(v0 + i * nvl, a.dhw - 1);                   // clamped address, masked store
     yr[i] = oct8_ld<YBF>(yp, v * a.ysw + c0, v * a.ysw + c0 + 4);
-    d0[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0);
-    d1[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0 + 4);
+    dr[i] = oct8_ld<DBF>(dp, v * a.dsw + c0, v * a.dsw + c0 + 4);
   }
   float mu[8], rs[8], g[8], bt[8], m1[8], m2[8];
   {
@@ -411,9 +410,9 @@ __global__ __launch_bounds__(256) void norm_bwd_apply8_kernel(Nb8Args a) {
   }
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    float yv[8], ov[8];
+    float yv[8], ov[8], dv[8];
     oct8_f8(yr[i], yv);
-    const float dv[8] = {d0[i].x, d0[i].y, d0[i].z, d0[i].w, d1[i].x, d1[i].y, d1[i].z, d1[i].w};
+    oct8_f8(dr[i], dv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xhat = (yv[j] - mu[j]) * rs[j];
@@ -422,10 +421,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply8_kernel(Nb8Args a) {
       ov[j] = rs[j] * (g[j] * dz - m1[j] - xhat * m2[j]);
     }
     const unsigned v = v0 + i * nvl;
-    if (v < a.dhw) {
-      *reinterpret_cast<float4*>(op + v * a.osw + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-      *reinterpret_cast<float4*>(op + v * a.osw + c0 + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
-    }
+    if (v < a.dhw) oct8_st<DBF>(op, v * a.osw + c0, ov);
   }
 }
 
@@ -444,17 +440,16 @@ struct NbsArgs {
   const float* mean; const float* rstd; const float* gamma; const float* beta;
 };
 
-template <bool YBF>
+template <bool YBF, bool DBF = false>
 __global__ __launch_bounds__(256) void norm_bwd_small_kernel(NbsArgs a) {
   __shared__ float part[2][8][256];
   __shared__ float mm[2][32];
   const int n = blockIdx.y;
   const unsigned cg = threadIdx.x & 3, vl = threadIdx.x >> 2;
   const unsigned c0 = blockIdx.x * 32 + cg * 8;
-  const float* dp = a.dout + (long long)n * a.dsn;
-  const float* yp = YBF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.y) + (long long)n * a.ysn)
-                        : a.y + (long long)n * a.ysn;
-  float* op = a.o + (long long)n * a.osn;
+  const float* dp = item_base<DBF>(a.dout, n, a.dsn);
+  const float* yp = item_base<YBF>(a.y, n, a.ysn);
+  float* op = const_cast<float*>(item_base<DBF>(a.o, n, a.osn));
   float mu[8], rs[8], g[8], bt[8];
   {
     const unsigned pc = (unsigned)n * a.C + c0;
@@ -480,19 +475,18 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(NbsArgs a) {
   for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
   for (unsigned vb = vl; vb < a.dhw; vb += 64 * IT) {
     Oct8<YBF> yr[IT];
-    float4 d0[IT], d1[IT];
+    Oct8<DBF> dr[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const unsigned v = min(vb + 64 * i, a.dhw - 1);
       yr[i] = oct8_ld<YBF>(yp, v * a.ysw + c0, v * a.ysw + c0 + 4);
-      d0[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0);
-      d1[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0 + 4);
+      dr[i] = oct8_ld<DBF>(dp, v * a.dsw + c0, v * a.dsw + c0 + 4);
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      float yv[8];
+      float yv[8], dv[8];
       oct8_f8(yr[i], yv);
-      const float dv[8] = {d0[i].x, d0[i].y, d0[i].z, d0[i].w, d1[i].x, d1[i].y, d1[i].z, d1[i].w};
+      oct8_f8(dr[i], dv);
       const bool live = vb + 64 * i < a.dhw;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -521,19 +515,18 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(NbsArgs a) {
   for (int j = 0; j < 8; ++j) { m1[j] = mm[0][cg * 8 + j]; m2[j] = mm[1][cg * 8 + j]; }
   for (unsigned vb = vl; vb < a.dhw; vb += 64 * IT) {
     Oct8<YBF> yr[IT];
-    float4 d0[IT], d1[IT];
+    Oct8<DBF> dr[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const unsigned v = min(vb + 64 * i, a.dhw - 1);
       yr[i] = oct8_ld<YBF>(yp, v * a.ysw + c0, v * a.ysw + c0 + 4);
-      d0[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0);
-      d1[i] = *reinterpret_cast<const float4*>(dp + v * a.dsw + c0 + 4);
+      dr[i] = oct8_ld<DBF>(dp, v * a.dsw + c0, v * a.dsw + c0 + 4);
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      float yv[8], ov[8];
+      float yv[8], ov[8], dv[8];
       oct8_f8(yr[i], yv);
-      const float dv[8] = {d0[i].x, d0[i].y, d0[i].z, d0[i].w, d1[i].x, d1[i].y, d1[i].z, d1[i].w};
+      oct8_f8(dr[i], dv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xhat = (yv[j] - mu[j]) * rs[j];
@@ -542,10 +535,7 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(NbsArgs a) {
         ov[j] = rs[j] * (g[j] * dz - m1[j] - xhat * m2[j]);
       }
       const unsigned v = vb + 64 * i;
-      if (v < a.dhw) {
-        *reinterpret_cast<float4*>(op + v * a.osw + c0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-        *reinterpret_cast<float4*>(op + v * a.osw + c0 + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
-      }
+      if (v < a.dhw) oct8_st<DBF>(op, v * a.osw + c0, ov);
     }
   }
 }
@@ -829,8 +819,14 @@ int launch_channel_sums(const mmtta_tensor* x, float* part, hipStream_t s) {
   RedArgs a;
   a.x = tv(x); a.dout = tv(x); a.t = nl(nullptr); a.part = part;
   rows_geometry(x, a.rows_per_n, a.vox_per_row);
-  if (vec4_rd(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4>), dim3(x->n * a.rows_per_n), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((channel_reduce_kernel<0, 1>), dim3(x->n * a.rows_per_n), dim3(256), 0, s, a);
+  const dim3 grid(x->n * a.rows_per_n);
+  if (is_bf16(x)) {
+    if (vec4_rd(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((channel_reduce_kernel<0, 1, true>), grid, dim3(256), 0, s, a);
+  } else {
+    if (vec4_rd(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((channel_reduce_kernel<0, 1>), grid, dim3(256), 0, s, a);
+  }
   return launch_status("channel sums");
 }
 
@@ -949,8 +945,8 @@ extern "C" int mmtta_combine(const mmtta_tensor* a, const mmtta_norm_on_load* ta
 
 extern "C" int mmtta_norm_bwd_reduce(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
                                      float* part, void* stream) {
-  MMTTA_CHECK(dout == nullptr || dout->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_norm_bwd_reduce: `dout` must be fp32-stored");
   MMTTA_CHECK(dout && y && t && part && dout->ptr && y->ptr && t->mean && t->rstd, MMTTA_ERR_INVALID, "norm bwd reduce: null argument");
+  MMTTA_CHECK(!is_bf16(dout) || is_bf16(y), MMTTA_ERR_UNSUPPORTED, "norm bwd reduce: a bf16-stored gradient needs a bf16-stored activation");
   MMTTA_CHECK(same_shape(dout, y) && is_cl(dout) && is_cl(y), MMTTA_ERR_INVALID, "norm bwd reduce: shape/layout mismatch");
   RedArgs a;
   a.x = tv(y); a.dout = tv(dout); a.t = nl(t); a.part = part;
@@ -958,7 +954,10 @@ extern "C" int mmtta_norm_bwd_reduce(const mmtta_tensor* dout, const mmtta_tenso
   const dim3 grid(y->n * a.rows_per_n);
   hipStream_t s = (hipStream_t)stream;
   const bool v4 = vec4_rd(y) && vec4_rd(dout);
-  if (is_bf16(y)) {
+  if (is_bf16(dout)) {
+    if (v4) hipLaunchKernelGGL((channel_reduce_kernel<1, 4, true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((channel_reduce_kernel<1, 1, true, true>), grid, dim3(256), 0, s, a);
+  } else if (is_bf16(y)) {
     if (v4) hipLaunchKernelGGL((channel_reduce_kernel<1, 4, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((channel_reduce_kernel<1, 1, true>), grid, dim3(256), 0, s, a);
   } else {
@@ -993,9 +992,10 @@ extern "C" int mmtta_norm_bwd_finalize(int kind, int groups, const float* part, 
 
 extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
                                     const float* m1, const float* m2, const mmtta_tensor* dy, void* stream) {
-  MMTTA_CHECK(dout == nullptr || dout->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_norm_bwd_apply: `dout` must be fp32-stored");
-  MMTTA_CHECK(dy == nullptr || dy->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_norm_bwd_apply: `dy` must be fp32-stored");
   MMTTA_CHECK(dout && y && t && dy && m1 && m2 && t->mean && t->rstd, MMTTA_ERR_INVALID, "norm bwd apply: null argument");
+  MMTTA_CHECK(dout->dtype == dy->dtype && (!is_bf16(dout) || is_bf16(y)), MMTTA_ERR_UNSUPPORTED,
+              "norm bwd apply: `dout` and `dy` share one storage type (bf16 only next to a bf16-stored activation)");
+  const bool dbf = is_bf16(dout);
   MMTTA_CHECK(same_shape(dout, y) && same_shape(dy, y), MMTTA_ERR_INVALID, "norm bwd apply: shape mismatch");
   MMTTA_CHECK(is_cl(dout) && is_cl(y) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "norm bwd apply: channels-last only");
   EwArgs e;
@@ -1013,7 +1013,8 @@ extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor
       return ((uintptr_t)t->ptr) % 16 == 0 && t->sw % per == 0 && t->sn % per == 0;
     };
     const bool pow2 = C >= 8 && C <= 2048 && (C & (C - 1)) == 0;
-    const bool ok8 = v4 && pow2 && dense(dout) && dense(y) && dense(dy) && al(dout, 4) && al(dy, 4) && al(y, is_bf16(y) ? 8 : 4) &&
+    const bool ok8 = v4 && pow2 && dense(dout) && dense(y) && dense(dy) && al(dout, dbf ? 8 : 4) && al(dy, dbf ? 8 : 4) &&
+                     al(y, is_bf16(y) ? 8 : 4) &&
                      ((uintptr_t)t->mean % 16 == 0) && ((uintptr_t)t->rstd % 16 == 0) && ((uintptr_t)m1 % 16 == 0) &&
                      ((uintptr_t)m2 % 16 == 0) && (!t->gamma || (uintptr_t)t->gamma % 16 == 0) &&
                      (!t->beta || (uintptr_t)t->beta % 16 == 0) && dhw * std::max(std::max(dout->sw, y->sw), dy->sw) < (1LL << 31);
@@ -1028,7 +1029,10 @@ extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor
       const bool four = dhw / (nvl * 4) >= 1024;
       const long long per = nvl * (four ? 4 : 2);
       const dim3 g8((unsigned)((dhw + per - 1) / per), (unsigned)y->n);
-      if (is_bf16(y)) {
+      if (dbf) {
+        if (four) hipLaunchKernelGGL((norm_bwd_apply8_kernel<true, 4, true>), g8, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((norm_bwd_apply8_kernel<true, 2, true>), g8, dim3(256), 0, s, q);
+      } else if (is_bf16(y)) {
         if (four) hipLaunchKernelGGL((norm_bwd_apply8_kernel<true, 4>), g8, dim3(256), 0, s, q);
         else hipLaunchKernelGGL((norm_bwd_apply8_kernel<true, 2>), g8, dim3(256), 0, s, q);
       } else {
@@ -1038,7 +1042,10 @@ extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor
       return launch_status("norm bwd apply");
     }
   }
-  if (is_bf16(y)) {
+  if (dbf) {
+    if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4, true, true, true>), grid, dim3(256), 0, s, e);
+    else hipLaunchKernelGGL((elementwise_kernel<1, 1, true, true, true>), grid, dim3(256), 0, s, e);
+  } else if (is_bf16(y)) {
     if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4, false, true, false>), grid, dim3(256), 0, s, e);
     else hipLaunchKernelGGL((elementwise_kernel<1, 1, false, true, false>), grid, dim3(256), 0, s, e);
   } else {
@@ -1052,14 +1059,14 @@ extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor
 // groups of 32, 16-byte aligned octets
 static bool nbs_ok(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t, const mmtta_tensor* dy) {
   if (!dout || !y || !t || !dy || !t->mean || !t->rstd) return false;
-  if (dout->dtype != MMTTA_F32 || dy->dtype != MMTTA_F32) return false;
+  if (dout->dtype != dy->dtype || (is_bf16(dout) && !is_bf16(y))) return false;
   if (!same_shape(dout, y) || !same_shape(dy, y) || !is_cl(dout) || !is_cl(y) || !is_cl(dy)) return false;
   const long long dhw = (long long)y->d * y->h * y->w;
   auto dense = [](const mmtta_tensor* x) { return x->sh == (int64_t)x->w * x->sw && x->sd == (int64_t)x->h * x->sh; };
   auto al = [](const mmtta_tensor* x, int per) { return ((uintptr_t)x->ptr) % 16 == 0 && x->sw % per == 0 && x->sn % per == 0; };
   auto a16 = [](const void* p) { return p == nullptr || ((uintptr_t)p) % 16 == 0; };
-  return y->c % 32 == 0 && dhw >= 1 && dhw <= 4096 && dense(dout) && dense(y) && dense(dy) && al(dout, 4) && al(dy, 4) &&
-         al(y, is_bf16(y) ? 8 : 4) && a16(t->mean) && a16(t->rstd) && a16(t->gamma) && a16(t->beta);
+  return y->c % 32 == 0 && dhw >= 1 && dhw <= 4096 && dense(dout) && dense(y) && dense(dy) && al(dout, is_bf16(dout) ? 8 : 4) &&
+         al(dy, is_bf16(dy) ? 8 : 4) && al(y, is_bf16(y) ? 8 : 4) && a16(t->mean) && a16(t->rstd) && a16(t->gamma) && a16(t->beta);
 }
 
 extern "C" int mmtta_norm_bwd_small_ok(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
@@ -1078,7 +1085,8 @@ extern "C" int mmtta_norm_bwd_small(const mmtta_tensor* dout, const mmtta_tensor
   q.C = y->c; q.relu = t->relu; q.dhw = (unsigned)((long long)y->d * y->h * y->w); q.count = (double)count;
   q.mean = t->mean; q.rstd = t->rstd; q.gamma = t->gamma; q.beta = t->beta;
   const dim3 grid((unsigned)(y->c / 32), (unsigned)y->n);
-  if (is_bf16(y)) hipLaunchKernelGGL(norm_bwd_small_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q);
+  if (is_bf16(dout)) hipLaunchKernelGGL((norm_bwd_small_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, q);
+  else if (is_bf16(y)) hipLaunchKernelGGL(norm_bwd_small_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q);
   else hipLaunchKernelGGL(norm_bwd_small_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q);
   return launch_status("norm bwd (one launch)");
 }

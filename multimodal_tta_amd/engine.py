@@ -302,7 +302,7 @@ class ConvolutionBlock(Block):
         x, x_nl, y, nl = self.saved
         dy = dT
         if self.norm is not None:
-            dy = self.rt.pool.cl((self.key, "dy"), *y.shape)
+            dy = self.rt.pool.cl((self.key, "dy"), *y.shape, dtype=dT.dtype)      # gradients keep their storage type
             self.norm.backward(self.rt.pool, self.key, dT, y, nl, dy, self.rt.training, grad_accumulate)
         self.conv.wgrad(x, x_nl, dy, grad_accumulate)
         if need_dx:
@@ -350,7 +350,7 @@ class ResidualUnitBlock(Block):
             unit = self.units[u]
             if u > 0:
                 inp = unit.saved[0]
-                dprev = pool.cl((self.key, "dprev", u), *inp.shape)
+                dprev = pool.cl((self.key, "dprev", u), *inp.shape, dtype=self.rt.grad_dtype(inp.shape[-1]))
                 unit.bwd(d, dprev, accumulate=False, need_dx=True, grad_accumulate=grad_accumulate)
                 d = dprev
             else:
@@ -379,6 +379,10 @@ class Runtime:
         # forward activations of more than 4 channels stored as bf16 (torch-autocast style): set by runtimes whose every
         # layer kind has storage-agnostic kernels (models/unet.py); gradients, logits, statistics, weights stay fp32
         self.act_bf16 = False
+        # gradients of more than 4 channels stored as bf16 as well (method.grad_storage; only next to bf16-stored
+        # activations): every consumer of such a gradient - input-gradient and weight-gradient convolutions - rounds it to
+        # bf16 while staging it anyway; statistics, reductions, the reduced weight gradients and the optimizer stay fp32
+        self.grad_bf16 = False
         self.training = False
         self.overlap_wgrad = True      # weight gradients on a side stream (joined before the optimizer)
         self.n_side = 2                # layers alternate between the side streams (a layer always uses the same one)
@@ -392,6 +396,10 @@ class Runtime:
     def act_dtype(self, channels: int) -> torch.dtype:
         """Storage type of a forward activation with `channels` channels."""
         return torch.bfloat16 if (self.act_bf16 and channels > 4) else torch.float32
+
+    def grad_dtype(self, channels: int) -> torch.dtype:
+        """Storage type of an activation GRADIENT with `channels` channels."""
+        return torch.bfloat16 if (self.grad_bf16 and self.act_bf16 and channels > 4) else torch.float32
 
     # -- construction helpers
     def make_ref(self, name: str, param: torch.nn.Parameter) -> ParamRef:

@@ -65,7 +65,7 @@ class HipSegModel(nn.Module):
             self._rt = None
 
     # ---- engine binding
-    def set_precision(self, precision: str, storage: Optional[str] = None) -> None:
+    def set_precision(self, precision: str, storage: Optional[str] = None, grad_storage: Optional[str] = None) -> None:
         """'fp32': exact fp32 MFMA everywhere, fp32 storage (the parity path).  'bf16': forward, input-gradient and
         27-tap weight-gradient convolutions round their operands to bf16 and accumulate in fp32; norms, loss, the
         optimizer and the master weights stay fp32.  ``storage`` (bf16 precision only): 'bf16' (default) keeps the wide
@@ -76,10 +76,15 @@ class HipSegModel(nn.Module):
         storage = "bf16" if storage is None else str(storage).lower()
         if storage not in ("bf16", "fp32"):
             raise ValueError(f"storage must be 'bf16' or 'fp32', got {storage!r}")
+        grad_storage = "bf16" if grad_storage is None else str(grad_storage).lower()
+        if grad_storage not in ("bf16", "fp32"):
+            raise ValueError(f"grad_storage must be 'bf16' or 'fp32', got {grad_storage!r}")
         dt = ops.PRECISIONS[precision]
-        if dt != self.conv_dtype or storage != getattr(self, "act_storage", "bf16"):
+        if (dt != self.conv_dtype or storage != getattr(self, "act_storage", "bf16")
+                or grad_storage != getattr(self, "grad_storage", "bf16")):
             self.conv_dtype = dt
             self.act_storage = storage
+            self.grad_storage = grad_storage      # bf16: the wide activation gradients too (where activations are bf16-stored)
             self._rt = None
 
     def configure_training(self, trainable: Optional[Set[str]] = None,

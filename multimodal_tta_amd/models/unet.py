@@ -39,6 +39,7 @@ class UNetRuntime(Runtime):
                          and str(norm_name).upper() == "INSTANCE" and self.channels[0] in (32, 64)
                          and all(c % 8 == 0 and c >= 32 for c in self.channels)
                          and self.in_channels <= 4 and self.out_channels <= 4)
+        self.grad_bf16 = self.act_bf16 and getattr(model, "grad_storage", "bf16") == "bf16"
         L = len(self.strides)
         self.L = L
         self.down: List[Any] = []
@@ -73,7 +74,7 @@ class UNetRuntime(Runtime):
         width = 2 * c[i] if i < self.L - 1 else c[i] + c[i + 1]
         d, h, w = dims[i]
         return self.pool.cl(("dcat" if grad else "cat", i), n, d, h, w, width,
-                            dtype=torch.float32 if grad else self.act_dtype(width))
+                            dtype=self.grad_dtype(width) if grad else self.act_dtype(width))
 
     def _level_dims(self, d, h, w):
         dims = []
@@ -139,7 +140,7 @@ class UNetRuntime(Runtime):
             dcat = self._cat(i, n, dims, grad=True)
             if self.upru[i] is not None:
                 yt = self.upconv[i].saved[2]
-                dT = self.pool.cl(("dT", i), *yt.shape)
+                dT = self.pool.cl(("dT", i), *yt.shape, dtype=self.grad_dtype(yt.shape[-1]))
                 self.upru[i].bwd(d, dT, accumulate=False, need_dx=True)
                 self.upconv[i].bwd(dT, dcat, accumulate=False)
             else:

@@ -77,6 +77,7 @@ class EntropyMinimizationTTA:
         self.params_spec = get_config(m, "params", "all")
         self.precision = str(get_config(m, "precision", "fp32")).lower()
         self.storage = str(get_config(m, "storage", "bf16")).lower()      # activation storage of bf16 precision
+        self.grad_storage = str(get_config(m, "grad_storage", "bf16")).lower()      # activation-gradient storage, likewise
         self.missing = [int(i) for i in (get_config(m, "missing_modalities", []) or [])]
         md = get_config(m, "moddrop", {}) or {}
         self.moddrop_p = float(get_config(md, "p", 0.0)) if bool(get_config(md, "enabled", False)) else 0.0
@@ -140,7 +141,7 @@ class EntropyMinimizationTTA:
         self.model = model
         ops.tune_for_volumes_in_flight(self.tune_volumes or self.lanes * self.group)      # launch geometry for that many volumes
         names = select_params(model, self.params_spec)
-        model.set_precision(self.precision, self.storage)
+        model.set_precision(self.precision, self.storage, self.grad_storage)
         model.set_group(self.group)
         model.configure_training(set(names), self.no_decay_keys, self.treat_1d)
         model.to(device)

@@ -681,3 +681,39 @@ def test_pointwise_conv_weight_gradient_on_transposed_reads(case, stored):
     assert (out[1][0] - ref).abs().max().item() <= 1.5e-2 * scale + 1e-5
     assert (out[1][0] - out[0][0]).abs().max().item() <= 1e-2 * scale + 1e-6, "differs from the fp32-MFMA kernel"
     close("bias gradient", out[1][1], mod.bias.grad)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", [
+    (32, 32, 3, 1, False, (1, 8, 8, 16)), (64, 128, 3, 2, False, (1, 6, 6, 8)), (64, 32, 3, 2, True, (1, 4, 4, 8)),
+    (256, 512, 1, 1, False, (1, 4, 4, 4)), (40, 72, 3, 1, False, (2, 5, 9, 11))])
+def test_bf16_stored_gradients_through_the_convolutions(cin, cout, k, stride, transposed, shape):
+    """method.grad_storage: bf16 - the output gradient dy arrives bf16-stored and the input gradient dx leaves bf16-stored.
+    With a bf16-representable dy the weight / bias gradient equal the fp32-stored call BIT FOR BIT (the kernels round dy to
+    bf16 while staging it anyway: same operands, same order) and dx equals round_bf16(fp32-stored dx) to one bf16 ulp."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(7 + cin)
+    n, d, h, w = shape
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = (torch.randn(n, cin, d, h, w) * 1.3).to(torch.bfloat16).float()
+    x16 = cl_bf16(x)
+    op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+    wt = mod.weight.detach().cuda().contiguous()
+    op.pack(wt)
+    _, do, ho, wo, _ = op.out_shape(x16)
+    gy = torch.randn(n, cout, do, ho, wo).to(torch.bfloat16).float()
+    res = {}
+    for name, gcl in (("fp32", cl(gy)), ("bf16", cl_bf16(gy))):
+        dw = torch.empty_like(wt)
+        db = torch.empty(cout, device="cuda")
+        op.wgrad(x16, None, gcl, dw, db)
+        dx = ops.new_cl(n, d, h, w, cin, "cuda", ldc=ops.row_pad(cin, gcl.dtype), dtype=gcl.dtype, zero=True)
+        op.dgrad(gcl, dx)
+        op.dgrad(gcl, dx, accumulate=True, add=dx.clone())          # accumulate + fused add in the gradient's storage
+        torch.cuda.synchronize()
+        res[name] = (dw.clone(), db.clone(), dx.float().clone())
+    assert torch.equal(res["fp32"][0], res["bf16"][0]), "weight gradient differs between fp32- and bf16-stored dy"
+    assert torch.equal(res["fp32"][1], res["bf16"][1]), "bias gradient differs"
+    want = res["fp32"][2]
+    err = (res["bf16"][2] - want).abs().max().item() / want.abs().max().item()
+    assert err <= 3 * 2.0 ** -8, f"bf16-stored input gradient: {err:.3e} of max (three roundings to bf16)"

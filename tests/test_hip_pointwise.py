@@ -388,3 +388,56 @@ def test_intensity_normalisation_matches_the_oracle():
     close("legacy", normalize_image(x4.cuda(), mean=[0.1, 0.2, 0.3, 0.4], std=[1.0, 2.0, 0.5, 4.0]),
           oracle.normalize_image(x4, mean=[0.1, 0.2, 0.3, 0.4], std=[1.0, 2.0, 0.5, 4.0]), rel=1e-6, abs_=1e-6)
     assert normalize_image(x4.cuda(), normalize=False).data_ptr() != 0
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 16, 16, 16), (2, 32, 9, 10, 11), (1, 512, 8, 8, 8), (1, 24, 6, 6, 7)])
+def test_norm_backward_with_bf16_stored_gradients(shape):
+    """method.grad_storage: bf16 - the gradient going INTO the norm backward and the one coming out are bf16-stored (next to a
+    bf16-stored activation).  With a bf16-representable incoming gradient the three-pass form (reduce / finalize / apply:
+    octet kernel, generic kernel for C = 24) and the one-launch form compute what the fp32-stored forms compute, the result
+    rounded to bf16 once on the way out: equal to round_bf16(fp32 result) to one bf16 ulp (the reductions see the same
+    values; only the apply's fp32 summation order inside m1 / m2 may differ in the last fp32 bit)."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(21)
+    n, c, d, h, w = shape
+    y = (torch.randn(shape) * 1.7 + 0.3).to(torch.bfloat16).float()
+    gout = torch.randn(shape).to(torch.bfloat16).float()
+    y32, g32 = cl(y), cl(gout)
+    y16 = ops.new_cl(n, d, h, w, c, "cuda", ldc=ops.row_pad(c, torch.bfloat16), dtype=torch.bfloat16)
+    y16.copy_(y32)
+    g16 = ops.new_cl(n, d, h, w, c, "cuda", ldc=ops.row_pad(c, torch.bfloat16), dtype=torch.bfloat16)
+    g16.copy_(g32)
+    rows = ops.reduce_rows_per_n(y32)
+    part = torch.empty(n * rows * 2 * c, device="cuda")
+    ops.channel_stats(y32, part)
+    mean, rstd = torch.empty(n * c, device="cuda"), torch.empty(n * c, device="cuda")
+    scratch = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
+    ops.norm_stats_finalize(ops.NORM_INSTANCE, 1, part, rows, n, c, d * h * w, 1e-5, True, None, None, 0.1, mean, rstd, scratch)
+    nl = ops.NL(mean, rstd, None, None, relu=True)
+    out = {}
+    for name, yy, gg in (("fp32", y16, g32), ("bf16", y16, g16)):
+        bpart = torch.empty(n * rows * 2 * c, device="cuda")
+        m1, m2 = torch.empty(n * c, device="cuda"), torch.empty(n * c, device="cuda")
+        ops.norm_bwd_reduce(gg, yy, nl, bpart)
+        ops.norm_bwd_finalize(ops.NORM_INSTANCE, 1, bpart, rows, n, c, d * h * w, None, True, m1, m2, None, None, False, scratch)
+        dy = torch.empty_like(gg)
+        ops.norm_bwd_apply(gg, yy, nl, m1, m2, dy)
+        torch.cuda.synchronize()
+        out[name] = (bpart.clone(), dy.float().clone())
+        if c % 32 == 0 and d * h * w <= 4096:
+            dy1 = torch.empty_like(gg)
+            assert ops.norm_bwd_small_ok(gg, yy, nl, dy1)
+            ops.norm_bwd_small(gg, yy, nl, d * h * w, dy1)
+            torch.cuda.synchronize()
+            out[name + "_small"] = dy1.float().clone()
+    assert torch.equal(out["fp32"][0], out["bf16"][0]), "the reduction sees the same gradient values in either storage"
+    want = out["fp32"][1].to(torch.bfloat16).float()
+    ulp = want.abs() * 2.0 ** -7 + 1e-30
+    assert bool(((out["bf16"][1] - want).abs() <= ulp).all()), "bf16-stored result differs from round_bf16(fp32 result)"
+    if "bf16_small" in out:
+        want1 = out["fp32_small"].to(torch.bfloat16).float()
+        assert bool(((out["bf16_small"] - want1).abs() <= want1.abs() * 2.0 ** -7 + 1e-30).all())
+    # a bf16 gradient next to an fp32-stored activation is refused (the engine never builds that pair)
+    with pytest.raises(ops.MmttaError):
+        ops.norm_bwd_reduce(g16, y32, nl, part)

@@ -358,6 +358,45 @@ def test_dicece_sums_and_gradient_single_region_bce_pos_weight():
         assert gerr <= 2e-5, f"channels_last={channels_last}: gradient rel err {gerr:.3e}"
 
 
+@pytest.mark.parametrize("kw", [dict(include_background=True), dict(include_background=False),
+                                dict(include_background=False, squared_pred=True, jaccard=True, weight=[0.5, 2.0, 1.0]),
+                                dict(include_background=True, weight=[0.5, 2.0, 1.0, 1.5])])
+def test_dicece_softmax_head_sums_and_gradient(kw):
+    """Softmax heads at the kernel level (reference src/core/trainers/seg_trainer.py:41-54, SURVEY A.5 softmax branch):
+    mmtta_dice_ce_sums / mmtta_dice_ce_grad with softmax=1 - Dice on softmax probabilities, its gradient through the softmax
+    Jacobian, soft-label CE with class weights - against oracle.DiceCELoss(softmax=True) and its autograd gradient."""
+    import oracle
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(5)
+    w = kw.get("weight")
+    B, R, D, H, W = 2, (len(w) if w else 3), 6, 9, 10
+    z = torch.randn(B, R, D, H, W) * 2.0
+    y = torch.nn.functional.one_hot(torch.randint(0, R, (B, D, H, W)), R).permute(0, 4, 1, 2, 3).float()
+    wt = torch.tensor(w) if w else None
+    zz = z.clone().requires_grad_(True)
+    loss_fn = oracle.DiceCELoss(include_background=kw["include_background"], softmax=True, squared_pred=kw.get("squared_pred", False),
+                                jaccard=kw.get("jaccard", False), weight=wt, lambda_dice=2.0, lambda_ce=0.5)
+    loss = loss_fn(zz, y)
+    loss.backward()
+    wd = wt.cuda() if wt is not None else None
+    for channels_last in (True, False):
+        zg = ops.to_cl(z.cuda()) if channels_last else z.cuda().contiguous()
+        sums = torch.zeros(B * (R * 3 + 1), dtype=torch.float64, device="cuda")
+        ops.dice_ce_sums(zg, y.cuda(), wd, kw.get("squared_pred", False), sums, logits_channels_last=channels_last, softmax=True)
+        dz = torch.zeros_like(zg)
+        ops.dice_ce_grad(zg, y.cuda(), wd, kw.get("squared_pred", False), kw.get("jaccard", False), kw["include_background"], 2.0,
+                         0.5, sums, dz, logits_channels_last=channels_last, softmax=True)
+        torch.cuda.synchronize()
+        got = (dz.permute(0, 4, 1, 2, 3) if channels_last else dz).cpu()
+        gerr = (got - zz.grad).abs().max().item() / zz.grad.abs().max().item()
+        assert gerr <= 5e-5, f"{kw} channels_last={channels_last}: gradient rel err {gerr:.3e}"
+        # the Dice sums are sums of SOFTMAX probabilities: every voxel contributes 1 in total
+        s = sums.cpu().view(B, R * 3 + 1)
+        if not kw.get("squared_pred", False):
+            assert torch.allclose(s[:, 1:R * 3:3].sum(1), torch.full((B,), float(D * H * W), dtype=torch.float64), rtol=1e-6)
+
+
 @pytest.mark.parametrize("variant", ["hecktor_r1", "softmax_r3", "batchnorm_affine_only"])
 def test_adaptation_variants_match_the_oracle(variant):
     """Other heads / norms of the adaptation loop: the HECKTOR-shaped single-region sigmoid head (2 modalities),
