@@ -56,7 +56,7 @@ def mfma_peak(kernel_name: str) -> float:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32, help="timed adapted volumes per rank")
+    ap.add_argument("--steps", type=int, default=48, help="timed adapted volumes per rank (default: two rounds of 3 lanes x 8)")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="unet", choices=["unet", "unet_multimodal_deepfusion"])
     ap.add_argument("--task", default="brats", choices=["brats", "hecktor21"])

@@ -215,7 +215,8 @@ __device__ __forceinline__ void direct_stats(const DArgs& a, int n, const float*
 // (KL lanes x NO outputs x KL passes) are combined by a halving exchange: log2(KL) steps, each lane ends with
 // the NO outputs of one voxel.  A workgroup keeps its weights in LDS and walks a contiguous range of units;
 // ranges that are neighbours in the volume run on the same XCD (xcd_contiguous_id) so halo rows hit its L2.
-template <int KL, int NO, bool HAS_T>
+// XBF: the input is bf16-stored (the 1x1x1 head of the deep-fusion net reads a wide forward activation)
+template <int KL, int NO, bool HAS_T, bool XBF = false>
 __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
   extern __shared__ float lds[];
   constexpr int VW = 64 / KL;            // voxels per pass
@@ -242,7 +243,16 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
   const int rowlen = (a.out.w + xstep - 1) / xstep;
   const int chunks = (rowlen + 63) / 64;
   const long long units = (long long)a.out.d * a.out.h * xstep * chunks;
-  const unsigned sw4 = (unsigned)a.in.sw * 4u;         // bytes between x neighbours of the input
+  constexpr unsigned EB = XBF ? 2u : 4u;              // bytes per input element
+  const unsigned sw4 = (unsigned)a.in.sw * EB;        // bytes between x neighbours of the input
+  auto ld4 = [](const char* p) {                       // 4 consecutive input channels
+    if constexpr (XBF) {
+      const uint2 u = *reinterpret_cast<const uint2*>(p);
+      return make_float4(bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu), bf16_bits_to_f32(u.y >> 16));
+    } else {
+      return *reinterpret_cast<const float4*>(p);
+    }
+  };
   float ssum[NO], ssq[NO];
 #pragma unroll
   for (int c = 0; c < NO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
     float acc[NP * NO];
 #pragma unroll
     for (int i = 0; i < NP * NO; ++i) acc[i] = 0.f;
-    const char* inb = reinterpret_cast<const char*>(a.in.p + (long long)n * a.in.sn);
+    const char* inb = reinterpret_cast<const char*>(a.in.p) + (long long)n * a.in.sn * EB;
     for (int kz = 0; kz < a.ksize; ++kz) {
       int iz;
       if (!a.transposed) iz = oz * a.stride + kz - pad;
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
           iy = s2 ? (t >> 1) : t;
         }
         if ((unsigned)iy >= (unsigned)a.in.h) continue;
-        const char* row = inb + ((long long)iz * a.in.sd + (long long)iy * a.in.sh) * 4;
+        const char* row = inb + ((long long)iz * a.in.sd + (long long)iy * a.in.sh) * EB;
         for (int kx = 0; kx < a.ksize; ++kx) {
           // input x of voxel i of this wave's row: ix = xa*i + xb (wave-uniform xa, xb)
           int xa, xb;
@@ -295,11 +305,11 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
           const int ilast = ibase + 63;
           const bool fast = px + xstep * ilast < a.out.w && xa * ibase + xb >= 0 && xa * ilast + xb < a.in.w;
           if (fast) {
-            unsigned boff = (unsigned)(xa * (ibase + g) + xb) * sw4 + (unsigned)k0 * 4u;
+            unsigned boff = (unsigned)(xa * (ibase + g) + xb) * sw4 + (unsigned)k0 * EB;
             const unsigned bstep = (unsigned)(xa * VW) * sw4;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-              const float4 x4 = *reinterpret_cast<const float4*>(row + boff);
+              const float4 x4 = ld4(row + boff);
               boff += bstep;
               const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256) void direct_klane_kernel(DArgs a) {
               const int i = ibase + p * VW + g;
               const int ix = xa * i + xb;
               const bool ok = px + xstep * i < a.out.w && (unsigned)ix < (unsigned)a.in.w;
-              const float4 x4 = *reinterpret_cast<const float4*>(row + (unsigned)(ok ? ix : 0) * sw4 + (unsigned)k0 * 4u);
+              const float4 x4 = ld4(row + (unsigned)(ok ? ix : 0) * sw4 + (unsigned)k0 * EB);
               const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -1198,7 +1208,9 @@ int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_n
   // the <= 4-channel gathered tensor is always fp32 (network input, gradient); the 32 / 64-channel result may be
   // bf16-stored, on the matrix-core path only
   MMTTA_CHECK(is_f32(x), MMTTA_ERR_UNSUPPORTED, "thin-K conv: the gathered tensor must be fp32-stored");
-  const bool mfma_path = d->dtype == MMTTA_BF16 && (x->c >= 2 || y->c > 32);
+  // (a bf16-stored result - the deep-fusion stems under method.storage: bf16 - takes the matrix-core kernel for one input
+  // channel as well: the VALU kernel writes fp32 only)
+  const bool mfma_path = d->dtype == MMTTA_BF16 && (x->c >= 2 || y->c > 32 || is_bf16(y));
   MMTTA_CHECK(mfma_path || (is_f32(y) && !a.add_bf), MMTTA_ERR_UNSUPPORTED, "thin-K conv (VALU path): fp32-stored tensors only");
   MMTTA_CHECK(a.add == nullptr || (a.add_bf != 0) == is_bf16(y), MMTTA_ERR_UNSUPPORTED, "thin-K conv: the fused add must share the output's storage type");
   a.accumulate = accumulate; a.stats = stats;
@@ -1208,7 +1220,7 @@ int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_n
   const bool has_t = a.tin.mean != nullptr || a.tin.scale != nullptr;
   const int S = d->op == MMTTA_CONV_FWD ? d->stride : 2;       // CONVT_DGRAD: stride-2 gather
   // one input channel (the single-modality stems of the deep-fusion net) is 27 FMAs per output: the VALU kernel wins there
-  if (d->dtype == MMTTA_BF16 && (x->c >= 2 || y->c > 32)) {
+  if (mfma_path) {
     if (S == 1) { if (has_t) launch_chan_mfma<1, true>(a, x->c, y->c, blocks, stream); else launch_chan_mfma<1, false>(a, x->c, y->c, blocks, stream); }
     else { if (has_t) launch_chan_mfma<2, true>(a, x->c, y->c, blocks, stream); else launch_chan_mfma<2, false>(a, x->c, y->c, blocks, stream); }
     return launch_status("thin-K conv (bf16 MFMA)");
@@ -1346,6 +1358,15 @@ int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const m
 template <int KL, bool HAS_T>
 static void launch_klane(const DArgs& a, int n, size_t lds, hipStream_t stream) {
   const dim3 grid(a.blocks_per_n, n), block(256);
+  if (a.in.bf) {
+    switch (a.N) {
+      case 1: hipLaunchKernelGGL((direct_klane_kernel<KL, 1, HAS_T, true>), grid, block, lds, stream, a); break;
+      case 2: hipLaunchKernelGGL((direct_klane_kernel<KL, 2, HAS_T, true>), grid, block, lds, stream, a); break;
+      case 3: hipLaunchKernelGGL((direct_klane_kernel<KL, 3, HAS_T, true>), grid, block, lds, stream, a); break;
+      default: hipLaunchKernelGGL((direct_klane_kernel<KL, 4, HAS_T, true>), grid, block, lds, stream, a); break;
+    }
+    return;
+  }
   switch (a.N) {
     case 1: hipLaunchKernelGGL((direct_klane_kernel<KL, 1, HAS_T>), grid, block, lds, stream, a); break;
     case 2: hipLaunchKernelGGL((direct_klane_kernel<KL, 2, HAS_T>), grid, block, lds, stream, a); break;
@@ -1610,8 +1631,8 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   // bf16-stored operands: only the INPUT of the matrix-core up-convolution (the 64 / 32-channel concat buffer); the
   // <= 4-channel results and every other direct variant work on fp32-stored tensors
   MMTTA_CHECK(is_f32(y) && !(epi && epi->add && is_bf16(epi->add)), MMTTA_ERR_UNSUPPORTED, "direct conv: outputs are fp32-stored");
-  MMTTA_CHECK(is_f32(x) || (variant == 3 && d->dtype == MMTTA_BF16), MMTTA_ERR_UNSUPPORTED,
-              "direct conv: a bf16-stored input is supported by the matrix-core up-convolution only");
+  MMTTA_CHECK(is_f32(x) || (variant == 3 && d->dtype == MMTTA_BF16) || variant == 1, MMTTA_ERR_UNSUPPORTED,
+              "direct conv: a bf16-stored input is supported by the matrix-core up-convolution and the lanes-along-K kernel only");
   if (variant == 1) {
     const size_t kl_lds = (size_t)T * a.K * 16 + 32 * sizeof(float);
     if (a.K == 64) { if (has_t) launch_klane<16, true>(a, y->n, kl_lds, stream); else launch_klane<16, false>(a, y->n, kl_lds, stream); }

@@ -622,7 +622,8 @@ struct LinArgs {
 
 // COUNT inputs are a template parameter: their loads are straight-line (a load behind a run-time `k < count`
 // branch is waited for before the next one is issued)
-template <int VEC, int COUNT>
+// IBF / OBF: storage of the inputs (all alike) and of the output (bf16: the wide forward activations of bf16 precision)
+template <int VEC, int COUNT, bool IBF = false, bool OBF = false>
 __global__ __launch_bounds__(256) void lincomb_kernel(LinArgs e) {
   const int C = e.o.c;
   const int CV = (C + VEC - 1) / VEC;
@@ -635,20 +636,20 @@ __global__ __launch_bounds__(256) void lincomb_kernel(LinArgs e) {
     int n, z, y, x;
     vox_decompose(e.o, v, n, z, y, x);
     float acc[VEC];
-    float* op = e.o.p + vox_addr(e.o, n, z, y, x) + c0;
+    const long long oo = vox_addr(e.o, n, z, y, x) + c0;          // element offsets: the same code addresses 2- and 4-byte elements
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     if (e.accumulate) {
-      if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(op); acc[0] = t.x; acc[1] = t.y; acc[2] = t.z; acc[3] = t.w; }
-      else acc[0] = op[0];
+      if (VEC == 4) { const float4 t = ld4_t<OBF>(e.o.p, oo); acc[0] = t.x; acc[1] = t.y; acc[2] = t.z; acc[3] = t.w; }
+      else acc[0] = ld1_t<OBF>(e.o.p, oo);
     }
     float4 tv4[COUNT];
     float ts[COUNT];
 #pragma unroll
     for (int k = 0; k < COUNT; ++k) {
-      const float* ip = e.in[k].p + vox_addr(e.in[k], n, z, y, x) + c0;
-      if (VEC == 4) tv4[k] = *reinterpret_cast<const float4*>(ip);
-      else ts[k] = ip[0];
+      const long long io = vox_addr(e.in[k], n, z, y, x) + c0;
+      if (VEC == 4) tv4[k] = ld4_t<IBF>(e.in[k].p, io);
+      else ts[k] = ld1_t<IBF>(e.in[k].p, io);
     }
 #pragma unroll
     for (int k = 0; k < COUNT; ++k) {
@@ -659,8 +660,8 @@ __global__ __launch_bounds__(256) void lincomb_kernel(LinArgs e) {
         acc[0] = fmaf(e.w[k], ts[k], acc[0]);
       }
     }
-    if (VEC == 4) *reinterpret_cast<float4*>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    else op[0] = acc[0];
+    if (VEC == 4) st4_t<OBF>(e.o.p, oo, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    else st1_t<OBF>(e.o.p, oo, acc[0]);
   }
 }
 
@@ -677,7 +678,7 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, int& i0, int
 
 // VEC = 4: a thread owns 4 consecutive channels of one output voxel (16-byte accesses, index arithmetic amortised);
 // VEC = 1: scalar fallback for unaligned views.
-template <int VEC>
+template <int VEC, bool BF = false>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(TV x, TV y) {
   const int C = y.c;
   const int CV = (C + VEC - 1) / VEC;
@@ -692,25 +693,27 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(TV x, TV y) {
     src_index(oz, x.d, y.d, z0, z1, lz);
     src_index(oy, x.h, y.h, y0, y1, ly);
     src_index(ox, x.w, y.w, x0, x1, lx);
-    const float* xp = x.p + (long long)n * x.sn + c;
+    const float* xp = x.p;
+    const long long xb = (long long)n * x.sn + c;                 // element offset of (item, channel): x and y share one storage (BF)
     const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
     const long long o00 = (long long)z0 * x.sd + (long long)y0 * x.sh, o01 = (long long)z0 * x.sd + (long long)y1 * x.sh;
     const long long o10 = (long long)z1 * x.sd + (long long)y0 * x.sh, o11 = (long long)z1 * x.sd + (long long)y1 * x.sh;
     const long long a0 = (long long)x0 * x.sw, a1 = (long long)x1 * x.sw;
-    float* op = y.p + vox_addr(y, n, oz, oy, ox) + c;
+    const long long oo = vox_addr(y, n, oz, oy, ox) + c;
     if (VEC == 4) {
-      const float4 v000 = *reinterpret_cast<const float4*>(xp + o00 + a0), v001 = *reinterpret_cast<const float4*>(xp + o00 + a1);
-      const float4 v010 = *reinterpret_cast<const float4*>(xp + o01 + a0), v011 = *reinterpret_cast<const float4*>(xp + o01 + a1);
-      const float4 v100 = *reinterpret_cast<const float4*>(xp + o10 + a0), v101 = *reinterpret_cast<const float4*>(xp + o10 + a1);
-      const float4 v110 = *reinterpret_cast<const float4*>(xp + o11 + a0), v111 = *reinterpret_cast<const float4*>(xp + o11 + a1);
+      const float4 v000 = ld4_t<BF>(xp, xb + o00 + a0), v001 = ld4_t<BF>(xp, xb + o00 + a1);
+      const float4 v010 = ld4_t<BF>(xp, xb + o01 + a0), v011 = ld4_t<BF>(xp, xb + o01 + a1);
+      const float4 v100 = ld4_t<BF>(xp, xb + o10 + a0), v101 = ld4_t<BF>(xp, xb + o10 + a1);
+      const float4 v110 = ld4_t<BF>(xp, xb + o11 + a0), v111 = ld4_t<BF>(xp, xb + o11 + a1);
 #define MMTTA_TRI(f) (wz0 * (wy0 * (wx0 * v000.f + lx * v001.f) + ly * (wx0 * v010.f + lx * v011.f)) + \
                       lz * (wy0 * (wx0 * v100.f + lx * v101.f) + ly * (wx0 * v110.f + lx * v111.f)))
-      *reinterpret_cast<float4*>(op) = make_float4(MMTTA_TRI(x), MMTTA_TRI(y), MMTTA_TRI(z), MMTTA_TRI(w));
+      st4_t<BF>(y.p, oo, make_float4(MMTTA_TRI(x), MMTTA_TRI(y), MMTTA_TRI(z), MMTTA_TRI(w)));
 #undef MMTTA_TRI
     } else {
-      const float v = wz0 * (wy0 * (wx0 * xp[o00 + a0] + lx * xp[o00 + a1]) + ly * (wx0 * xp[o01 + a0] + lx * xp[o01 + a1])) +
-                      lz * (wy0 * (wx0 * xp[o10 + a0] + lx * xp[o10 + a1]) + ly * (wx0 * xp[o11 + a0] + lx * xp[o11 + a1]));
-      op[0] = v;
+      auto X = [&](long long o) { return ld1_t<BF>(xp, xb + o); };
+      const float v = wz0 * (wy0 * (wx0 * X(o00 + a0) + lx * X(o00 + a1)) + ly * (wx0 * X(o01 + a0) + lx * X(o01 + a1))) +
+                      lz * (wy0 * (wx0 * X(o10 + a0) + lx * X(o10 + a1)) + ly * (wx0 * X(o11 + a0) + lx * X(o11 + a1)));
+      st1_t<BF>(y.p, oo, v);
     }
   }
 }
@@ -852,15 +855,9 @@ extern "C" int mmtta_reduce_rows_per_n(const mmtta_tensor* t) {
 }
 
 extern "C" int mmtta_channel_stats(const mmtta_tensor* x, float* part, void* stream) {
-  MMTTA_CHECK(x == nullptr || x->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_channel_stats: `x` must be fp32-stored");
   MMTTA_CHECK(x && x->ptr && part, MMTTA_ERR_INVALID, "channel_stats: null argument");
   MMTTA_CHECK(is_cl(x), MMTTA_ERR_UNSUPPORTED, "channel_stats: tensor must be channels-last");
-  RedArgs a;
-  a.x = tv(x); a.dout = tv(x); a.t = nl(nullptr); a.part = part;
-  rows_geometry(x, a.rows_per_n, a.vox_per_row);
-  if (vec4_rd(x)) hipLaunchKernelGGL((channel_reduce_kernel<0, 4>), dim3(x->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((channel_reduce_kernel<0, 1>), dim3(x->n * a.rows_per_n), dim3(256), 0, (hipStream_t)stream, a);
-  return launch_status("channel_stats");
+  return launch_channel_sums(x, part, (hipStream_t)stream);
 }
 
 extern "C" int mmtta_norm_stats_finalize(int kind, int groups, const float* part, int rows_per_n, int n, int c,
@@ -1092,16 +1089,21 @@ extern "C" int mmtta_norm_bwd_small(const mmtta_tensor* dout, const mmtta_tensor
 }
 
 extern "C" int mmtta_upsample2x_fwd(const mmtta_tensor* x, const mmtta_tensor* y, void* stream) {
-  MMTTA_CHECK(x == nullptr || x->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_fwd: `x` must be fp32-stored");
-  MMTTA_CHECK(y == nullptr || y->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_fwd: `y` must be fp32-stored");
   MMTTA_CHECK(x && y && x->ptr && y->ptr, MMTTA_ERR_INVALID, "upsample: null tensor");
+  MMTTA_CHECK(x->dtype == y->dtype, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_fwd: `x` and `y` must share one storage type");
   MMTTA_CHECK(y->n == x->n && y->c == x->c && y->d == 2 * x->d && y->h == 2 * x->h && y->w == 2 * x->w, MMTTA_ERR_INVALID,
               "upsample: y must be exactly 2x of x");
   MMTTA_CHECK(is_cl(x) && is_cl(y), MMTTA_ERR_UNSUPPORTED, "upsample: channels-last only");
   const bool v4 = vec4_rd(x) && vec4_wr(y);
   const long long total = (long long)y->n * y->d * y->h * y->w * (v4 ? (y->c + 3) / 4 : y->c);
-  if (v4) hipLaunchKernelGGL(upsample_fwd_kernel<4>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
-  else hipLaunchKernelGGL(upsample_fwd_kernel<1>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
+  const dim3 ug(grid_for(total, 16384));
+  if (is_bf16(x)) {
+    if (v4) hipLaunchKernelGGL((upsample_fwd_kernel<4, true>), ug, dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
+    else hipLaunchKernelGGL((upsample_fwd_kernel<1, true>), ug, dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
+  } else {
+    if (v4) hipLaunchKernelGGL(upsample_fwd_kernel<4>, ug, dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
+    else hipLaunchKernelGGL(upsample_fwd_kernel<1>, ug, dim3(256), 0, (hipStream_t)stream, tv(x), tv(y));
+  }
   return launch_status("upsample fwd");
 }
 
@@ -1121,10 +1123,10 @@ extern "C" int mmtta_upsample2x_bwd(const mmtta_tensor* dy, const mmtta_tensor* 
 
 extern "C" int mmtta_lincomb(int count, const mmtta_tensor* const* in, const float* w, const mmtta_tensor* out,
                              int accumulate, void* stream) {
-  MMTTA_CHECK(out == nullptr || out->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "lincomb: fp32-stored tensors only");
-  for (int i = 0; in != nullptr && i < count; ++i)
-    MMTTA_CHECK(in[i] == nullptr || in[i]->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "lincomb: fp32-stored tensors only");
   MMTTA_CHECK(count >= 1 && count <= 8 && in && w && out && out->ptr, MMTTA_ERR_INVALID, "lincomb: bad argument");
+  for (int i = 0; i < count; ++i)
+    MMTTA_CHECK(in[i] != nullptr && in[i]->dtype == in[0]->dtype, MMTTA_ERR_UNSUPPORTED, "lincomb: the inputs must share one storage type");
+  const bool ibf = is_bf16(in[0]), obf = is_bf16(out);
   LinArgs e;
   bool v4 = vec4_wr(out);
   for (int k = 0; k < count; ++k) {
@@ -1139,13 +1141,17 @@ extern "C" int mmtta_lincomb(int count, const mmtta_tensor* const* in, const flo
   const long long total = (long long)out->n * out->d * out->h * out->w * (v4 ? (out->c + 3) / 4 : out->c);
   const dim3 grid(grid_for(total)), block(256);
   hipStream_t st = (hipStream_t)stream;
+#define MMTTA_LINCOMB_S(N, I, O) \
+  do { if (v4) hipLaunchKernelGGL((lincomb_kernel<4, N, I, O>), grid, block, 0, st, e); \
+       else hipLaunchKernelGGL((lincomb_kernel<1, N, I, O>), grid, block, 0, st, e); } while (0)
 #define MMTTA_LINCOMB(N) \
-  case N: if (v4) hipLaunchKernelGGL((lincomb_kernel<4, N>), grid, block, 0, st, e); \
-          else hipLaunchKernelGGL((lincomb_kernel<1, N>), grid, block, 0, st, e); break;
+  case N: if (ibf && obf) MMTTA_LINCOMB_S(N, true, true); else if (obf) MMTTA_LINCOMB_S(N, false, true); \
+          else if (ibf) MMTTA_LINCOMB_S(N, true, false); else MMTTA_LINCOMB_S(N, false, false); break;
   switch (count) {
     MMTTA_LINCOMB(1) MMTTA_LINCOMB(2) MMTTA_LINCOMB(3) MMTTA_LINCOMB(4)
     MMTTA_LINCOMB(5) MMTTA_LINCOMB(6) MMTTA_LINCOMB(7) MMTTA_LINCOMB(8)
   }
 #undef MMTTA_LINCOMB
+#undef MMTTA_LINCOMB_S
   return launch_status("lincomb");
 }

@@ -284,6 +284,12 @@ class DeepFusionRuntime(Runtime):
         self.channels = list(model.channels)
         self.out_channels = model.num_classes
         M, nlev = self.M, len(self.channels)
+        # bf16 precision stores the wide forward activations as bf16 (method.storage: bf16), like the U-Net: every layer kind
+        # of this runtime has storage-agnostic kernels (one-channel stems on the matrix-core thin-K kernel, trilinear
+        # resample, modality means, the 1x1x1 head).  Gradients stay fp32-stored here.
+        self.act_bf16 = (model.conv_dtype == ops.BF16 and getattr(model, "act_storage", "bf16") == "bf16"
+                         and self.channels[0] in (32, 64) and all(ch % 8 == 0 and ch >= 32 for ch in self.channels)
+                         and self.out_channels <= 4)
         encs = list(model.specific_encoders)
         self.encf = [build_residual_unit_family(self, [f"specific_encoders.{m}.layers.{i}" for m in range(M)],
                                                 [e.layers[i] for e in encs]) for i in range(nlev)]
@@ -339,27 +345,28 @@ class DeepFusionRuntime(Runtime):
         self.state = dict(n=n, dims=dims, keep=keep, x=x_cl)
         # encoders: every layer ONE launch sequence over the n * M (volume, modality) items -------------------
         skips: List[torch.Tensor] = []
-        catf = pool.cl("catf", n * M, *bd, 2 * c[-1])
+        act = self.act_dtype
+        catf = pool.cl("catf", n * M, *bd, 2 * c[-1], dtype=act(2 * c[-1]))
         cur = xm
         for i in range(nlev - 1):
-            out = pool.cl(("skip", i), n * M, *dims[i + 1], c[i])
+            out = pool.cl(("skip", i), n * M, *dims[i + 1], c[i], dtype=act(c[i]))
             self.encf[i].fwd(cur, None, out)
             skips.append(out)
             cur = out
         self.encf[nlev - 1].fwd(cur, None, catf[..., c[-1]:])
         # fusion -----------------------------------------------------------------------------------------------
-        shared = pool.cl("shared", n, *bd, c[-1])
+        shared = pool.cl("shared", n, *bd, c[-1], dtype=act(c[-1]))
         ops.lincomb([mem(catf, m)[..., c[-1]:] for m in keep], [1.0 / K] * K, shared)
         for m in range(M):
             ops.lincomb([shared], [1.0], mem(catf, m)[..., :c[-1]])
         y, nl = self.fusion.fwd(catf, None)                               # shared weights: one set per volume, M items each
-        fused = pool.cl("fused", n * M, *bd, c[-1])
+        fused = pool.cl("fused", n * M, *bd, c[-1], dtype=act(c[-1]))
         ops.combine(y, nl, catf[..., :c[-1]], None, fused)                # shared + relu(norm(conv(cat[shared, feat_m])))
-        bcat = pool.cl("bcat", n, *bd, M * c[-1])
+        bcat = pool.cl("bcat", n, *bd, M * c[-1], dtype=act(M * c[-1]))
         for m in range(M):
             src = mem(fused, m) if m in keep else shared                  # an absent branch feeds the shared mean
             ops.lincomb([src], [1.0], bcat[..., m * c[-1]:(m + 1) * c[-1]])
-        xdec = pool.cl(("xdec", -1), n, *bd, c[-1])
+        xdec = pool.cl(("xdec", -1), n, *bd, c[-1], dtype=act(c[-1]))
         self.bott.op.forward(bcat, None, None, xdec)
         # decoder ----------------------------------------------------------------------------------------------
         skip_src = [2, 1, 0, None]                     # fused_skips[2], [1], [0], input mean
@@ -368,16 +375,18 @@ class DeepFusionRuntime(Runtime):
         for j in range(self.nstage):
             cin, cout = c[nlev - 1 - j], c[nlev - 2 - j]
             lo, hi = dims[nlev - 1 - j], dims[nlev - 2 - j]
-            p = pool.cl(("pre", j), n, *lo, cout)
+            p = pool.cl(("pre", j), n, *lo, cout, dtype=act(cout))
             self.pre[j].op.forward(cur, None, self.pre[j].bias_data(), p)
             sc = c[skip_src[j]] if skip_src[j] is not None else 1
-            cat = pool.cl(("dcat_in", j), n, *hi, cout + sc, ldc=(cout + sc + 3) // 4 * 4)
+            # rows padded to 4 floats / 8 bf16; zero-filled once: the pad lanes behind a ragged channel count (32 + 1) are read
+            # by the 8-channel loaders of the implicit GEMM and must hold finite values
+            cat = pool.cl(("dcat_in", j), n, *hi, cout + sc, zero=True, dtype=act(cout + sc))
             ops.upsample2x_fwd(p, cat[..., :cout])
             if skip_src[j] is not None:
                 ops.lincomb([mem(skips[skip_src[j]], m) for m in keep], [1.0 / K] * K, cat[..., cout:])
             else:
                 ops.lincomb([x_cl[..., m:m + 1] for m in keep], [1.0 / K] * K, cat[..., cout:])
-            out = pool.cl(("xdec", j), n, *hi, cout)
+            out = pool.cl(("xdec", j), n, *hi, cout, dtype=act(cout))
             self.dec[j].fwd(cat, None, out)
             self.cats.append((cur, p, cat))
             cur = out

@@ -150,7 +150,7 @@ def set_option(key: int, value: int) -> int:
 # launch-geometry knobs (include/mmtta.h: per batch item) measured best for 4 volumes in flight on one GPU; the optimum
 # scales inversely with the volumes in flight (lanes x group): one volume alone wants 384 / 512 / 512 / 1024 (round 1), sixteen
 # want 24 / 32 / 32 / 64 (profiles/r03_tuning_sweep.txt) - the launches of all volumes together should fill the chip about once
-TUNE_AT_4 = {2: 96, 3: 128, 4: 128, 5: 256}      # SPLITK_BELOW, SPLITK_TARGET, WGRAD_WORKGROUPS, WGRAD_THIN_SLABS
+TUNE_AT_4 = {2: 96, 3: 128, 4: 128, 5: 256, 12: 128}      # SPLITK_BELOW, SPLITK_TARGET, WGRAD_WORKGROUPS, WGRAD_THIN_SLABS, CLASS_FUSED_MIN_WORKGROUPS
 _TUNED_FOR: Optional[int] = None
 
 
