@@ -424,6 +424,9 @@ extern int g_thin_mfma;             // api.hip: MMTTA_OPT_THIN_MFMA
 extern int g_epilogue_vec;          // api.hip: MMTTA_OPT_EPILOGUE_VEC16
 extern int g_tune[4];               // api.hip: launch-geometry knobs (MMTTA_OPT_SPLITK_BELOW ... MMTTA_OPT_WGRAD_THIN_SLABS)
 bool direct_applicable(const mmtta_conv_desc* d);
+// bytes of the fragment-ordered bf16 weight image W' of the 2x2x2 gather-GEMM up-convolution (conv_direct.hip,
+// upconv8_kernel), stored behind the fp32 tap image of the packed buffer; 0 for every other layer
+long long upconv8_image_bytes(const mmtta_conv_desc* d);
 int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);
 bool pointwise_small_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y, const float* stats,
                                 const mmtta_conv_epilogue* epi, const mmtta_norm_on_load* x_norm);

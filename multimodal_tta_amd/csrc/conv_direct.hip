@@ -788,6 +788,12 @@ bool direct_applicable(const mmtta_conv_desc* d) {
   return N <= 4 && (size_t)T * K * 16 + (size_t)K * 8 + 128 <= 96 * 1024;
 }
 
+long long upconv8_image_bytes(const mmtta_conv_desc* d) {
+  const bool ok = d->op == MMTTA_CONVT_FWD && d->ksize == 3 && d->stride == 2 && (d->cin == 32 || d->cin == 64) && d->cout <= 4 &&
+                  d->dtype == MMTTA_BF16;
+  return ok ? (long long)8 * (d->cin / 16) * 64 * 16 : 0;
+}
+
 static bool aligned16(const mmtta_tensor* x) {
   return x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 && x->sn % 4 == 0 && ((uintptr_t)x->ptr) % 16 == 0;
 }
@@ -1323,7 +1329,12 @@ static int direct_variant(const mmtta_conv_desc* d, const mmtta_tensor* x) {
   direct_dims(d, K, N);
   if (!aligned16(x) || (long long)x->w * x->sw * 4 >= (1LL << 31)) return 0;
   if ((K == 32 || K == 64) && d->op == MMTTA_CONVT_FWD && d->ksize == 3 && d->stride == 2 &&
-      (long long)x->d * x->sd < (1LL << 31)) return 3;       // 32-bit offsets inside a batch item
+      (long long)x->d * x->sd < (1LL << 31)) {               // 32-bit offsets inside a batch item
+    // bf16 precision: the 2x2x2 gather GEMM (upconv8_kernel) when the input admits its 8-channel items
+    const int q = is_bf16(x) ? 8 : 4;
+    if (d->dtype == MMTTA_BF16 && x->sw % q == 0 && x->sh % q == 0 && x->sd % q == 0 && x->sn % q == 0) return 5;
+    return 3;
+  }
   if (K == 32 || K == 64) return 1;
   if (K <= 4 && d->stride == 1 && d->ksize == 3) return (d->dtype == MMTTA_BF16 && g_thin_mfma && N <= 4) ? 4 : 2;
   return 0;
@@ -1345,6 +1356,7 @@ int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const m
     return (int)((dhw + 255) / 256);
   }
   if (v == 3) return x->d * x->h * ((x->w + 63) / 64);       // one workgroup per (input row pair, 64-voxel chunk)
+  if (v == 5) return ((x->d + 3) / 4) * ((x->h + 3) / 4) * ((x->w + 7) / 8);      // one statistics row per coarse 4 x 4 x 8 tile
   if (v == 4) {                                    // one workgroup per TZ x 8 x 64 tile (MMTTA_OPT_THIN_MFMA = 2: TZ = 4)
     const int tz = g_thin_mfma == 3 ? 2 : g_thin_mfma == 2 ? 4 : 8;
     return ((y->d + tz - 1) / tz) * ((y->h + 7) / 8) * ((y->w + 63) / 64);
@@ -1560,6 +1572,187 @@ static void launch_upconv_mfma(const DArgs& a, int n, hipStream_t stream) {
   }
 }
 
+// ------------------------------------------------------------------ the up-convolution as ONE 2x2x2 gather GEMM (round 3)
+// ConvTranspose3d K -> R (k3 s2 p1 op1, R <= 4): the 8 fine voxels 2g + p of a coarse voxel g need exactly the 8 coarse
+// neighbours g + d, d in {0,1}^3, and every one of the 27 taps belongs to ONE (offset d, parity p) pair.  So
+//     out'[g][(p, co)] = sum_{d, ci} in[g + d][ci] * W'[d][ci][(p, co)]
+// is a dense 8-offset convolution on the COARSE grid with N = 8 parities x 4 (padded) channels = 32 columns - one
+// v_mfma_f32_32x32x16_bf16 column block - followed by a pixel shuffle.  The kernel above it (upconv_mfma_kernel, round 1)
+// ran a workgroup per input row pair: every workgroup re-staged four rows, rebuilt the weight image from the fp32 taps and
+// used 3 of 32 MFMA rows - 431 us for a group of 8 volumes at 64^3 -> 128^3 against 75 us of HBM time.  Here:
+//   * W' is part of the PACKED image (written once per optimizer step by the pack kernels, bf16, already in B-fragment
+//     order: entry ((d * K/16 + ks) * 64 + lane) = the lane's 8 k values of column lane & 31), copied into LDS once per
+//     workgroup - workgroups are persistent over a contiguous range of tiles;
+//   * a tile = 4 x 4 x 8 coarse voxels (one z-slice = one 32-row block per wave), its 5 x 5 x 9 halo box staged once as
+//     bf16 [voxel][K] (norm + ReLU applied on the way, out-of-range voxels exact zeros);
+//   * 8 offsets x K/16 MFMAs per wave and tile; the accumulator (row = coarse voxel, column = (parity, channel)) goes
+//     through a wave-private LDS slab [2 fine z][8 fine y][16 fine x][4] laid out so that the 64 lanes hit 64 distinct banks,
+//     and comes back as one float4 = one fine voxel per lane: 256-byte runs per output row, bias / fused add / accumulate
+//     / statistics in the shared epilogue.
+__device__ __forceinline__ void upconv8_slot(int tap, int& d, int& p) {
+  // per axis: k = 1 -> parity 0 reads g; k = 0 -> parity 1 reads g + 1; k = 2 -> parity 1 reads g   (out = 2 g - 1 + k)
+  const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+  p = ((kz != 1 ? 1 : 0) * 2 + (ky != 1 ? 1 : 0)) * 2 + (kx != 1 ? 1 : 0);
+  d = ((kz == 0 ? 1 : 0) * 2 + (ky == 0 ? 1 : 0)) * 2 + (kx == 0 ? 1 : 0);
+}
+// halfword index of W'[d][k][(p, co)] in the fragment-ordered image
+__device__ __forceinline__ int upconv8_index(int K, int d, int k, int col) {
+  return (((d * (K >> 4) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + col) << 3) + (k & 7);
+}
+
+template <int K, int NO, bool HAS_T, bool INBF>
+__global__ __launch_bounds__(256, 2) void upconv8_kernel(DArgs a, int tiles_per_n, int tz, int ty, int tx) {
+  constexpr int TZ = 4, TY = 4, TX = 8, BZ = TZ + 1, BY = TY + 1, BX = TX + 1;
+  constexpr int VS = K + 8;                           // halfwords per staged voxel: 16 lanes of a ds_read_b128 -> 16 distinct slots
+  constexpr int KS = K / 16, KC8 = K / 8;
+  constexpr int BOXV = BZ * BY * BX;
+  constexpr int NIT = (BOXV * KC8 + 255) / 256;       // 8-channel items per thread
+  constexpr int SLAB_Z = 8 * 72 + 16, SLAB = 2 * SLAB_Z;   // floats of one wave's output slab (padded: conflict-free writes)
+  constexpr int BOX_HW = (BOXV * VS + 7) / 8 * 8;
+  extern __shared__ float lds[];
+  unsigned short* lh = reinterpret_cast<unsigned short*>(lds);                 // box image, later the four output slabs
+  uint4* wl = reinterpret_cast<uint4*>(lh + (BOX_HW > SLAB * 4 * 2 ? BOX_HW : SLAB * 4 * 2));   // W': 8 * KS * 64 fragments
+  float* red = reinterpret_cast<float*>(wl + 8 * KS * 64);                     // 32 floats
+  const int n = blockIdx.y;
+  a.w = pset_packed(a.ps, a.w, n); a.bias = pset_bias(a.ps, a.bias, n);        // this batch item's parameter set
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  {  // W' of this batch item's set: behind the fp32 tap image [27][K][4]
+    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)27 * K * 16);
+    for (int i = tid; i < 8 * KS * 64; i += 256) wl[i] = src[i];
+  }
+  // a thread's items i = tid + 256 j all carry the same channel octet (256 % KC8 == 0): one coefficient set per thread
+  static_assert(256 % KC8 == 0, "items of a thread must share their channel octet");
+  float sc[8], sh[8];
+  if (HAS_T) nl_coeff_vec<8>(a.tin, n, K, (tid % KC8) * 8, sc, sh);
+  const float relu_lo = (HAS_T && a.tin.relu) ? 0.f : -__builtin_inff();
+  const float* inb = item_base<INBF>(a.in.p, n, a.in.sn);
+  const unsigned isd = (unsigned)a.in.sd, ish = (unsigned)a.in.sh, isw = (unsigned)a.in.sw;
+  long long tfirst, tlast;
+  unit_range(tiles_per_n, xcd_contiguous_id(blockIdx.x, gridDim.x), gridDim.x, tfirst, tlast);
+  for (long long tile = tfirst; tile < tlast; ++tile) {
+    int t = (int)tile;
+    const int txi = t % tx; t /= tx;
+    const int tyi = t % ty;
+    const int tzi = t / ty;
+    const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;
+    // ---- stage the halo box: all loads first (clamped addresses), then transform / mask / pack
+    Oct8<INBF> raw[NIT];
+    unsigned okm = 0u;
+    int ldsoff[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int i = min(tid + 256 * j, BOXV * KC8 - 1);
+      const int cv = i % KC8, bv = i / KC8;
+      const int bz = bv / (BY * BX), brem = bv - bz * (BY * BX), by = brem / BX, bx = brem - by * BX;
+      const int iz = gz0 + bz, iy = gy0 + by, ix = gx0 + bx;
+      okm |= ((iz < a.in.d && iy < a.in.h && ix < a.in.w) ? 1u : 0u) << j;
+      const unsigned off = (unsigned)min(iz, a.in.d - 1) * isd + (unsigned)min(iy, a.in.h - 1) * ish + (unsigned)min(ix, a.in.w - 1) * isw + cv * 8;
+      raw[j] = oct8_ld<INBF>(inb, off, off + 4);
+      ldsoff[j] = bv * VS + cv * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      float v[8];
+      oct8_f8(raw[j], v);
+      if (HAS_T) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = fmaxf(fmaf(v[q], sc[q], sh[q]), relu_lo);
+      }
+      const unsigned m = ((okm >> j) & 1u) ? 0xffffffffu : 0u;
+      uint4 pk;
+      pk.x = f32x2_to_bf16x2(v[0], v[1]) & m; pk.y = f32x2_to_bf16x2(v[2], v[3]) & m;
+      pk.z = f32x2_to_bf16x2(v[4], v[5]) & m; pk.w = f32x2_to_bf16x2(v[6], v[7]) & m;
+      if (tid + 256 * j < BOXV * KC8) *reinterpret_cast<uint4*>(lh + ldsoff[j]) = pk;
+    }
+    __syncthreads();
+    // ---- 8 offsets x KS k-steps: one 32 x 32 block per wave (rows = the 4 x 8 coarse voxels of z-slice `wave`)
+    ufloat16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    {
+      const unsigned short* arow = lh + ((wave * BY + (r >> 3)) * BX + (r & 7)) * VS + 8 * h;
+      const uint4* brow = wl + lane;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const unsigned short* ad = arow + ((((d >> 2) & 1) * BY + ((d >> 1) & 1)) * BX + (d & 1)) * VS;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint4 af = *reinterpret_cast<const uint4*>(ad + ks * 16);
+          const uint4 bf = brow[(d * KS + ks) * 64];
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ubf16x8, af), __builtin_bit_cast(ubf16x8, bf), acc, 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                   // the box image is dead: its space becomes the output slabs
+    // ---- pixel shuffle through LDS.  Accumulator i of lane (h, r): coarse (y, x) = (i >> 2, (i & 3) + 4 h), column r =
+    // (pz, py, px, co).  Slab address = pz * SLAB_Z + (2 y + py) * 72 + (2 x + px) * 4 + co: for one i the 64 lanes fall on
+    // banks co + 4 px + 8 py + 16 pz + 32 h - all distinct.
+    float* slab = lds + wave * SLAB;
+    {
+      const int pz = r >> 4, py = (r >> 3) & 1, px = (r >> 2) & 1, co = r & 3;
+      float* sp = slab + pz * SLAB_Z + py * 72 + (px + 8 * h) * 4 + co;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sp[(i >> 2) * 144 + (i & 3) * 8] = acc[i];
+    }
+    __syncthreads();
+    float ssum[NO], ssq[NO];
+#pragma unroll
+    for (int c = 0; c < NO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int v = lane + 64 * q;                     // fine voxel of the slab: (fz, fy, fx) = (v >> 7, (v >> 4) & 7, v & 15)
+      const int fz = v >> 7, fy = (v >> 4) & 7, fx = v & 15;
+      const float4 o4 = *reinterpret_cast<const float4*>(slab + fz * SLAB_Z + fy * 72 + fx * 4);
+      const int oz = 2 * (gz0 + wave) + fz, oy = 2 * gy0 + fy, ox = 2 * gx0 + fx;
+      if (oz < a.out.d && oy < a.out.h && ox < a.out.w) {
+        const float vals[4] = {o4.x, o4.y, o4.z, o4.w};
+        direct_epilogue<NO>(a, n, oz, oy, ox, vals, ssum, ssq);
+      }
+    }
+    // ---- statistics row of this tile (the following norm): lanes -> waves -> one row
+    if (a.stats != nullptr) {
+#pragma unroll
+      for (int c = 0; c < NO; ++c) {
+        const float s = wave_sum(ssum[c]), q2 = wave_sum(ssq[c]);
+        if (lane == 0) { red[(0 * 4 + wave) * 4 + c] = s; red[(1 * 4 + wave) * 4 + c] = q2; }
+      }
+    }
+    __syncthreads();                                   // slabs read, partial sums visible: the next tile may stage
+    if (a.stats != nullptr && tid < NO) {
+      const float s = red[0 * 4 + tid] + red[1 * 4 + tid] + red[2 * 4 + tid] + red[3 * 4 + tid];
+      const float q2 = red[16 + 0 * 4 + tid] + red[16 + 1 * 4 + tid] + red[16 + 2 * 4 + tid] + red[16 + 3 * 4 + tid];
+      const long long rrow = (long long)n * tiles_per_n + tile;
+      a.stats[(rrow * 2 + 0) * a.N + tid] = s;
+      a.stats[(rrow * 2 + 1) * a.N + tid] = q2;
+    }
+  }
+}
+
+template <int K, bool HAS_T, bool INBF>
+static void launch_upconv8(const DArgs& a, int n, int tz, int ty, int tx, hipStream_t stream) {
+  constexpr int VS = K + 8, BOX_HW = (225 * VS + 7) / 8 * 8, SLAB = 2 * (8 * 72 + 16);
+  constexpr size_t lds = (size_t)(BOX_HW > SLAB * 8 ? BOX_HW : SLAB * 8) * 2 + (size_t)8 * (K / 16) * 64 * 16 + 32 * sizeof(float);
+  const int tiles_per_n = tz * ty * tx;
+  // persistent workgroups: each copies W' once and walks a contiguous range of tiles (an XCD sweeps one part of the volume)
+  const dim3 grid(tiles_per_n < 128 ? tiles_per_n : 128, n), block(256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)upconv8_kernel<K, 1, HAS_T, INBF>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)upconv8_kernel<K, 2, HAS_T, INBF>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)upconv8_kernel<K, 3, HAS_T, INBF>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)upconv8_kernel<K, 4, HAS_T, INBF>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_set = true;
+  }
+  switch (a.N) {
+    case 1: hipLaunchKernelGGL((upconv8_kernel<K, 1, HAS_T, INBF>), grid, block, lds, stream, a, tiles_per_n, tz, ty, tx); break;
+    case 2: hipLaunchKernelGGL((upconv8_kernel<K, 2, HAS_T, INBF>), grid, block, lds, stream, a, tiles_per_n, tz, ty, tx); break;
+    case 3: hipLaunchKernelGGL((upconv8_kernel<K, 3, HAS_T, INBF>), grid, block, lds, stream, a, tiles_per_n, tz, ty, tx); break;
+    default: hipLaunchKernelGGL((upconv8_kernel<K, 4, HAS_T, INBF>), grid, block, lds, stream, a, tiles_per_n, tz, ty, tx); break;
+  }
+}
+
 template <int K, bool HAS_T>
 static void launch_upconv(const DArgs& a, int n, hipStream_t stream) {
   const dim3 grid(a.blocks_per_n, n), block(256);
@@ -1631,6 +1824,17 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   // bf16-stored operands: only the INPUT of the matrix-core up-convolution (the 64 / 32-channel concat buffer); the
   // <= 4-channel results and every other direct variant work on fp32-stored tensors
   MMTTA_CHECK(is_f32(y) && !(epi && epi->add && is_bf16(epi->add)), MMTTA_ERR_UNSUPPORTED, "direct conv: outputs are fp32-stored");
+  if (variant == 5) {
+    const int tz = (x->d + 3) / 4, ty = (x->h + 3) / 4, tx = (x->w + 7) / 8;
+    if (is_bf16(x)) {
+      if (a.K == 64) { if (has_t) launch_upconv8<64, true, true>(a, y->n, tz, ty, tx, stream); else launch_upconv8<64, false, true>(a, y->n, tz, ty, tx, stream); }
+      else { if (has_t) launch_upconv8<32, true, true>(a, y->n, tz, ty, tx, stream); else launch_upconv8<32, false, true>(a, y->n, tz, ty, tx, stream); }
+    } else {
+      if (a.K == 64) { if (has_t) launch_upconv8<64, true, false>(a, y->n, tz, ty, tx, stream); else launch_upconv8<64, false, false>(a, y->n, tz, ty, tx, stream); }
+      else { if (has_t) launch_upconv8<32, true, false>(a, y->n, tz, ty, tx, stream); else launch_upconv8<32, false, false>(a, y->n, tz, ty, tx, stream); }
+    }
+    return launch_status("up-convolution (2x2x2 gather GEMM)");
+  }
   MMTTA_CHECK(is_f32(x) || (variant == 3 && d->dtype == MMTTA_BF16) || variant == 1, MMTTA_ERR_UNSUPPORTED,
               "direct conv: a bf16-stored input is supported by the matrix-core up-convolution and the lanes-along-K kernel only");
   if (variant == 1) {

@@ -48,7 +48,7 @@ struct Taps {      // host-side description of one tap set
 };
 
 // One output parity class of a launch (a plain conv is a single class with all its taps).  The stride-2
-// transposed forms run their 8 classes in ONE launch: class = tile index / tiles_per_cls.
+// transposed forms run their 8 classes in ONE launch, interleaved with the tile index (class_of_tile below).
 struct ClassInfo {
   int tap0, ntaps;
   int oz, oy, ox;
@@ -80,11 +80,21 @@ struct GArgs {
   int ovec;        // 16-byte epilogue stores (out / add rows 16-byte aligned, Co % 4 == 0)
   int coef_off;    // word offset of the coefficient table behind the LDS box image
   int rowload;     // the input admits the row-structured loader (alignment, 24-bit strides, < 2^31 elements)
-  int ncls, tiles_per_cls;
+  int ncls;
   ClassInfo cls[8];
   int toff[27];   // box-relative voxel offset of each tap (int32 tables: read with SCALAR loads)
   int slab[27];   // weight slab of each tap
 };
+
+// Launch tile index -> (parity class, tile inside the class).  The classes of one tile are NEIGHBOURS in the index, the
+// 8-tap class first: the 8 XCDs each run one contiguous eighth of the index (xcd_contiguous_id), and with the classes laid
+// out one after the other XCD c ran class c alone - 1 tap's work on XCD 0 against 8 taps' on XCD 7, the launch as slow as
+// its heaviest eighth (2.4x the mean of 27/8 taps).  Interleaved, every XCD carries the same mix and the 8 classes of a tile
+// read their shared input box from one L2.
+__device__ __forceinline__ void class_of_tile(const GArgs& a, int tile, int& cidx, int& t) {
+  if (a.ncls == 8) { cidx = 7 - (tile & 7); t = tile >> 3; }
+  else { cidx = 0; t = tile; }
+}
 
 // MFMA row index v of a tile -> local voxel.  PERM (bf16 images): inside every 32-row block (4 y-rows x 8 x) the
 // rows are permuted so that the 16 lanes ds_read_b128 services together ({0-3,12-15,20-27} and {4-11,16-19,28-31})
@@ -281,9 +291,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
                                            gridDim.x * gridDim.y * gridDim.z);
   const int bx = (int)(lflat % gridDim.x);
   const int lby = (int)((lflat / gridDim.x) % gridDim.y), lbz = (int)(lflat / (gridDim.x * gridDim.y));
-  const int cidx = bx / a.tiles_per_cls;
+  int cidx, t;
+  class_of_tile(a, bx, cidx, t);
   const ClassInfo ci = a.cls[cidx];
-  int t = bx % a.tiles_per_cls;
   const int tile_in_n = t % (a.tz * a.ty * a.tx);
   const int txi = t % a.tx; t /= a.tx;
   const int tyi = t % a.ty; t /= a.ty;
@@ -1115,9 +1125,9 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
   constexpr int RB = MT / 32;
   const int tid = threadIdx.x, r = tid & 31, rg = tid >> 5;
   const int tile = blockIdx.x / RB, rb = blockIdx.x % RB;
-  const int cidx = tile / a.tiles_per_cls;
+  int cidx, t;
+  class_of_tile(a, tile, cidx, t);
   const ClassInfo ci = a.cls[cidx];
-  int t = tile % a.tiles_per_cls;
   const int tile_in_n = t % (a.tz * a.ty * a.tx);
   const int txi = t % a.tx; t /= a.tx;
   const int tyi = t % a.ty; t /= a.ty;
@@ -1202,6 +1212,36 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GArgs a, int tiles
 // torch layout W[A][B][T] (A = dim0, B = dim1, T = k^3 taps) -> P[T][Kp][Np]
 // kn_is_ba: K = B, N = A (Conv3d forward, ConvTranspose3d input gradient)
 // else    : K = A, N = B (Conv3d input gradient, ConvTranspose3d forward)
+// W'[d][k][(p, co)] of the 2x2x2 gather-GEMM up-convolution (conv_direct.hip): tap (kz, ky, kx) of a k3 s2 transposed
+// convolution belongs to exactly one (coarse offset d, output parity p) pair - per axis k = 1: (p 0, d 0); k = 0: (p 1, d 1);
+// k = 2: (p 1, d 0) - the image is in MFMA B-fragment order (lane = 32 * ((k >> 3) & 1) + column, 8 k per lane), bf16; the
+// 37 slots no tap owns are written as zeros.  One call writes the 64 (d, p) entries of one (input channel k, output channel
+// co) pair; `src` = that pair's 27 taps (null: a padded output channel, all zeros).
+__device__ __forceinline__ void upconv8_put_pair(unsigned short* img, int K, int k, int co, const float* src) {
+  for (int dp = 0; dp < 64; ++dp) {
+    const int d = dp >> 3, p = dp & 7;
+    int tap = 0;
+    bool owned = true;
+#pragma unroll
+    for (int ax = 2; ax >= 0; --ax) {                       // z, y, x: (p 0, d 0) -> k 1; (p 1, d 1) -> k 0; (p 1, d 0) -> k 2
+      const int pa = (p >> ax) & 1, da = (d >> ax) & 1;
+      owned = owned && !(pa == 0 && da == 1);
+      tap = tap * 3 + (pa == 0 ? 1 : (da == 1 ? 0 : 2));
+    }
+    const float v = (owned && src != nullptr) ? src[tap] : 0.f;
+    img[(((d * (K >> 4) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + p * 4 + co) << 3) + (k & 7)] =
+        (unsigned short)(f32x2_to_bf16x2(v, 0.f) & 0xffffu);
+  }
+}
+
+// the whole W' image of one ConvTranspose3d weight [K][N][27] (single-layer pack path)
+__global__ void pack_upconv8_kernel(const float* __restrict__ w, unsigned short* __restrict__ img, int K, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * 4) return;
+  const int k = i >> 2, co = i & 3;
+  upconv8_put_pair(img, K, k, co, co < N ? w + ((long long)k * N + co) * 27 : nullptr);
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ p, int A, int B, int T,
                                     int Kp, int Np, int kn_is_ba) {
   const long long total = (long long)T * Kp * Np;
@@ -1249,6 +1289,7 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned s
 // or 512-byte (bf16: 32 n x 8 k) runs of the image out.  ~155 MB per U-Net repack: HBM-bound.
 struct PackEntry {
   const float* w; void* p;
+  unsigned short* up8;      // fragment-ordered bf16 image of the gather-GEMM up-convolution (or null)
   int A, B, T, Kp, Np, kn_is_ba, bf16, direct;
   long long start;   // first workgroup of this entry
 };
@@ -1378,6 +1419,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __re
     const float* src = e.w + ((long long)ai * e.B + bi) * e.T;
     for (int tp = 0; tp < e.T; ++tp)
       ((float*)e.p)[(long long)tp * e.Kp * e.Np + li] = nn < N ? src[tp] : 0.f;
+    if (e.up8 != nullptr) upconv8_put_pair(e.up8, e.Kp, k, nn, nn < N ? src : nullptr);      // + the gather-GEMM image W'
     return;
   }
   if (e.T == 27) pack_tile<27>(e, lb, tile);
@@ -1667,7 +1709,7 @@ extern "C" int64_t mmtta_conv_packed_bytes(const mmtta_conv_desc* d) {
   int K, N, si; bool cl;
   op_dims(d, K, N, si, cl);
   const int T = d->ksize * d->ksize * d->ksize;
-  if (direct_applicable(d)) return (int64_t)T * K * 4 * (int64_t)sizeof(float);
+  if (direct_applicable(d)) return (int64_t)T * K * 4 * (int64_t)sizeof(float) + upconv8_image_bytes(d);
   return (int64_t)T * roundup(K, 32) * roundup(N, 32) * (int64_t)(use_bf16(d, K) ? 2 : sizeof(float));
 }
 
@@ -1693,6 +1735,9 @@ extern "C" int mmtta_conv_pack_weights(const mmtta_conv_desc* d, const float* w,
   else
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, A, B, T,
                        Kp, Np, kn_is_ba);
+  if (direct && upconv8_image_bytes(d) > 0)       // ConvTranspose3d K -> R: + the gather-GEMM image behind the tap image
+    hipLaunchKernelGGL(pack_upconv8_kernel, dim3((K * 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                       (unsigned short*)((char*)packed + (size_t)T * Kp * Np * 4), K, N);
   return launch_status("pack weights");
 }
 
@@ -1710,6 +1755,7 @@ static int fill_pack_entry(const mmtta_conv_desc* d, const float* w, void* packe
   e.Kp = direct ? K : roundup(K, 32); e.Np = direct ? 4 : roundup(N, 32);
   e.kn_is_ba = (d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_DGRAD) ? 1 : 0;
   e.bf16 = use_bf16(d, K) ? 1 : 0; e.direct = direct ? 1 : 0;
+  e.up8 = (direct && upconv8_image_bytes(d) > 0) ? (unsigned short*)((char*)packed + (size_t)e.T * e.Kp * e.Np * 4) : nullptr;
   MMTTA_CHECK(e.T == 1 || e.T == 27, MMTTA_ERR_UNSUPPORTED, "pack: ksize %d", d->ksize);
   e.start = 0;
   return MMTTA_OK;
@@ -1852,7 +1898,6 @@ extern "C" int mmtta_conv_run_sets(const mmtta_conv_desc* d, const mmtta_tensor*
   }
   Taps ht[8];
   a.ncls = g.classes ? 8 : 1;
-  a.tiles_per_cls = g.tiles_per_n * x->n;
   a.so = g.classes ? 2 : 1;
   int tap0 = 0;
   for (int cls = 0; cls < a.ncls; ++cls) {

@@ -326,8 +326,10 @@ class ConvOp:
             check(-2, "conv_packed_bytes")
         self.n_sets = max(1, int(n_sets))
         self.nb_fwd, self.nb_dgrad = int(nb_f), int(nb_d)        # bytes of ONE image (multiples of 16)
-        self.packed_fwd = torch.empty(nb_f * self.n_sets, dtype=torch.uint8, device=self.device)
-        self.packed_dgrad = torch.empty(nb_d * self.n_sets, dtype=torch.uint8, device=self.device)
+        # zero-filled once: the pack kernels write only the entries a weight owns (padding and, for the gather-GEMM
+        # up-convolution image, the slots no tap maps to stay zero)
+        self.packed_fwd = torch.zeros(nb_f * self.n_sets, dtype=torch.uint8, device=self.device)
+        self.packed_dgrad = torch.zeros(nb_d * self.n_sets, dtype=torch.uint8, device=self.device)
         self._plans: Dict[Tuple, ConvPlan] = {}
         self.need_dgrad = True
         # per-item parameter sets (None: one set for the whole batch).  `sets_ctl.use_sets` (the owning runtime) switches
@@ -437,7 +439,7 @@ class ConvOp:
             if config == 13 and (self.cin_of(desc) >= 2 or self.cout_of(desc) > 32):
                 return "chan_mfma_kernel<bf16>"
             if config == 6 and int(desc.op) == CONVT_FWD and self.k == 3 and self.stride == 2 and self.cin in (32, 64):
-                return "upconv_mfma_kernel<bf16>"
+                return "upconv8_kernel<bf16>"
         return name
 
     def cin_of(self, desc) -> int:

@@ -38,7 +38,7 @@ def bench_name(k):
     m = re.match(r"wgrad_f32_kernel<(\d+),(\d+),(\d+),(\d+)>$", k)
     if m:
         return k
-    if k.startswith(("chan_mfma_kernel", "upconv_mfma_kernel")):
+    if k.startswith(("chan_mfma_kernel", "upconv_mfma_kernel", "upconv8_kernel")):
         return re.sub(r"<.*>$", "<bf16>", k)
     return re.sub(r"<.*>$", "", k) if k.startswith(("wgrad_small", "wgrad_tiny")) else k
 

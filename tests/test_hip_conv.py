@@ -717,3 +717,47 @@ def test_bf16_stored_gradients_through_the_convolutions(cin, cout, k, stride, tr
     want = res["fp32"][2]
     err = (res["bf16"][2] - want).abs().max().item() / want.abs().max().item()
     assert err <= 3 * 2.0 ** -8, f"bf16-stored input gradient: {err:.3e} of max (three roundings to bf16)"
+
+
+@pytest.mark.parametrize("stored", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,cout,shape", [(64, 3, (1, 5, 6, 19)), (32, 1, (2, 4, 4, 8)), (64, 4, (1, 3, 9, 33)), (32, 3, (1, 8, 8, 16))])
+def test_upconvolution_as_a_gather_gemm(cin, cout, shape, stored):
+    """ConvTranspose3d K -> R (k3 s2, R <= 4) in bf16 precision (upconv8_kernel: the 27 taps regrouped as 8 coarse offsets x
+    8 output parities, W' in the packed image): norm-on-load of a bf16- or fp32-stored input, bias, per-tile statistics,
+    a fused residual operand and the accumulate path, ragged extents (tile borders on every axis), against torch fp32."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(17 + cin + cout)
+    n, d, h, w = shape
+    mod = ref_module(cin, cout, 3, 2, True)
+    x = (torch.randn(n, cin, d, h, w) * 1.5 + 0.2).to(torch.bfloat16).float()
+    mu = x.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    xin = F.relu((x - mu[:, :, None, None, None]) * rstd[:, :, None, None, None])
+    res = torch.randn(n, cout, 2 * d, 2 * h, 2 * w)
+    y_ref = mod(xin) + res
+    op = ops.ConvOp(cin, cout, 3, 2, True, "cuda", dtype=ops.BF16)
+    op.pack(mod.weight.detach().cuda().contiguous())
+    nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    x_cl = cl_bf16(x) if stored == "bf16" else cl(x)
+    y_cl = ops.new_cl(n, 2 * d, 2 * h, 2 * w, cout, "cuda", ldc=4, zero=True)
+    rows = op.stats_rows(x_cl, y_cl)
+    assert rows == n * ((d + 3) // 4) * ((h + 3) // 4) * ((w + 7) // 8), "one statistics row per coarse 4x4x8 tile"
+    stats = torch.full((rows, 2, cout), float("nan"), device="cuda")
+    bias = mod.bias.detach().cuda()
+    op.forward(x_cl, nl, bias, y_cl, stats=stats, add=cl(res))
+    torch.cuda.synchronize()
+    got = ncdhw(y_cl)
+    scale = y_ref.abs().max().item()
+    err = (got - y_ref.detach()).abs().max().item() / scale
+    assert err <= 1.5e-2, f"forward: {err:.3e}"
+    st = stats.view(n, rows // n, 2, cout).double().sum(1).cpu()
+    assert torch.allclose(st[:, 0], got.double().sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[:, 1], (got.double() ** 2).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
+    # accumulate: y += conv(x) (no add): twice the convolution part
+    y2 = ops.new_cl(n, 2 * d, 2 * h, 2 * w, cout, "cuda", ldc=4, zero=True)
+    op.forward(x_cl, nl, bias, y2)
+    op.forward(x_cl, nl, bias, y2, accumulate=True)
+    torch.cuda.synchronize()
+    want2 = 2.0 * mod(xin).detach()
+    assert (ncdhw(y2) - want2).abs().max().item() / want2.abs().max().item() <= 1.5e-2

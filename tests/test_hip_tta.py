@@ -535,7 +535,7 @@ def test_evaluator_lanes_equal_sequential_evaluation():
     from multimodal_tta_amd.registry import get_dataset_builder, get_evaluation_strategy
     results = []
     for lanes in (1, 2, 3):
-        cfg = root_cfg(SMALL, steps=2, lr=1e-3)
+        cfg = root_cfg(SMALL, steps=2, lr=1e-3, tune_volumes=4)      # one launch geometry: the lanes may not change a bit
         cfg["method"]["lanes"] = lanes
         cfg["dataset"]["synthetic"]["num_volumes"] = 5
         cfg["dataset"]["synthetic"]["shape"] = [32, 32, 32]
