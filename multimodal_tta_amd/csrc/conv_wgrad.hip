@@ -1172,6 +1172,209 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
   }
 }
 
+
+// ------------------------------------------------------------------ thin-layer weight gradient on transposed reads
+// The same contraction as wgrad_small_kernel's bf16 branch - S[(tap, cs)][cb] = sum_o Q[o*si + tap - 1][cs] * P[o][cb], 27 taps,
+// operands rounded to bf16, v_mfma_f32_32x32x16_bf16 - with BOTH operands staged once as bf16 rows and read through
+// ds_read_b64_tr_b16.  wgrad_small_kernel kept fp32 images and built every fragment from 16 ds_read_b32 + 8 packs: 95
+// vector instructions per MFMA (profiles/r03a_pmc_sq_per_kernel.txt), which is what its launches were bound by.  Here
+//  * P sits in LDS as it sits in HBM ([voxel][32 channels] bf16, 64-byte rows, NCB column blocks side by side): its fragment
+//    is wgrad_tr_kernel's - two transposed reads 4 voxels apart;
+//  * Q's box is [voxel][4 channels] bf16, 8 bytes a voxel.  A transposed read takes 4 rows x 16 columns from 16 lane
+//    addresses (row = (lane & 15) >> 2, 8-byte chunk = lane & 3) and the hardware does not care where a chunk lies: chunk
+//    lp of lane half lc is pointed at TAP 4 lc + lp of the wave's 8 taps, so the 32 columns a wave's fragment holds are
+//    (tap, channel) = (column >> 2, column & 3) - the gather costs no instruction.  Wave w owns taps 8 w .. 8 w + 7 (the 5
+//    slots past tap 26 re-read tap 26 and are dropped), one accumulator per column block;
+//  * a k step is 16 output voxels = two x-rows of the 4 x 4 x 8 tile, as in wgrad_small_kernel.
+// Staging: a thread's box voxels / tile items are the same for every tile (decoded once); offsets are 32-bit elements
+// (host check); the next tile's loads are issued before this tile's MFMAs.
+template <int SI, bool PBF, int NCB>
+__global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
+  extern __shared__ float lds[];
+  constexpr int TZ = 4, TY = 4, TX = 8, MT = 128;
+  constexpr int BZ = (TZ - 1) * SI + 3, BY = (TY - 1) * SI + 3, BX = (TX - 1) * SI + 3;
+  constexpr int boxvox = BZ * BY * BX;
+  constexpr int QBYTES = (boxvox * 8 + 63) / 64 * 64;
+  constexpr int NQ = (boxvox + 255) / 256;
+  constexpr int NI = MT * 4 * NCB / 256;              // 8-channel items of the dense tile per thread
+  unsigned char* ql = reinterpret_cast<unsigned char*>(lds);
+  unsigned char* pl = ql + QBYTES;                    // NCB planes of [128 voxels][32 channels] bf16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const int lq = (lane & 15) >> 2, lp = lane & 3, lc = (lane >> 4) & 1;
+  const int cb0 = blockIdx.y * 32 * NCB;
+
+  // operand addresses (lane parts)
+  const int tapl = min(wave * 8 + lc * 4 + lp, 26);
+  const unsigned char* aread = ql + ((((tapl / 9) + 0) * BY + (tapl / 3) % 3 + h * SI) * BX + tapl % 3 + lq * SI) * 8;
+  const unsigned char* bread = pl + (h * 8 + lq) * 64 + lc * 32 + lp * 8;
+  f32x16 acc[NCB];
+#pragma unroll
+  for (int c = 0; c < NCB; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+  // staging roles (tile-independent)
+  int qpos[NQ];                                        // box voxel of pass q: bz << 16 | by << 8 | bx
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int bv = min(tid + 256 * q, boxvox - 1);
+    qpos[q] = ((bv / (BX * BY)) << 16) | (((bv / BX) % BY) << 8) | (bv % BX);
+  }
+  const int c8 = tid % (4 * NCB), pv0 = tid / (4 * NCB);        // item p: voxel pv0 + p * (256 / (4 NCB)), channel chunk c8
+  const int pc = cb0 + 8 * c8;
+  const bool pcok = pc < a.Cb;                                  // (Cb % 8 == 0: a chunk is inside or outside as a whole)
+  const unsigned pcl = (unsigned)min(pc, a.Cb - 8);
+  unsigned char* pst = pl + (c8 >> 2) * (MT * 64) + pv0 * 64 + (c8 & 3) * 16;
+  const unsigned qsd = (unsigned)a.qsd, qsh = (unsigned)a.qsh, qsw = (unsigned)a.qsw;
+  const unsigned psd = (unsigned)a.psd, psh = (unsigned)a.psh, psw = (unsigned)a.psw;
+  const float qlo = a.tq.relu ? 0.f : -__builtin_inff(), plo = a.tp.relu ? 0.f : -__builtin_inff();
+
+  const int sx = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int qset = sx / a.S, sls = sx - qset * a.S;
+  const int t0 = qset * a.tiles_set + sls * a.tiles_per_split;
+  const int t1 = min((qset + 1) * a.tiles_set, t0 + a.tiles_per_split);
+  const int tpn = a.tz * a.ty * a.tx;
+  float4 raw[NQ];
+  Oct8<PBF> pit[NI];
+  unsigned qok = 0u, pok = 0u;
+  float qsc[4], qsf[4], psc[8], psf[8], dbs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dbs[j] = 0.f;
+  int n_coef = -1;
+  const bool want_db = a.dbpart != nullptr;
+
+  auto issue = [&](int tile) {
+    const int n = tile / tpn;
+    int t = tile % tpn;
+    const int txi = t % a.tx; t /= a.tx;
+    const int tyi = t % a.ty;
+    const int tzi = t / a.ty;
+    const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
+    const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
+    const float* qb = a.q + (long long)n * a.qsn;
+    qok = 0u;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int iz = iz0 + (qpos[q] >> 16), iy = iy0 + ((qpos[q] >> 8) & 255), ix = ix0 + (qpos[q] & 255);
+      const bool ok = (unsigned)iz < (unsigned)a.Dq && (unsigned)iy < (unsigned)a.Hq && (unsigned)ix < (unsigned)a.Wq &&
+                      tid + 256 * q < boxvox;
+      qok |= (ok ? 1u : 0u) << q;
+      const unsigned off = (unsigned)min(max(iz, 0), a.Dq - 1) * qsd + (unsigned)min(max(iy, 0), a.Hq - 1) * qsh +
+                           (unsigned)min(max(ix, 0), a.Wq - 1) * qsw;
+      raw[q] = *reinterpret_cast<const float4*>(qb + off);
+    }
+    const float* pb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.p) + (long long)n * a.psn * (PBF ? 2 : 4));
+    pok = 0u;
+#pragma unroll
+    for (int p = 0; p < NI; ++p) {
+      const int v = pv0 + p * (256 / (4 * NCB));
+      const int oz = oz0 + v / (TX * TY), oy = oy0 + (v / TX) % TY, ox = ox0 + v % TX;
+      const bool ok = pcok && oz < a.Dp && oy < a.Hp && ox < a.Wp;
+      pok |= (ok ? 1u : 0u) << p;
+      const unsigned off = (unsigned)min(oz, a.Dp - 1) * psd + (unsigned)min(oy, a.Hp - 1) * psh + (unsigned)min(ox, a.Wp - 1) * psw + pcl;
+      pit[p] = oct8_ld<PBF>(pb, off, off + 4);
+    }
+    if (n != n_coef) {
+      nl_coeff_vec<4>(a.tq, n, a.Cs, 0, qsc, qsf);
+      nl_coeff_vec<8>(a.tp, n, a.Cb, (int)pcl, psc, psf);
+      n_coef = n;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (tid + 256 * q < boxvox) {
+        const unsigned okm = ((qok >> q) & 1u) ? 0xffffffffu : 0u;
+        const float v0 = fmaxf(fmaf(raw[q].x, qsc[0], qsf[0]), qlo);
+        const float v1 = a.Cs > 1 ? fmaxf(fmaf(raw[q].y, qsc[1], qsf[1]), qlo) : 0.f;
+        const float v2 = a.Cs > 2 ? fmaxf(fmaf(raw[q].z, qsc[2], qsf[2]), qlo) : 0.f;
+        const float v3 = a.Cs > 3 ? fmaxf(fmaf(raw[q].w, qsc[3], qsf[3]), qlo) : 0.f;
+        uint2 pk;
+        pk.x = wpack2(v0, v1) & okm; pk.y = wpack2(v2, v3) & okm;
+        *reinterpret_cast<uint2*>(ql + (tid + 256 * q) * 8) = pk;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NI; ++p) {
+      float v[8];
+      oct8_f8(pit[p], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], psc[j], psf[j]), plo);
+      const unsigned okm = ((pok >> p) & 1u) ? 0xffffffffu : 0u;
+      if (want_db) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbs[j] += __uint_as_float(__float_as_uint(v[j]) & okm);
+      }
+      uint4 pk;
+      pk.x = wpack2(v[0], v[1]) & okm; pk.y = wpack2(v[2], v[3]) & okm;
+      pk.z = wpack2(v[4], v[5]) & okm; pk.w = wpack2(v[6], v[7]) & okm;
+      *reinterpret_cast<uint4*>(pst + p * (256 / (4 * NCB)) * 64) = pk;
+    }
+  };
+
+  if (t0 < t1) issue(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+    commit();
+    __syncthreads();
+    if (tile + 1 < t1) issue(tile + 1);                 // lands during the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < MT / 16; ++kk) {
+      const int roff = ((((2 * kk) / TY) * SI * BY + ((2 * kk) % TY) * SI) * BX) * 8;
+      const wbf16x8 af = __builtin_bit_cast(wbf16x8, __builtin_shufflevector(
+          __builtin_amdgcn_ds_read_tr16_b64_v4i16((wlds4_t)(aread + roff)),
+          __builtin_amdgcn_ds_read_tr16_b64_v4i16((wlds4_t)(aread + roff + 4 * SI * 8)), 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) {
+        const wbf16x8 bf = MMTTA_TR_FRAG(bread, c * (MT * 64) + kk * 1024);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[c], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int sl = sx;
+#pragma unroll
+  for (int c = 0; c < NCB; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row32 = (i & 3) + 8 * (i >> 2) + 4 * h;         // (tap of the wave, channel) = (row32 >> 2, row32 & 3)
+      const int tap = wave * 8 + (row32 >> 2), cs = row32 & 3;
+      if (tap < 27 && cs < a.Cs) a.slab[((long long)sl * 128 + tap * a.Cs + cs) * a.CBp + cb0 + c * 32 + r] = acc[c][i];
+    }
+  if (want_db) {                                    // thread (voxel slot, chunk c8) holds channels cb0 + 8 c8 .. + 7
+    float* red8 = lds;                              // the images are dead: the loop ended with a barrier
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red8[tid * 8 + j] = dbs[j];
+    __syncthreads();
+    if (tid < 32 * NCB) {
+      const int k8 = tid >> 3, j = tid & 7;
+      float sacc = 0.f;
+      for (int m = 0; m < 256 / (4 * NCB); ++m) sacc += red8[(k8 + 4 * NCB * m) * 8 + j];
+      a.dbpart[(long long)sl * a.CBp + cb0 + tid] = sacc;
+    }
+  }
+}
+
+template <int SI, bool PBF, int NCB>
+static void launch_thin_tr_t(const W2Args& a, dim3 grid, hipStream_t s) {
+  constexpr int BZ = 3 * SI + 3, BY = 3 * SI + 3, BX = 7 * SI + 3;
+  constexpr int QBYTES = (BZ * BY * BX * 8 + 63) / 64 * 64;
+  size_t lds = QBYTES + (size_t)NCB * 128 * 64;
+  if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);      // the bias-gradient reduction reuses the images
+  hipLaunchKernelGGL((wgrad_thin_tr_kernel<SI, PBF, NCB>), grid, dim3(256), lds, s, a);
+}
+
+static void launch_thin_tr(const W2Args& a, int si, int ncb, dim3 grid, hipStream_t s) {
+  if (si == 1) {
+    if (a.p_bf) { if (ncb == 2) launch_thin_tr_t<1, true, 2>(a, grid, s); else launch_thin_tr_t<1, true, 1>(a, grid, s); }
+    else { if (ncb == 2) launch_thin_tr_t<1, false, 2>(a, grid, s); else launch_thin_tr_t<1, false, 1>(a, grid, s); }
+  } else {
+    if (a.p_bf) { if (ncb == 2) launch_thin_tr_t<2, true, 2>(a, grid, s); else launch_thin_tr_t<2, true, 1>(a, grid, s); }
+    else { if (ncb == 2) launch_thin_tr_t<2, false, 2>(a, grid, s); else launch_thin_tr_t<2, false, 1>(a, grid, s); }
+  }
+}
+
 // small_is_cd == 0: dw[(cb*Cs + cs)*ntaps + tap]   (Conv3d with tiny Cin, ConvTranspose3d with tiny Cout)
 // small_is_cd == 1: dw[(cs*Cb + cb)*ntaps + tap]   (1x1x1 Conv3d with tiny Cout)
 __global__ void wgrad_small_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsl, int ntaps, int Cs,
@@ -1396,6 +1599,8 @@ struct WGeo {
   bool convt;
   bool tr;        // bf16 27-tap layer on the transposed-read kernel (its own tile shape)
   bool tr1;       // 1x1x1 layer of bf16 precision on the transposed-read streaming kernel
+  bool thin_tr;   // thin 27-tap layer of bf16 precision on the transposed-read kernel (wgrad_thin_tr_kernel)
+  int ncb;        // its 32-column blocks per workgroup
   int ips, nsets; // batch items per parameter set, sets per launch: tiles / S / nsl / *_floats / colsum_blocks are PER SET
 };
 
@@ -1420,6 +1625,8 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.convt = d->op == MMTTA_CONVT_FWD;
   w.tr = false;
   w.tr1 = false;
+  w.thin_tr = false;
+  w.ncb = 1;
   if (w.convt) MMTTA_CHECK(d->ksize == 3 && d->stride == 2, MMTTA_ERR_UNSUPPORTED, "wgrad: conv_transpose is k3 s2 only");
   w.g = w.convt ? dy : x;
   w.dn = w.convt ? x : dy;
@@ -1464,9 +1671,18 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     w.tiles = w.tz * w.ty * w.tx * w.ips;
     w.CGp = 128;
     w.CDp = roundup(w.pb->c, 32);
+    // bf16 precision, 27 taps: the transposed-read kernel when the operands admit its staging (Q: fp32 voxels of 16 bytes;
+    // P: 16-byte items of 8 channels; 32-bit element offsets inside a batch item)
+    auto q_ok = [](const mmtta_tensor* t) {
+      const int64_t last = (int64_t)(t->d - 1) * t->sd + (int64_t)(t->h - 1) * t->sh + (int64_t)(t->w - 1) * t->sw + 8;
+      return is_f32(t) && ((uintptr_t)t->ptr) % 16 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 &&
+             last < ((int64_t)1 << 31);
+    };
+    w.thin_tr = d->dtype == MMTTA_BF16 && w.ntaps == 27 && g_wgrad_vec && q_ok(w.q) && wtr_ok(w.pb) && w.pb->c % 8 == 0;
+    w.ncb = (w.thin_tr && (w.CDp / 32) % 2 == 0) ? 2 : 1;
     // slabs: one volume in flight 256 / 512 / 768 / 1024 -> 56 / 46 / 57 / 57 us per launch at 128^3; two in flight
     // (method.lanes: 2, the default) 256 edges out 512 for the whole step (41.9 vs 41.5 volumes/s): less slab traffic
-    int S = g_tune[3] / (w.CDp / 32);
+    int S = g_tune[3] / (w.CDp / 32 / w.ncb);
     if (S < 1) S = 1;
     if (S > w.tiles) S = w.tiles;
     w.tps = (w.tiles + S - 1) / S;
@@ -1569,7 +1785,7 @@ extern "C" int mmtta_conv_wgrad_kernel(const mmtta_conv_desc* d, const mmtta_ten
   const int st = wgeometry(d, x, dy, nullptr, w);
   if (st) return st < 0 ? st : -st;
   if (w.tiny) return 6;
-  if (w.small) return 3;
+  if (w.small) return w.thin_tr ? 10 : 3;
   if (w.tr1) return 9;
   if (w.tr) return w.si == 1 ? 7 : 8;
   if (w.ntaps == 1) return 2;
@@ -1634,7 +1850,9 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
     MMTTA_CHECK((w.ntaps == 27 && (w.si == 1 || w.si == 2)) || (w.ntaps == 1 && w.si == 1), MMTTA_ERR_UNSUPPORTED,
                 "wgrad (thin layer): %d taps with stride %d", w.ntaps, w.si);
     const dim3 sg(w.S * Q, w.CDp / 32);
-    if (w.ntaps == 1) {
+    if (w.thin_tr) {
+      launch_thin_tr(b, w.si, w.ncb, dim3(w.S * Q, w.CDp / 32 / w.ncb), s);
+    } else if (w.ntaps == 1) {
       if (b.p_bf) hipLaunchKernelGGL((wgrad_small_kernel<true, 1, false>), sg, dim3(256), lds, s, b);
       else hipLaunchKernelGGL((wgrad_small_kernel<false, 1, false>), sg, dim3(256), lds, s, b);
     } else if (w.si == 1) {

@@ -248,15 +248,16 @@ IGEMM_KERNELS = ["igemm_f32_kernel<1,4,8,8,8,8>", "igemm_f32_kernel<2,4,4,8,8,16
 
 WGRAD_KERNELS = ["wgrad_f32_kernel<4,4,8,7>", "wgrad_f32_kernel<2,2,8,7>", "wgrad_f32_kernel<4,4,8,1>", "wgrad_small_kernel",
                  "wgrad_bf16_kernel<4,4,1>", "wgrad_bf16_kernel<2,4,2>", "wgrad_tiny_kernel",
-                 "wgrad_tr_kernel<4,8,1>", "wgrad_tr_kernel<2,4,2>", "wgrad_tr1_kernel"]
+                 "wgrad_tr_kernel<4,8,1>", "wgrad_tr_kernel<2,4,2>", "wgrad_tr1_kernel", "wgrad_thin_tr_kernel"]
 
 
 class KernelProfiler:
     """Brackets every conv launch with events on the launch stream and books its algorithmic FLOPs
     (bench.py roofline: FLOPs per launch / measured duration).  Off unless installed in ops.PROFILER."""
 
-    def __init__(self, reps: int = 1):
+    def __init__(self, reps: int = 1, what_if: Sequence[str] = ()):
         self.records = []   # (kernel name, launches, flops, start event, end event)
+        self.what_if = tuple(what_if)       # "no_norm_on_load", "no_stats": see ConvOp._run
         # reps > 1: every profiled call is issued `reps` more times back to back between the two events, so the
         # queue stays ahead of the GPU and the host's launch latency does not leak into the measured duration
         # (outputs of accumulating calls are then wrong: use only in a throw-away pass)
@@ -414,7 +415,7 @@ class ConvOp:
             keep = desc_cl(add)
             epi = ConvEpilogue(C.pointer(keep), add_nl.struct() if add_nl is not None else _lib.norm_on_load())
         sets = self._sets(desc)
-        def launch():
+        def launch(nlr=nlr, stats=stats):
             check(
                 _lib.load().mmtta_conv_run_sets(
                     C.byref(desc), C.byref(dx), nlr, ptr(packed), ptr(bias), C.byref(epi) if epi is not None else None,
@@ -424,9 +425,16 @@ class ConvOp:
 
         launch()
         if PROFILER is not None:
+            # what-if timings (scripts/layer_times.py --what-if): the TIMED repeats alone drop the norm-on-load of the input
+            # or the statistics rows of the output; the real launch above already produced the step's values
+            kw = {}
+            if "no_norm_on_load" in PROFILER.what_if:
+                kw["nlr"] = None
+            if "no_stats" in PROFILER.what_if:
+                kw["stats"] = None
             e0 = PROFILER.begin()
             for _ in range(PROFILER.reps):
-                launch()
+                launch(**kw)
             PROFILER.end(self._kernel_name(p.config, desc, x, y), PROFILER.reps,
                          self.flops(x, y, desc) * PROFILER.reps, e0, self._detail(desc.op, x),
                          self.io_bytes(x, y, packed) * PROFILER.reps)

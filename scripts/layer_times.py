@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--group", type=int, default=8, help="volumes per launch sequence (method.group)")
     ap.add_argument("--tune-volumes", type=int, default=16, help="launch geometry of the headline arrangement")
+    ap.add_argument("--what-if", default="", help="comma list of no_norm_on_load, no_stats: the timed repeats of the forward / "
+                    "input-gradient convolutions drop that part of their work (where do a kernel's microseconds go)")
     args = ap.parse_args()
     import bench
     from multimodal_tta_amd import ops
@@ -34,7 +36,7 @@ def main():
     G = int(plug.group)
     x = torch.stack([synth_volume(i, C, shape, int(cfg["model"]["num_classes"]))["image"] for i in range(G)]).cuda()
     plug.adapt_volume(x, steps=1)
-    prof = ops.KernelProfiler(reps=args.reps)
+    prof = ops.KernelProfiler(reps=args.reps, what_if=[w for w in args.what_if.split(",") if w])
     ops.PROFILER = prof
     plug.adapt_volume(x, steps=1)
     ops.PROFILER = None

@@ -8,13 +8,14 @@ test_lean_tile_matches_the_wide_tile; 15 class-fused);
 weight-gradient ids: mmtta_conv_wgrad_kernel (0 f32 s1, 1 f32 s2, 2 1x1, 3 small-channel, 6 tiny, 7 / 8 transposed-read
 bf16 s1 / s2: the default of bf16 precision, parity cases test_transposed_read_wgrad; 0 / 1 under option 11 = 0; ids 4 / 5
 were round 1's staging-transposed bf16 kernels, removed in round 3;
-9 the 1x1x1 streaming kernel of bf16 precision, parity cases test_pointwise_conv_weight_gradient_on_transposed_reads).
+9 the 1x1x1 streaming kernel of bf16 precision, parity cases test_pointwise_conv_weight_gradient_on_transposed_reads;
+10 the thin 27-tap layers of bf16 precision on transposed reads, parity cases test_thin_wgrad_on_transposed_reads).
 VERDICT r1 P1: ids 2 and 9 (igemm <4,4,4,4,8,32>) used to be reachable only by the full-size bench."""
 import ctypes as C
 
 import torch
 
-from test_hip_conv import BF16_CASES, CASES, TR_CASES
+from test_hip_conv import BF16_CASES, CASES, THIN_TR_CASES, TR_CASES
 
 # (case, (fwd, dgrad) config in fp32 mode, the same in bf16 mode, weight-gradient kernel (fp32 mode, bf16 mode))
 DISPATCH = [
@@ -27,8 +28,8 @@ DISPATCH = [
     ((128, 136, 3, 1, False, (2, 4, 6, 8)), (5, 5), (12, 12), (0, 7)),
     ((768, 128, 3, 2, True, (1, 8, 8, 8)), (2, 5), (9, 12), (1, 8)),
     ((256, 512, 1, 1, False, (1, 4, 4, 4)), (5, 5), (12, 12), (2, 9)),
-    ((64, 3, 3, 2, True, (1, 3, 5, 70)), (6, 4), (6, 13), (3, 3)),
-    ((4, 32, 3, 2, False, (1, 16, 16, 16)), (13, 6), (13, 6), (3, 3)),
+    ((64, 3, 3, 2, True, (1, 3, 5, 70)), (6, 4), (6, 13), (3, 10)),
+    ((4, 32, 3, 2, False, (1, 16, 16, 16)), (13, 6), (13, 6), (3, 10)),
     ((3, 3, 3, 1, False, (1, 8, 8, 8)), (6, 6), (6, 6), (6, 6)),
 ]
 
@@ -88,6 +89,8 @@ def test_every_kernel_instantiation_is_reached_by_a_parity_case():
                         seen_cfg.add(int(plan0.config))
                 finally:
                     lib.mmtta_set_option(10, prev)
+            if dtype == BF16 and wg == 10:
+                assert case in THIN_TR_CASES, f"{case}: thin transposed-read instantiation without a parity case"
             if dtype == BF16 and wg in (7, 8):
                 assert case in TR_CASES, f"{case}: transposed-read instantiation without a parity case"
                 # the same layer with its module input bf16-stored (method.storage: bf16): the same kernel
@@ -103,7 +106,7 @@ def test_every_kernel_instantiation_is_reached_by_a_parity_case():
                 assert kid0 == wg - 7, f"{case} option 0: weight-gradient kernel {kid0}, expected {wg - 7}"
                 seen_wg.add(kid0)
     assert seen_cfg == set(range(15)), f"conv configs without a parity case: {sorted(set(range(15)) - seen_cfg)}"
-    live_wg = set(range(10)) - {4, 5}            # ids 4 / 5 were the round-1 staging-transposed bf16 kernels (removed in round 3)
+    live_wg = set(range(11)) - {4, 5}            # ids 4 / 5 were the round-1 staging-transposed bf16 kernels (removed in round 3)
     assert seen_wg == live_wg, f"weight-gradient kernels without a parity case: {sorted(live_wg - seen_wg)}"
     assert {2, 9} <= splitk_wide, "the 32-channel-stage igemm also needs a split-K parity case"
 

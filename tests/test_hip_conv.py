@@ -683,6 +683,67 @@ def test_pointwise_conv_weight_gradient_on_transposed_reads(case, stored):
     close("bias gradient", out[1][1], mod.bias.grad)
 
 
+THIN_TR_CASES = [
+    (4, 32, 3, 2, False, (1, 16, 16, 16)),      # first encoder layer: Q = x (4 channels, norm-on-load), P = dy, bias from P
+    (3, 32, 3, 1, False, (1, 5, 7, 11)),        # stride 1, ragged tiles
+    (1, 32, 3, 2, False, (2, 6, 10, 12)),       # one-channel stem, two batch items, odd coarse extents
+    (2, 64, 3, 1, False, (1, 4, 9, 8)),         # two column blocks per workgroup with the bias partials
+    (64, 3, 3, 2, True, (1, 3, 5, 70)),         # full-resolution up-convolution: Q = dy, P = x (norm-on-load), two column blocks
+    (32, 2, 3, 2, True, (2, 4, 4, 16)),
+    (64, 1, 3, 2, True, (1, 3, 4, 9)),
+    (96, 4, 3, 2, True, (1, 2, 3, 5)),          # three column blocks: one per workgroup
+]
+
+
+@pytest.mark.parametrize("stored", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", THIN_TR_CASES)
+def test_thin_wgrad_on_transposed_reads(cin, cout, k, stride, transposed, shape, stored):
+    """bf16 precision, 27 taps, <= 4 channels on one side: wgrad_thin_tr_kernel (both operands bf16 rows in LDS, fragments by
+    ds_read_b64_tr_b16, the taps folded into the transposed read's chunk addresses) against wgrad_small_kernel's bf16
+    branch (MMTTA_OPT_WGRAD_VECTOR_STAGING = 0: the same bf16-rounded operands, fp32 accumulation in another order) and
+    torch fp32 - with the norm-on-load of the module input, the accumulate path, the wide operand fp32- or bf16-stored."""
+    from multimodal_tta_amd import _lib, ops
+    import ctypes as C
+
+    torch.manual_seed(5 + cin + 7 * cout)
+    n, d, h, w = shape
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = (torch.randn(n, cin, d, h, w) * 1.5 + 0.25).to(torch.bfloat16).float()
+    mu = x.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    xin = F.relu((x - mu[:, :, None, None, None]) * rstd[:, :, None, None, None]).requires_grad_(True)
+    y_ref = mod(xin)
+    gy = torch.randn_like(y_ref).to(torch.bfloat16).float()
+    y_ref.backward(gy)
+    nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    wt = mod.weight.detach().cuda().contiguous()
+    wide_is_x = transposed
+    x_cl = cl_bf16(x) if (stored == "bf16" and wide_is_x) else cl(x)
+    gy_cl = cl_bf16(gy) if (stored == "bf16" and not wide_is_x) else cl(gy)
+    out = {}
+    for mode in (0, 1):
+        prev = ops.set_option(11, mode)
+        try:
+            op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+            kid = int(_lib.load().mmtta_conv_wgrad_kernel(C.byref(op.d_fwd), C.byref(ops.desc_cl(x_cl)), C.byref(ops.desc_cl(gy_cl))))
+            assert kid == (10 if mode else 3), f"option 11 = {mode}: weight-gradient kernel {kid}"
+            op.pack(wt)
+            dw = torch.empty_like(wt)
+            db = torch.empty(cout, device="cuda")
+            op.wgrad(x_cl, nl, gy_cl, dw, db)
+            op.wgrad(x_cl, nl, gy_cl, dw, db, accumulate=True)
+            torch.cuda.synchronize()
+            out[mode] = (dw.cpu() / 2, db.cpu() / 2)
+        finally:
+            ops.set_option(11, prev)
+    ref = mod.weight.grad
+    scale = ref.abs().max().item()
+    assert (out[1][0] - ref).abs().max().item() <= 1.5e-2 * scale + 1e-5
+    assert (out[1][0] - out[0][0]).abs().max().item() <= 2e-4 * scale + 1e-6, "differs from wgrad_small_kernel beyond summation order"
+    close("bias gradient", out[1][1], mod.bias.grad)
+    close("bias gradient (both kernels)", out[1][1], out[0][1])
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", [
     (32, 32, 3, 1, False, (1, 8, 8, 16)), (64, 128, 3, 2, False, (1, 6, 6, 8)), (64, 32, 3, 2, True, (1, 4, 4, 8)),
     (256, 512, 1, 1, False, (1, 4, 4, 4)), (40, 72, 3, 1, False, (2, 5, 9, 11))])
