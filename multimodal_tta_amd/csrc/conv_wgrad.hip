@@ -909,6 +909,7 @@ struct W2Args {
   int S, tiles_set;   // slabs and tiles per parameter set
   int qvec4, pvec4;
   int p_bf;        // the dense tensor P is bf16-stored (forward activation of bf16 precision)
+  int p_thin;      // wgrad_thin_tr_kernel: P has <= 4 channels too (fp32 voxels of 16 bytes)
   int bf;          // bf16 precision mode: operands rounded to bf16, 16 voxels per v_mfma_f32_32x32x16_bf16
 };
 
@@ -1188,15 +1189,23 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
 //  * a k step is 16 output voxels = two x-rows of the 4 x 4 x 8 tile, as in wgrad_small_kernel.
 // Staging: a thread's box voxels / tile items are the same for every tile (decoded once); offsets are 32-bit elements
 // (host check); the next tile's loads are issued before this tile's MFMAs.
-template <int SI, bool PBF, int NCB>
+// PM: storage of the dense operand P - 0: fp32, 8-channel items; 1: bf16, 8-channel items; 2: P is thin as well (<= 4
+// channels, fp32 voxels of 16 bytes: the full-resolution R -> R convolutions, both sides <= 4 channels): its tile rows
+// hold 4 live columns, the other 28 are zeroed once (the matrix cores are idle either way; what counts is that a voxel
+// costs a load, two packs and a store instead of wgrad_tiny_kernel's 243 FMAs on the vector ALU).
+template <int SI, int PM, int NCB>
 __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
   extern __shared__ float lds[];
-  constexpr int TZ = 4, TY = 4, TX = 8, MT = 128;
+  constexpr bool PBF = PM == 1, PTHIN = PM == 2;
+  static_assert(!PTHIN || NCB == 1, "a thin P is one column block");
+  // stride 1: 4 x 8 x 8 tiles (box 6 x 10 x 10 = 2.3 voxels read per output voxel, 2.8 with 4 x 4 x 8; twice the MFMAs
+  // behind one round of loads); stride 2: 4 x 4 x 8 (the 9 x 9 x 17 box is 6 staging passes already)
+  constexpr int TZ = 4, TY = SI == 1 ? 8 : 4, TX = 8, MT = TZ * TY * TX;
   constexpr int BZ = (TZ - 1) * SI + 3, BY = (TY - 1) * SI + 3, BX = (TX - 1) * SI + 3;
   constexpr int boxvox = BZ * BY * BX;
   constexpr int QBYTES = (boxvox * 8 + 63) / 64 * 64;
   constexpr int NQ = (boxvox + 255) / 256;
-  constexpr int NI = MT * 4 * NCB / 256;              // 8-channel items of the dense tile per thread
+  constexpr int NI = PTHIN ? 1 : MT * 4 * NCB / 256;  // items of the dense tile per thread (PTHIN: threads 0..127, one voxel each)
   unsigned char* ql = reinterpret_cast<unsigned char*>(lds);
   unsigned char* pl = ql + QBYTES;                    // NCB planes of [128 voxels][32 channels] bf16
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1222,11 +1231,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
     const int bv = min(tid + 256 * q, boxvox - 1);
     qpos[q] = ((bv / (BX * BY)) << 16) | (((bv / BX) % BY) << 8) | (bv % BX);
   }
-  const int c8 = tid % (4 * NCB), pv0 = tid / (4 * NCB);        // item p: voxel pv0 + p * (256 / (4 NCB)), channel chunk c8
+  const int c8 = PTHIN ? 0 : tid % (4 * NCB);                   // item p: voxel pv0 + p * (256 / (4 NCB)), channel chunk c8
+  const int pv0 = PTHIN ? (tid & (MT - 1)) : tid / (4 * NCB);
   const int pc = cb0 + 8 * c8;
-  const bool pcok = pc < a.Cb;                                  // (Cb % 8 == 0: a chunk is inside or outside as a whole)
-  const unsigned pcl = (unsigned)min(pc, a.Cb - 8);
+  const bool pcok = PTHIN ? tid < MT : pc < a.Cb;               // (Cb % 8 == 0: a chunk is inside or outside as a whole)
+  const unsigned pcl = PTHIN ? 0u : (unsigned)min(pc, a.Cb - 8);
   unsigned char* pst = pl + (c8 >> 2) * (MT * 64) + pv0 * 64 + (c8 & 3) * 16;
+  if constexpr (PTHIN) {                                        // columns 4..31 of the tile rows: zero for the whole launch
+    for (int i = tid; i < MT * 7; i += 256) *reinterpret_cast<uint2*>(pl + (i / 7) * 64 + 8 + (i % 7) * 8) = make_uint2(0u, 0u);
+  }
   const unsigned qsd = (unsigned)a.qsd, qsh = (unsigned)a.qsh, qsw = (unsigned)a.qsw;
   const unsigned psd = (unsigned)a.psd, psh = (unsigned)a.psh, psw = (unsigned)a.psw;
   const float qlo = a.tq.relu ? 0.f : -__builtin_inff(), plo = a.tp.relu ? 0.f : -__builtin_inff();
@@ -1238,6 +1251,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
   const int tpn = a.tz * a.ty * a.tx;
   float4 raw[NQ];
   Oct8<PBF> pit[NI];
+  float4 pthin = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned qok = 0u, pok = 0u;
   float qsc[4], qsf[4], psc[8], psf[8], dbs[8];
 #pragma unroll
@@ -1274,7 +1288,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
       const bool ok = pcok && oz < a.Dp && oy < a.Hp && ox < a.Wp;
       pok |= (ok ? 1u : 0u) << p;
       const unsigned off = (unsigned)min(oz, a.Dp - 1) * psd + (unsigned)min(oy, a.Hp - 1) * psh + (unsigned)min(ox, a.Wp - 1) * psw + pcl;
-      pit[p] = oct8_ld<PBF>(pb, off, off + 4);
+      if constexpr (PTHIN) pthin = *reinterpret_cast<const float4*>(pb + off);
+      else pit[p] = oct8_ld<PBF>(pb, off, off + 4);
     }
     if (n != n_coef) {
       nl_coeff_vec<4>(a.tq, n, a.Cs, 0, qsc, qsf);
@@ -1296,8 +1311,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
         *reinterpret_cast<uint2*>(ql + (tid + 256 * q) * 8) = pk;
       }
     }
+    if constexpr (PTHIN) {
+      if (tid < MT) {
+        const unsigned okm = (pok & 1u) ? 0xffffffffu : 0u;
+        const float raw4[4] = {pthin.x, pthin.y, pthin.z, pthin.w};
+        float v[4];
 #pragma unroll
-    for (int p = 0; p < NI; ++p) {
+        for (int j = 0; j < 4; ++j) {
+          v[j] = __uint_as_float(__float_as_uint(fmaxf(fmaf(raw4[j], psc[j], psf[j]), plo)) & (j < a.Cb ? okm : 0u));
+          dbs[j] += v[j];
+        }
+        *reinterpret_cast<uint2*>(pst) = make_uint2(wpack2(v[0], v[1]), wpack2(v[2], v[3]));
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < (PTHIN ? 0 : NI); ++p) {
       float v[8];
       oct8_f8(pit[p], v);
 #pragma unroll
@@ -1348,30 +1376,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
     for (int j = 0; j < 8; ++j) red8[tid * 8 + j] = dbs[j];
     __syncthreads();
     if (tid < 32 * NCB) {
-      const int k8 = tid >> 3, j = tid & 7;
       float sacc = 0.f;
-      for (int m = 0; m < 256 / (4 * NCB); ++m) sacc += red8[(k8 + 4 * NCB * m) * 8 + j];
+      if constexpr (PTHIN) {                        // threads 0..127 hold channels 0..3 of their voxel
+        if (tid < 4)
+          for (int m = 0; m < MT; ++m) sacc += red8[m * 8 + tid];
+      } else {
+        const int k8 = tid >> 3, j = tid & 7;
+        for (int m = 0; m < 256 / (4 * NCB); ++m) sacc += red8[(k8 + 4 * NCB * m) * 8 + j];
+      }
       a.dbpart[(long long)sl * a.CBp + cb0 + tid] = sacc;
     }
   }
 }
 
-template <int SI, bool PBF, int NCB>
+template <int SI, int PM, int NCB>
 static void launch_thin_tr_t(const W2Args& a, dim3 grid, hipStream_t s) {
-  constexpr int BZ = 3 * SI + 3, BY = 3 * SI + 3, BX = 7 * SI + 3;
+  constexpr int TY = SI == 1 ? 8 : 4;
+  constexpr int BZ = 3 * SI + 3, BY = (TY - 1) * SI + 3, BX = 7 * SI + 3;
   constexpr int QBYTES = (BZ * BY * BX * 8 + 63) / 64 * 64;
-  size_t lds = QBYTES + (size_t)NCB * 128 * 64;
+  size_t lds = QBYTES + (size_t)NCB * (4 * TY * 8) * 64;
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);      // the bias-gradient reduction reuses the images
-  hipLaunchKernelGGL((wgrad_thin_tr_kernel<SI, PBF, NCB>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((wgrad_thin_tr_kernel<SI, PM, NCB>), grid, dim3(256), lds, s, a);
 }
 
 static void launch_thin_tr(const W2Args& a, int si, int ncb, dim3 grid, hipStream_t s) {
-  if (si == 1) {
-    if (a.p_bf) { if (ncb == 2) launch_thin_tr_t<1, true, 2>(a, grid, s); else launch_thin_tr_t<1, true, 1>(a, grid, s); }
-    else { if (ncb == 2) launch_thin_tr_t<1, false, 2>(a, grid, s); else launch_thin_tr_t<1, false, 1>(a, grid, s); }
+  if (a.p_thin) {                                   // both sides thin: stride 1 only (wgeometry)
+    launch_thin_tr_t<1, 2, 1>(a, grid, s);
+  } else if (si == 1) {
+    if (a.p_bf) { if (ncb == 2) launch_thin_tr_t<1, 1, 2>(a, grid, s); else launch_thin_tr_t<1, 1, 1>(a, grid, s); }
+    else { if (ncb == 2) launch_thin_tr_t<1, 0, 2>(a, grid, s); else launch_thin_tr_t<1, 0, 1>(a, grid, s); }
   } else {
-    if (a.p_bf) { if (ncb == 2) launch_thin_tr_t<2, true, 2>(a, grid, s); else launch_thin_tr_t<2, true, 1>(a, grid, s); }
-    else { if (ncb == 2) launch_thin_tr_t<2, false, 2>(a, grid, s); else launch_thin_tr_t<2, false, 1>(a, grid, s); }
+    if (a.p_bf) { if (ncb == 2) launch_thin_tr_t<2, 1, 2>(a, grid, s); else launch_thin_tr_t<2, 1, 1>(a, grid, s); }
+    else { if (ncb == 2) launch_thin_tr_t<2, 0, 2>(a, grid, s); else launch_thin_tr_t<2, 0, 1>(a, grid, s); }
   }
 }
 
@@ -1601,6 +1637,7 @@ struct WGeo {
   bool tr1;       // 1x1x1 layer of bf16 precision on the transposed-read streaming kernel
   bool thin_tr;   // thin 27-tap layer of bf16 precision on the transposed-read kernel (wgrad_thin_tr_kernel)
   int ncb;        // its 32-column blocks per workgroup
+  bool p_thin;    // ... with <= 4 channels on the dense side as well
   int ips, nsets; // batch items per parameter set, sets per launch: tiles / S / nsl / *_floats / colsum_blocks are PER SET
 };
 
@@ -1627,6 +1664,7 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.tr1 = false;
   w.thin_tr = false;
   w.ncb = 1;
+  w.p_thin = false;
   if (w.convt) MMTTA_CHECK(d->ksize == 3 && d->stride == 2, MMTTA_ERR_UNSUPPORTED, "wgrad: conv_transpose is k3 s2 only");
   w.g = w.convt ? dy : x;
   w.dn = w.convt ? x : dy;
@@ -1643,7 +1681,16 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     return ((uintptr_t)t->ptr) % 16 == 0 && t->sc == 1 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 &&
            (long long)t->w * t->sw * 4 < (1LL << 31);
   };
+  // fp32 voxels of 16 bytes addressed by 32-bit element offsets inside a batch item (wgrad_thin_tr_kernel's thin operands)
+  auto q_ok = [](const mmtta_tensor* t) {
+    const int64_t last = (int64_t)(t->d - 1) * t->sd + (int64_t)(t->h - 1) * t->sh + (int64_t)(t->w - 1) * t->sw + 8;
+    return is_f32(t) && ((uintptr_t)t->ptr) % 16 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 &&
+           last < ((int64_t)1 << 31);
+  };
   w.tiny = !w.convt && d->cin <= 4 && d->cout <= 4 && d->ksize == 3 && d->stride == 1 && al16(x) && al16(dy);
+  // bf16 precision with the thin layers on the matrix cores (MMTTA_OPT_THIN_MFMA, like their forward / input gradient):
+  // the transposed-read kernel below instead of the fp32 vector-ALU kernel
+  if (w.tiny && d->dtype == MMTTA_BF16 && g_thin_mfma && g_wgrad_vec && q_ok(x) && q_ok(dy)) w.tiny = false;
   if (w.tiny) {
     const long long units = (long long)w.ips * dy->d * ((dy->h + 1) / 2) * ((dy->w + 63) / 64);
     long long blocks = (units + 3) / 4;
@@ -1666,23 +1713,26 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   }
   else if (w.convt && d->cout <= 4) { w.small = true; w.q = dy; w.pb = x; }
   if (w.small) {
-    w.TZ = 4; w.TY = 4; w.TX = 8;
-    w.tz = (w.pb->d + 3) / 4; w.ty = (w.pb->h + 3) / 4; w.tx = (w.pb->w + 7) / 8;
-    w.tiles = w.tz * w.ty * w.tx * w.ips;
     w.CGp = 128;
     w.CDp = roundup(w.pb->c, 32);
     // bf16 precision, 27 taps: the transposed-read kernel when the operands admit its staging (Q: fp32 voxels of 16 bytes;
     // P: 16-byte items of 8 channels; 32-bit element offsets inside a batch item)
-    auto q_ok = [](const mmtta_tensor* t) {
-      const int64_t last = (int64_t)(t->d - 1) * t->sd + (int64_t)(t->h - 1) * t->sh + (int64_t)(t->w - 1) * t->sw + 8;
-      return is_f32(t) && ((uintptr_t)t->ptr) % 16 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 &&
-             last < ((int64_t)1 << 31);
-    };
-    w.thin_tr = d->dtype == MMTTA_BF16 && w.ntaps == 27 && g_wgrad_vec && q_ok(w.q) && wtr_ok(w.pb) && w.pb->c % 8 == 0;
+    w.p_thin = w.pb->c <= 4 && w.si == 1 && g_thin_mfma;
+    w.thin_tr = d->dtype == MMTTA_BF16 && w.ntaps == 27 && g_wgrad_vec && q_ok(w.q) &&
+                (w.p_thin ? q_ok(w.pb) : (wtr_ok(w.pb) && w.pb->c % 8 == 0));
+    if (!w.thin_tr) w.p_thin = false;
     w.ncb = (w.thin_tr && (w.CDp / 32) % 2 == 0) ? 2 : 1;
+    w.TZ = 4; w.TY = (w.thin_tr && w.si == 1) ? 8 : 4; w.TX = 8;
+    w.tz = (w.pb->d + 3) / 4; w.ty = (w.pb->h + w.TY - 1) / w.TY; w.tx = (w.pb->w + 7) / 8;
+    w.tiles = w.tz * w.ty * w.tx * w.ips;
     // slabs: one volume in flight 256 / 512 / 768 / 1024 -> 56 / 46 / 57 / 57 us per launch at 128^3; two in flight
     // (method.lanes: 2, the default) 256 edges out 512 for the whole step (41.9 vs 41.5 volumes/s): less slab traffic
     int S = g_tune[3] / (w.CDp / 32 / w.ncb);
+    // the transposed-read kernel does little per tile (8 MFMAs a wave behind one round of loads): it hides its memory latency
+    // with workgroups per CU (86 - 172 registers: 3 - 5 per SIMD), so it wants 4x the slabs, down to 8 tiles each
+    // (24 volumes in flight, per group of 8, 42 -> 168 slabs per volume: 3 -> 3 at 128^3 475 -> 265 us, 4 -> 32 145 -> 123, the
+    // up-convolution 262 -> 239; 336: 238 / 128 / 241; 672 slabs: 249 / 142 / 272)
+    if (w.thin_tr) S = std::min(4 * S, std::max(1, w.tiles / 8));
     if (S < 1) S = 1;
     if (S > w.tiles) S = w.tiles;
     w.tps = (w.tiles + S - 1) / S;
@@ -1844,6 +1894,7 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
     b.p_bf = is_bf16(w.pb) ? 1 : 0;
     if (b.p_bf) b.pvec4 = (((uintptr_t)w.pb->ptr) % 8 == 0 && w.pb->sw % 4 == 0 && w.pb->sh % 4 == 0 && w.pb->sd % 4 == 0 && w.pb->sn % 4 == 0) ? 1 : 0;
     b.bf = (d->dtype == MMTTA_BF16 && w.ntaps == 27) ? 1 : 0;
+    b.p_thin = w.p_thin ? 1 : 0;
     const int ext = w.ntaps == 1 ? 0 : 2;
     const int BZ = 3 * w.si + ext + 1, BY = 3 * w.si + ext + 1, BX = 7 * w.si + ext + 1;
     const size_t lds = ((size_t)BZ * BY * BX * 4 + 128 * 32) * sizeof(float);

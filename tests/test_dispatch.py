@@ -30,7 +30,7 @@ DISPATCH = [
     ((256, 512, 1, 1, False, (1, 4, 4, 4)), (5, 5), (12, 12), (2, 9)),
     ((64, 3, 3, 2, True, (1, 3, 5, 70)), (6, 4), (6, 13), (3, 10)),
     ((4, 32, 3, 2, False, (1, 16, 16, 16)), (13, 6), (13, 6), (3, 10)),
-    ((3, 3, 3, 1, False, (1, 8, 8, 8)), (6, 6), (6, 6), (6, 6)),
+    ((3, 3, 3, 1, False, (1, 8, 8, 8)), (6, 6), (6, 6), (6, 10)),
 ]
 
 
