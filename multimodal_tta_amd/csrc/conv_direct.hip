@@ -1631,27 +1631,42 @@ __global__ __launch_bounds__(256, 2) void upconv8_kernel(DArgs a, int tiles_per_
   const unsigned isd = (unsigned)a.in.sd, ish = (unsigned)a.in.sh, isw = (unsigned)a.in.sw;
   long long tfirst, tlast;
   unit_range(tiles_per_n, xcd_contiguous_id(blockIdx.x, gridDim.x), gridDim.x, tfirst, tlast);
+  // staging roles: a thread's box items are the same for every tile (decoded once); the loads of tile t + 1 are issued
+  // right after tile t's image is complete and land under its MFMAs and epilogue (each tile used to start with a full
+  // memory latency, two workgroups per CU to hide it)
+  int pos[NIT];                                       // box voxel of item j: bz << 16 | by << 8 | bx
+  const int cv = tid % KC8;
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int bv = min(tid + 256 * j, BOXV * KC8 - 1) / KC8;
+    const int bz = bv / (BY * BX), brem = bv - bz * (BY * BX), by = brem / BX, bx = brem - by * BX;
+    pos[j] = (bz << 16) | (by << 8) | bx;
+  }
+  Oct8<INBF> raw[NIT];
+  unsigned okm = 0u;
+  auto issue = [&](long long tile) {
+    int t = (int)tile;
+    const int txi = t % tx; t /= tx;
+    const int tyi = t % ty;
+    const int tzi = t / ty;
+    const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;
+    okm = 0u;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int iz = gz0 + (pos[j] >> 16), iy = gy0 + ((pos[j] >> 8) & 255), ix = gx0 + (pos[j] & 255);
+      okm |= ((iz < a.in.d && iy < a.in.h && ix < a.in.w) ? 1u : 0u) << j;
+      const unsigned off = (unsigned)min(iz, a.in.d - 1) * isd + (unsigned)min(iy, a.in.h - 1) * ish + (unsigned)min(ix, a.in.w - 1) * isw + cv * 8;
+      raw[j] = oct8_ld<INBF>(inb, off, off + 4);
+    }
+  };
+  if (tfirst < tlast) issue(tfirst);
   for (long long tile = tfirst; tile < tlast; ++tile) {
     int t = (int)tile;
     const int txi = t % tx; t /= tx;
     const int tyi = t % ty;
     const int tzi = t / ty;
     const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;
-    // ---- stage the halo box: all loads first (clamped addresses), then transform / mask / pack
-    Oct8<INBF> raw[NIT];
-    unsigned okm = 0u;
-    int ldsoff[NIT];
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      const int i = min(tid + 256 * j, BOXV * KC8 - 1);
-      const int cv = i % KC8, bv = i / KC8;
-      const int bz = bv / (BY * BX), brem = bv - bz * (BY * BX), by = brem / BX, bx = brem - by * BX;
-      const int iz = gz0 + bz, iy = gy0 + by, ix = gx0 + bx;
-      okm |= ((iz < a.in.d && iy < a.in.h && ix < a.in.w) ? 1u : 0u) << j;
-      const unsigned off = (unsigned)min(iz, a.in.d - 1) * isd + (unsigned)min(iy, a.in.h - 1) * ish + (unsigned)min(ix, a.in.w - 1) * isw + cv * 8;
-      raw[j] = oct8_ld<INBF>(inb, off, off + 4);
-      ldsoff[j] = bv * VS + cv * 8;
-    }
+    // ---- the halo box of this tile (requested one tile ago): transform / mask / pack
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
       float v[8];
@@ -1664,9 +1679,11 @@ __global__ __launch_bounds__(256, 2) void upconv8_kernel(DArgs a, int tiles_per_
       uint4 pk;
       pk.x = f32x2_to_bf16x2(v[0], v[1]) & m; pk.y = f32x2_to_bf16x2(v[2], v[3]) & m;
       pk.z = f32x2_to_bf16x2(v[4], v[5]) & m; pk.w = f32x2_to_bf16x2(v[6], v[7]) & m;
-      if (tid + 256 * j < BOXV * KC8) *reinterpret_cast<uint4*>(lh + ldsoff[j]) = pk;
+      if (tid + 256 * j < BOXV * KC8)
+        *reinterpret_cast<uint4*>(lh + ((((pos[j] >> 16) * BY + ((pos[j] >> 8) & 255)) * BX + (pos[j] & 255)) * VS + cv * 8)) = pk;
     }
     __syncthreads();
+    if (tile + 1 < tlast) issue(tile + 1);
     // ---- 8 offsets x KS k-steps: one 32 x 32 block per wave (rows = the 4 x 8 coarse voxels of z-slice `wave`)
     ufloat16 acc;
 #pragma unroll
