@@ -49,7 +49,7 @@ PEAK_HBM_GBPS = 8000.0
 
 def mfma_peak(kernel_name: str) -> float:
     """Dense MFMA peak of the operand type the named kernel feeds the matrix cores with."""
-    bf = "bf16" in kernel_name or kernel_name.startswith("wgrad_tr_kernel")     # the transposed-read kernel is bf16-only
+    bf = "bf16" in kernel_name or kernel_name.startswith(("wgrad_tr", "wgrad_thin_tr"))     # the transposed-read kernels are bf16-only
     return PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
 
 

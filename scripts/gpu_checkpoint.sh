@@ -7,9 +7,11 @@ if [ "$2" != "notests" ]; then
 fi
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/prof -o run -- python3 $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-variants > $O/bench_traced.json 2> $O/trace.err
+# the headline arrangement (lanes x group volumes per round) needs a whole round of volumes: 24 warm-up + 24 dry-run + 24 timed
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/prof -o run -- python3 $R/bench.py --steps 24 --warmup 24 --no-cpu-baseline --no-variants > $O/bench_traced.json 2> $O/trace.err
 cd $R
 python scripts/trace_summary.py $O/prof/run_results.db > $O/kernels.md 2>> $O/trace.err
+python scripts/trace_summary.py $O/prof/run_results.db --json > $O/trace_avg_us.json 2>> $O/trace.err
 python scripts/trace_timeline.py $O/prof/run_results.db > $O/timeline.md 2>> $O/trace.err
 ls $O/prof | head; cp $O/prof/*stats*.csv $O/ 2>/dev/null; rm -rf $O/prof
 python -c "

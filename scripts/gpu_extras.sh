@@ -7,13 +7,14 @@ timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smok
 tail -1 $out/smoke.log
 run() {   # name, bench arguments...
   local name=$1; shift
-  timeout -k 10 500 python bench.py "$@" --no-cpu-baseline --no-variants > $out/bench_$name.json 2> $out/bench_$name.err || { tail -20 $out/bench_$name.err; exit 1; }
+  timeout -k 10 500 python bench.py "$@" --no-variants > $out/bench_$name.json 2> $out/bench_$name.err || { tail -20 $out/bench_$name.err; exit 1; }
   python -c "import json;d=json.load(open('$out/bench_$name.json'));r=d['roofline'];print('$name', round(d['value'],2), 'vol/s', round(d['ms_per_step'],2), 'ms;', r['kernel'], 'frac', round(r['frac'],3), '| whole volume', {k: round(v,3) for k,v in r['whole_volume'].items() if k.startswith('frac') or k.startswith('eff')})"
 }
-run hecktor_unet --task hecktor21 --steps 8 --warmup 2
-run deepfusion_brats --model unet_multimodal_deepfusion --steps 4 --warmup 1
-run unet_fp32 --precision fp32 --steps 8 --warmup 2
-run brats_full_160x192x160 --shape 160 192 160 --steps 8 --warmup 2
+# (whole rounds of lanes x group volumes: a partial round runs smaller groups)
+run hecktor_unet --task hecktor21 --steps 48 --warmup 8
+run deepfusion_brats --model unet_multimodal_deepfusion --steps 24 --warmup 4
+run unet_fp32 --precision fp32 --steps 24 --warmup 4
+run brats_full_160x192x160 --shape 160 192 160 --steps 24 --warmup 4
 if [ "$2" != "nopmc" ]; then
   bash scripts/pmc_bench.sh > $out/pmc.log 2>&1 || { tail -20 $out/pmc.log; exit 1; }
   cp gpurun_out/pmc_bench/sq_per_kernel.txt gpurun_out/pmc_bench/mem_per_kernel.txt gpurun_out/pmc_bench/traffic.json $out/
