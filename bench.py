@@ -393,7 +393,9 @@ def main():
         # (the equality check runs one volume at a time under the HEADLINE's launch geometry - the geometry fixes the summation
         # order, method.tune_volumes -; the latency figure under the geometry tuned for one volume in flight)
         for name, prec, nl, ng, tune in (("one_volume_same_geometry", args.precision, 1, 1, lanes * group),
-                                         ("one_volume", args.precision, 1, 1, None), ("fp32", "fp32", lanes, group, None)):
+                                         ("one_volume", args.precision, 1, 1, None),
+                                         ("one_lane", args.precision, 1, group, None),      # one launch sequence of `group` volumes
+                                         ("fp32", "fp32", lanes, group, None)):
             if (prec, nl, ng) == (args.precision, lanes, group):
                 continue
             a2 = argparse.Namespace(**vars(args))
