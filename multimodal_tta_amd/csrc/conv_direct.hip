@@ -1248,7 +1248,7 @@ struct PArgs {
   PSets ps;                        // per-item parameter sets (the batch item varies per thread here)
 };
 
-template <int KI>
+template <int KI, bool OBF>
 __global__ __launch_bounds__(256) void pointwise_small_k_kernel(PArgs a) {
   const int NV = a.out.c / 4;
   const long long dhw = (long long)a.out.d * a.out.h * a.out.w;
@@ -1287,12 +1287,11 @@ __global__ __launch_bounds__(256) void pointwise_small_k_kernel(PArgs a) {
       const float4 w4 = *reinterpret_cast<const float4*>(wn + (long long)k * a.Np + n0);
       o[0] = fmaf(xs[k], w4.x, o[0]); o[1] = fmaf(xs[k], w4.y, o[1]); o[2] = fmaf(xs[k], w4.z, o[2]); o[3] = fmaf(xs[k], w4.w, o[3]);
     }
-    float* op = a.out.p + ooff + n0;
     if (a.accumulate) {
-      const float4 t = *reinterpret_cast<const float4*>(op);
+      const float4 t = ld4_any(a.out.p, ooff + n0, OBF);
       o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
     }
-    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+    st4_any(a.out.p, ooff + n0, make_float4(o[0], o[1], o[2], o[3]), OBF);
   }
 }
 
@@ -1301,7 +1300,9 @@ bool pointwise_small_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x,
   if (d->ksize != 1 || d->stride != 1 || stats != nullptr || (epi && epi->add)) return false;
   if (x_norm && (x_norm->mean || x_norm->scale)) return false;
   if (!(d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONV_DGRAD)) return false;
-  return x->c <= 4 && y->c % 4 == 0 && y->c >= 4 && aligned16(x) && x->sw >= 4 && aligned16(y);
+  return x->c <= 4 && is_f32(x) && y->c % 4 == 0 && y->c >= 4 && aligned16(x) && x->sw >= 4 &&
+         (is_bf16(y) ? (y->sc == 1 && y->sw % 4 == 0 && y->sh % 4 == 0 && y->sd % 4 == 0 && y->sn % 4 == 0 && ((uintptr_t)y->ptr) % 8 == 0)
+                     : aligned16(y));
 }
 
 int pointwise_small_run(const mmtta_tensor* x, const void* packed, int Kp, int Np, const float* bias, const mmtta_tensor* y,
@@ -1312,12 +1313,16 @@ int pointwise_small_run(const mmtta_tensor* x, const void* packed, int Kp, int N
   const long long total = (long long)y->n * y->d * y->h * y->w * (y->c / 4);
   long long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  switch (x->c) {
-    case 1: hipLaunchKernelGGL(pointwise_small_k_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(pointwise_small_k_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(pointwise_small_k_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL(pointwise_small_k_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a); break;
+#define MMTTA_PW(KI) \
+  do { if (is_bf16(y)) hipLaunchKernelGGL((pointwise_small_k_kernel<KI, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a); \
+       else hipLaunchKernelGGL((pointwise_small_k_kernel<KI, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a); } while (0)
+  switch (x->c) {           // (the output may be a bf16-stored gradient: method.grad_storage)
+    case 1: MMTTA_PW(1); break;
+    case 2: MMTTA_PW(2); break;
+    case 3: MMTTA_PW(3); break;
+    default: MMTTA_PW(4); break;
   }
+#undef MMTTA_PW
   return launch_status("1x1 conv (small K)");
 }
 

@@ -1842,7 +1842,7 @@ extern "C" int mmtta_conv_run_sets(const mmtta_conv_desc* d, const mmtta_tensor*
   if (st) return st;
   const PSets ps = psets(sets);
   if (direct_applicable(d)) return direct_conv_run(d, x, x_norm, packed, bias, epi, y, accumulate, stats, ps, (hipStream_t)stream);
-  if (pointwise_small_applicable(d, x, y, stats, epi, x_norm) && !use_bf16(d, g.K) && is_f32(x) && is_f32(y))
+  if (pointwise_small_applicable(d, x, y, stats, epi, x_norm) && !use_bf16(d, g.K) && is_f32(x))      // (y: fp32- or bf16-stored)
     return pointwise_small_run(x, packed, g.Kp, g.Np, bias, y, accumulate, ps, (hipStream_t)stream);
   if (chan_applicable(d, x, y) && !use_bf16(d, g.K))
     return chan_conv_run(d, x, x_norm, packed, g.Kp, g.Np, bias, epi, y, accumulate, stats, ps, (hipStream_t)stream);

@@ -737,7 +737,8 @@ __device__ __forceinline__ int axis_weights(int i, int in, int out, int* os, flo
   return cnt;
 }
 
-template <int VEC>
+// BF: both gradients bf16-stored (method.grad_storage; offsets are elements either way)
+template <int VEC, bool BF = false>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(TV dy, TV dx, int accumulate) {
   const int C = dx.c;
   const int CV = (C + VEC - 1) / VEC;
@@ -752,31 +753,31 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(TV dy, TV dx, int acc
     const int nz = axis_weights(iz, dx.d, dy.d, oz, wz);
     const int ny = axis_weights(iy, dx.h, dy.h, oy, wy);
     const int nx = axis_weights(ix, dx.w, dy.w, ox, wx);
-    const float* gp = dy.p + (long long)n * dy.sn + c;
+    const long long gbase = (long long)n * dy.sn + c;
     float s[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s[j] = 0.f;
     for (int a = 0; a < nz; ++a)
       for (int b = 0; b < ny; ++b) {
         const float wzy = wz[a] * wy[b];
-        const float* row = gp + (long long)oz[a] * dy.sd + (long long)oy[b] * dy.sh;
+        const long long row = gbase + (long long)oz[a] * dy.sd + (long long)oy[b] * dy.sh;
         for (int k = 0; k < nx; ++k) {
           const float wgt = wzy * wx[k];
           if (VEC == 4) {
-            const float4 g4 = *reinterpret_cast<const float4*>(row + (long long)ox[k] * dy.sw);
+            const float4 g4 = ld4_any(dy.p, row + (long long)ox[k] * dy.sw, BF);
             s[0] = fmaf(wgt, g4.x, s[0]); s[1] = fmaf(wgt, g4.y, s[1]); s[2] = fmaf(wgt, g4.z, s[2]); s[3] = fmaf(wgt, g4.w, s[3]);
           } else {
-            s[0] += wgt * row[(long long)ox[k] * dy.sw];
+            s[0] += wgt * ld1_any(dy.p, row + (long long)ox[k] * dy.sw, BF);
           }
         }
       }
-    float* o = dx.p + vox_addr(dx, n, iz, iy, ix) + c;
+    const long long o = vox_addr(dx, n, iz, iy, ix) + c;
     if (VEC == 4) {
       float4 r = make_float4(s[0], s[1], s[2], s[3]);
-      if (accumulate) { const float4 t = *reinterpret_cast<const float4*>(o); r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
-      *reinterpret_cast<float4*>(o) = r;
+      if (accumulate) { const float4 t = ld4_any(dx.p, o, BF); r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+      st4_any(dx.p, o, r, BF);
     } else {
-      *o = accumulate ? *o + s[0] : s[0];
+      st1_any(dx.p, o, accumulate ? ld1_any(dx.p, o, BF) + s[0] : s[0], BF);
     }
   }
 }
@@ -1108,16 +1109,21 @@ extern "C" int mmtta_upsample2x_fwd(const mmtta_tensor* x, const mmtta_tensor* y
 }
 
 extern "C" int mmtta_upsample2x_bwd(const mmtta_tensor* dy, const mmtta_tensor* dx, int accumulate, void* stream) {
-  MMTTA_CHECK(dy == nullptr || dy->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_bwd: `dy` must be fp32-stored");
-  MMTTA_CHECK(dx == nullptr || dx->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_bwd: `dx` must be fp32-stored");
   MMTTA_CHECK(dx && dy && dx->ptr && dy->ptr, MMTTA_ERR_INVALID, "upsample bwd: null tensor");
+  MMTTA_CHECK(dy->dtype == dx->dtype, MMTTA_ERR_UNSUPPORTED, "mmtta_upsample2x_bwd: `dy` and `dx` must share one storage type");
   MMTTA_CHECK(dy->n == dx->n && dy->c == dx->c && dy->d == 2 * dx->d && dy->h == 2 * dx->h && dy->w == 2 * dx->w,
               MMTTA_ERR_INVALID, "upsample bwd: dy must be exactly 2x of dx");
   MMTTA_CHECK(is_cl(dx) && is_cl(dy), MMTTA_ERR_UNSUPPORTED, "upsample bwd: channels-last only");
   const bool v4 = vec4_rd(dy) && vec4_wr(dx);
   const long long total = (long long)dx->n * dx->d * dx->h * dx->w * (v4 ? (dx->c + 3) / 4 : dx->c);
-  if (v4) hipLaunchKernelGGL(upsample_bwd_kernel<4>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
-  else hipLaunchKernelGGL(upsample_bwd_kernel<1>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
+  const dim3 ug(grid_for(total, 16384));
+  if (is_bf16(dy)) {
+    if (v4) hipLaunchKernelGGL((upsample_bwd_kernel<4, true>), ug, dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
+    else hipLaunchKernelGGL((upsample_bwd_kernel<1, true>), ug, dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
+  } else {
+    if (v4) hipLaunchKernelGGL(upsample_bwd_kernel<4>, ug, dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
+    else hipLaunchKernelGGL(upsample_bwd_kernel<1>, ug, dim3(256), 0, (hipStream_t)stream, tv(dy), tv(dx), accumulate);
+  }
   return launch_status("upsample bwd");
 }
 

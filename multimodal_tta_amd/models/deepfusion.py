@@ -286,10 +286,12 @@ class DeepFusionRuntime(Runtime):
         M, nlev = self.M, len(self.channels)
         # bf16 precision stores the wide forward activations as bf16 (method.storage: bf16), like the U-Net: every layer kind
         # of this runtime has storage-agnostic kernels (one-channel stems on the matrix-core thin-K kernel, trilinear
-        # resample, modality means, the 1x1x1 head).  Gradients stay fp32-stored here.
+        # resample, modality means, the 1x1x1 head) - and since round 3 so has every consumer of a wide GRADIENT
+        # (method.grad_storage: the head's input gradient, trilinear-resample backward, the linear combinations).
         self.act_bf16 = (model.conv_dtype == ops.BF16 and getattr(model, "act_storage", "bf16") == "bf16"
                          and self.channels[0] in (32, 64) and all(ch % 8 == 0 and ch >= 32 for ch in self.channels)
                          and self.out_channels <= 4)
+        self.grad_bf16 = self.act_bf16 and getattr(model, "grad_storage", "bf16") == "bf16"
         encs = list(model.specific_encoders)
         self.encf = [build_residual_unit_family(self, [f"specific_encoders.{m}.layers.{i}" for m in range(M)],
                                                 [e.layers[i] for e in encs]) for i in range(nlev)]
@@ -415,31 +417,35 @@ class DeepFusionRuntime(Runtime):
         K, M, nlev = len(keep), self.M, len(c)
         mem = lambda t, m: self._member(t, M, m)
         last = st["last"]
+        # gradients of the wide tensors in the runtime's gradient storage (method.grad_storage: bf16 next to bf16-stored
+        # activations): every buffer below is read by convolutions that round it to bf16 anyway, by the norm backward and by
+        # linear combinations with fp32 arithmetic
+        gd = lambda t: dict(dtype=self.grad_dtype(t.shape[-1]))
         self.final.wgrad(last, None, dlogits)
-        d = pool.cl(("dxdec", self.nstage - 1), *last.shape)
+        d = pool.cl(("dxdec", self.nstage - 1), *last.shape, **gd(last))
         self.final.op.dgrad(dlogits, d)
         dskips = {}
         for j in range(self.nstage - 1, -1, -1):
             src, p, cat = self.cats[j]
             cout = p.shape[-1]
-            dcat = pool.cl(("dcat", j), *cat.shape[:4], cat.shape[-1], ldc=(cat.shape[-1] + 3) // 4 * 4)
+            dcat = pool.cl(("dcat", j), *cat.shape[:4], cat.shape[-1], **gd(cat))
             self.dec[j].bwd(d, dcat, accumulate=False, need_dx=True)
             dskips[j] = dcat[..., cout:]
-            dp = pool.cl(("dpre", j), *p.shape)
+            dp = pool.cl(("dpre", j), *p.shape, **gd(p))
             ops.upsample2x_bwd(dcat[..., :cout], dp)
             self.pre[j].wgrad(src, None, dp)
-            d = pool.cl(("dxdec", j - 1), *src.shape)
+            d = pool.cl(("dxdec", j - 1), *src.shape, **gd(src))
             self.pre[j].op.dgrad(dp, d)
         bcat = st["bcat"]
         self.bott.wgrad(bcat, None, d)
-        dbcat = pool.cl("dbcat", *bcat.shape)
+        dbcat = pool.cl("dbcat", *bcat.shape, **gd(bcat))
         self.bott.op.dgrad(d, dbcat)
         # fusion: fused_m = shared + T(conv(cat[shared, feat_m])); absent members get a ZERO output gradient
         fused = st["fused"]
-        dfused = pool.cl("dfused", *fused.shape)
+        dfused = pool.cl("dfused", *fused.shape, **gd(fused))
         for m in range(M):
             ops.lincomb([dbcat[..., m * c[-1]:(m + 1) * c[-1]]], [1.0 if m in keep else 0.0], mem(dfused, m))
-        dcatf = pool.cl("dcatf", *st["catf"].shape)
+        dcatf = pool.cl("dcatf", *st["catf"].shape, **gd(st["catf"]))
         self.fusion.bwd(dfused, dcatf, accumulate=False, need_dx=True)
         terms = []
         for m in keep:
@@ -447,7 +453,7 @@ class DeepFusionRuntime(Runtime):
         for m in range(M):
             if m not in keep:
                 terms.append(dbcat[..., m * c[-1]:(m + 1) * c[-1]])
-        dshared = pool.cl("dshared", *st["shared"].shape)
+        dshared = pool.cl("dshared", *st["shared"].shape, **gd(st["shared"]))
         for k0 in range(0, len(terms), 8):
             chunk = terms[k0:k0 + 8]
             ops.lincomb(chunk, [1.0] * len(chunk), dshared, accumulate=k0 > 0)
@@ -460,7 +466,7 @@ class DeepFusionRuntime(Runtime):
             if i == 0:
                 self.encf[0].bwd(dout, None, need_dx=False)
                 break
-            dx = pool.cl(("dskip", i - 1), *st["skips"][i - 1].shape)
+            dx = pool.cl(("dskip", i - 1), *st["skips"][i - 1].shape, **gd(st["skips"][i - 1]))
             stage = skip_src.index(i - 1) if (i - 1) in skip_src else None
             if stage is not None:
                 for m in range(M):

@@ -684,6 +684,33 @@ def test_pointwise_conv_weight_gradient_on_transposed_reads(case, stored):
     close("bias gradient", out[1][1], mod.bias.grad)
 
 
+@pytest.mark.parametrize("r,cout,shape", [(3, 32, (1, 5, 6, 7)), (1, 64, (2, 4, 4, 8)), (4, 32, (1, 3, 3, 130))])
+def test_head_input_gradient_into_a_bf16_stored_gradient(r, cout, shape):
+    """The input gradient of a 1x1x1 head (R <= 4 -> C channels: pointwise_small_k_kernel, fp32 arithmetic) written into a
+    bf16-stored gradient tensor (method.grad_storage in the deep-fusion decoder): round_bf16 of the fp32-stored result,
+    accumulate in the gradient's storage."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(3 + r + cout)
+    n, d, h, w = shape
+    mod = ref_module(cout, r, 1, 1, False)
+    wt = mod.weight.detach().cuda().contiguous()
+    op = ops.ConvOp(cout, r, 1, 1, False, "cuda", dtype=ops.BF16)
+    op.pack(wt)
+    gy = torch.randn(n, r, d, h, w)
+    want = torch.nn.functional.conv_transpose3d(gy, mod.weight.detach())          # dx of a 1x1x1 convolution
+    res = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        dx = ops.new_cl(n, d, h, w, cout, "cuda", ldc=ops.row_pad(cout, dt), dtype=dt, zero=True)
+        op.dgrad(cl(gy), dx)
+        op.dgrad(cl(gy), dx, accumulate=True)
+        torch.cuda.synchronize()
+        res[name] = dx.float().permute(0, 4, 1, 2, 3).cpu() / 2
+    scale = want.abs().max().item()
+    assert (res["fp32"] - want).abs().max().item() <= 2e-5 * scale + 1e-6
+    assert (res["bf16"] - want).abs().max().item() <= 3 * 2.0 ** -8 * scale
+
+
 THIN_TR_CASES = [
     (4, 32, 3, 2, False, (1, 16, 16, 16)),      # first encoder layer: Q = x (4 channels, norm-on-load), P = dy, bias from P
     (3, 32, 3, 1, False, (1, 5, 7, 11)),        # stride 1, ragged tiles

@@ -234,6 +234,35 @@ def test_upsample_trilinear(shape):
     close("upsample bwd", ncdhw(dx_cl), x.grad, rel=1e-5, abs_=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 4, 6, 8), (2, 33, 3, 4, 5), (1, 8, 8, 8, 8)])
+def test_upsample_backward_with_bf16_stored_gradients(shape):
+    """method.grad_storage: bf16 in the deep-fusion decoder - the adjoint of the trilinear resample reads a bf16-stored
+    gradient (also a channel slice of the concat gradient: 33 channels in rows of 40) and writes a bf16-stored one, fp32
+    arithmetic in between: equal to round_bf16(fp32 result on the same bf16 input) to one bf16 ulp; accumulate included."""
+    from multimodal_tta_amd import ops
+    torch.manual_seed(21)
+    n, c, d, h, w = shape
+    x = torch.randn(n, c, d, h, w, requires_grad=True)
+    up = torch.nn.Upsample(scale_factor=(2.0, 2.0, 2.0), mode="trilinear", align_corners=True)
+    ref = up(x)
+    g = torch.randn_like(ref).to(torch.bfloat16).float()
+    ref.backward(g)
+    g16 = ops.new_cl(n, 2 * d, 2 * h, 2 * w, c, "cuda", ldc=ops.row_pad(c, torch.bfloat16), zero=True, dtype=torch.bfloat16)
+    g16.copy_(g.permute(0, 2, 3, 4, 1).to(torch.bfloat16))
+    dx = ops.new_cl(n, d, h, w, c, "cuda", ldc=ops.row_pad(c, torch.bfloat16), zero=True, dtype=torch.bfloat16)
+    ops.upsample2x_bwd(g16, dx)
+    torch.cuda.synchronize()
+    got = dx.float().permute(0, 4, 1, 2, 3).cpu()
+    scale = x.grad.abs().max().item()
+    assert (got - x.grad).abs().max().item() <= 2.0 ** -8 * scale, "bf16-stored adjoint"
+    ops.upsample2x_bwd(g16, dx, accumulate=True)
+    torch.cuda.synchronize()
+    got2 = dx.float().permute(0, 4, 1, 2, 3).cpu()
+    assert (got2 - 2 * x.grad).abs().max().item() <= 3 * 2.0 ** -8 * scale, "accumulate in the gradient's storage"
+    with pytest.raises(Exception):
+        ops.upsample2x_bwd(g16, ops.new_cl(n, d, h, w, c, "cuda"))          # mixed storage is refused, loudly
+
+
 def test_lincomb_mean_and_accumulate():
     from multimodal_tta_amd import ops
     torch.manual_seed(4)
