@@ -1456,6 +1456,10 @@ static Config pick_config(int Np, int si, long long voxels, int K, bool bf) {
   if (Np == 32) return {1, 1, 4, 4, 8, bf ? 16 : 8, bf};
   // (the stride-2 64-column layers as two 32-column groups - twice the workgroups, the halo staged twice - measured 65.0
   // against 65.5 volumes/s)
+  // (round 3: the 32 -> 64 layer at 64^3 fetches 3.6x its algorithmic bytes by the PMC count - two 16-channel stages each
+  // touch half of every 64-byte voxel row of a 9 x 9 x 17 box that the L2 does not hold in between.  One 32-channel stage
+  // on the same tile (110 KB of LDS: one workgroup per CU) 200 us against 124 per group of 8; on a 2 x 4 x 8 tile 146: the
+  // launch is bound by its latency chain, not by the fabric)
   if (Np == 64) return {2, 2, 4, 4, 8, bf ? 16 : 8, bf};
   return {4, 4, 4, 4, 8, bf ? 16 : 8, bf};
 }
