@@ -941,7 +941,9 @@ __global__ __launch_bounds__(256) void direct_chan_kernel(CArgs a) {
 // z-slice per wave) gathered from the bf16 halo box, two 8-byte LDS reads (two taps) per lane and k-step; B = the lane's
 // output channel, 7 x NB fragments kept in registers for the whole tile; the accumulator layout (column = channel = lane
 // & 31) is already "lanes along N", so stores stay 128-byte rows and the statistics per-lane sums.
-template <int S, int KI, int NB, bool HAS_T>
+// XBF: the gathered <= 4-channel tensor is bf16-stored, 8 bytes a voxel (the network input of bf16 precision, round 3: this
+// kernel and the thin weight gradient round it to bf16 while staging anyway - the same values from half the bytes)
+template <int S, int KI, int NB, bool HAS_T, bool XBF = false>
 __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
   constexpr int TZ = 4, TY = 4, TX = 8;
   constexpr int BZ = (TZ - 1) * S + 3, BY = (TY - 1) * S + 3, BX = (TX - 1) * S + 3, BOX = BZ * BY * BX;
@@ -967,13 +969,15 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
     constexpr int RPP = 256 / BX, NROW = BZ * BY, NQ = (NROW + RPP - 1) / RPP;
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (HAS_T) nl_coeff_vec<4>(a.tin, n, KI, 0, sc, sh);
-    const float* inb = a.in.p + (long long)n * a.in.sn;
+    const float* inb = XBF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.in.p) + (long long)n * a.in.sn)
+                           : a.in.p + (long long)n * a.in.sn;
     const int bx = tid % BX, r0 = tid / BX;
     const int ix = ix0 + bx;
     const bool xok = (unsigned)ix < (unsigned)a.in.w && r0 < RPP;
     const unsigned xoff = (unsigned)min(max(ix, 0), a.in.w - 1) * (unsigned)a.in.sw;
     const unsigned sd = (unsigned)a.in.sd, shh = (unsigned)a.in.sh;
     float4 raw[NQ];
+    uint2 rawh[NQ];
     unsigned okm = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -982,14 +986,23 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
       const int iz = iz0 + bz, iy = iy0 + by;
       const bool ok = xok && (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h;
       okm |= (ok ? 1u : 0u) << q;
-      raw[q] = *reinterpret_cast<const float4*>(inb + ((unsigned)min(max(iz, 0), a.in.d - 1) * sd +
-                                                       (unsigned)min(max(iy, 0), a.in.h - 1) * shh + xoff));
+      const unsigned off = (unsigned)min(max(iz, 0), a.in.d - 1) * sd + (unsigned)min(max(iy, 0), a.in.h - 1) * shh + xoff;
+      if constexpr (XBF) rawh[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(inb) + off);
+      else raw[q] = *reinterpret_cast<const float4*>(inb + off);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int row = r0 + q * RPP;
       if (r0 < RPP && row < NROW) {
         const bool ok = (okm >> q) & 1u;
+        if constexpr (XBF && !HAS_T && KI == 4) {           // already what the image holds: mask and store
+          const unsigned m = ok ? 0xffffffffu : 0u;
+          box[row * BX + bx] = make_uint2(rawh[q].x & m, rawh[q].y & m);
+          continue;
+        }
+        if constexpr (XBF)
+          raw[q] = make_float4(bf16_bits_to_f32(rawh[q].x & 0xffffu), __uint_as_float(rawh[q].x & 0xffff0000u),
+                               bf16_bits_to_f32(rawh[q].y & 0xffffu), __uint_as_float(rawh[q].y & 0xffff0000u));
         float r4[4] = {raw[q].x, raw[q].y, raw[q].z, raw[q].w};
         if (KI == 1) r4[0] = a.koff == 0 ? raw[q].x : a.koff == 1 ? raw[q].y : a.koff == 2 ? raw[q].z : raw[q].w;
         float v[4];
@@ -1154,6 +1167,10 @@ bool chan_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
                       ((uintptr_t)x->ptr) % 4 == 0;
   // the kernels address with 32-bit element offsets inside a batch item (input) / a z-slice (output)
   const bool small = (long long)x->d * x->sd < (1LL << 31) && (long long)(y->h + 4) * y->sh < (1LL << 31);
+  // bf16-stored gathered tensor (8-byte voxels): the matrix-core kernel's 32-column form
+  if (is_bf16(x))
+    return d->dtype == MMTTA_BF16 && K >= 2 && K <= 4 && N == 32 && x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 &&
+           x->sn % 4 == 0 && ((uintptr_t)x->ptr) % 8 == 0 && small;
   return K <= 4 && (N == 32 || (N == 64 && d->dtype == MMTTA_BF16)) && (aligned16(x) || slice1) && x->sw >= 4 && small;
 }
 
@@ -1177,6 +1194,10 @@ static void launch_chan_k(const CArgs& a, int K, int N, int blocks, hipStream_t 
 
 template <int S, int KI, bool HAS_T>
 static void launch_chan_mfma_n(const CArgs& a, int N, int blocks, hipStream_t s) {
+  if (a.in.bf) {                     // bf16-stored gathered tensor: the 32-column forms only (first encoder convolutions)
+    hipLaunchKernelGGL((chan_mfma_kernel<S, KI, 1, HAS_T, true>), dim3(blocks), dim3(256), 0, s, a);
+    return;
+  }
   if (N > 32) hipLaunchKernelGGL((chan_mfma_kernel<S, KI, 2, HAS_T>), dim3(blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((chan_mfma_kernel<S, KI, 1, HAS_T>), dim3(blocks), dim3(256), 0, s, a);
 }
@@ -1197,7 +1218,7 @@ int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_n
   CArgs a;
   a.ps = sets;
   a.in = tv(x); a.tin = nl(x_norm); a.out = tv(y);
-  a.koff = (int)((((uintptr_t)x->ptr) % 16) / 4);
+  a.koff = is_bf16(x) ? 0 : (int)((((uintptr_t)x->ptr) % 16) / 4);
   MMTTA_CHECK(a.koff == 0 || x->c == 1, MMTTA_ERR_UNSUPPORTED, "thin-K conv: only a one-channel slice may start inside a 16-byte group");
   a.in.p -= a.koff;
   a.w = (const float*)packed; a.Kp = Kp; a.Np = Np; a.bias = bias;
@@ -1211,12 +1232,12 @@ int chan_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_n
     a.add_bf = is_bf16(ad) ? 1 : 0;
     MMTTA_CHECK((long long)(ad->h + 4) * ad->sh < (1LL << 31), MMTTA_ERR_UNSUPPORTED, "thin-K conv: epilogue `add` slice beyond 2^31 elements");
   }
-  // the <= 4-channel gathered tensor is always fp32 (network input, gradient); the 32 / 64-channel result may be
-  // bf16-stored, on the matrix-core path only
-  MMTTA_CHECK(is_f32(x), MMTTA_ERR_UNSUPPORTED, "thin-K conv: the gathered tensor must be fp32-stored");
+  // the <= 4-channel gathered tensor is fp32 (gradients, fp32 precision) or - the network input of bf16 precision - bf16
+  // with 8-byte voxels, on the matrix-core path; the 32 / 64-channel result may be bf16-stored, on that path only
   // (a bf16-stored result - the deep-fusion stems under method.storage: bf16 - takes the matrix-core kernel for one input
   // channel as well: the VALU kernel writes fp32 only)
   const bool mfma_path = d->dtype == MMTTA_BF16 && (x->c >= 2 || y->c > 32 || is_bf16(y));
+  MMTTA_CHECK(is_f32(x) || mfma_path, MMTTA_ERR_UNSUPPORTED, "thin-K conv: a bf16-stored gathered tensor needs the matrix-core path");
   MMTTA_CHECK(mfma_path || (is_f32(y) && !a.add_bf), MMTTA_ERR_UNSUPPORTED, "thin-K conv (VALU path): fp32-stored tensors only");
   MMTTA_CHECK(a.add == nullptr || (a.add_bf != 0) == is_bf16(y), MMTTA_ERR_UNSUPPORTED, "thin-K conv: the fused add must share the output's storage type");
   a.accumulate = accumulate; a.stats = stats;

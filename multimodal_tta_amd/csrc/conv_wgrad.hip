@@ -910,6 +910,7 @@ struct W2Args {
   int qvec4, pvec4;
   int p_bf;        // the dense tensor P is bf16-stored (forward activation of bf16 precision)
   int p_thin;      // wgrad_thin_tr_kernel: P has <= 4 channels too (fp32 voxels of 16 bytes)
+  int q_bf;        // wgrad_thin_tr_kernel: the thin gathered tensor Q is bf16-stored (8 bytes a voxel)
   int bf;          // bf16 precision mode: operands rounded to bf16, 16 voxels per v_mfma_f32_32x32x16_bf16
 };
 
@@ -1193,7 +1194,8 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
 // channels, fp32 voxels of 16 bytes: the full-resolution R -> R convolutions, both sides <= 4 channels): its tile rows
 // hold 4 live columns, the other 28 are zeroed once (the matrix cores are idle either way; what counts is that a voxel
 // costs a load, two packs and a store instead of wgrad_tiny_kernel's 243 FMAs on the vector ALU).
-template <int SI, int PM, int NCB>
+// QBF: the thin gathered tensor is bf16-stored, 8 bytes a voxel (the network input of bf16 precision).
+template <int SI, int PM, int NCB, bool QBF = false>
 __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
   extern __shared__ float lds[];
   constexpr bool PBF = PM == 1, PTHIN = PM == 2;
@@ -1267,7 +1269,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
     const int tzi = t / a.ty;
     const int oz0 = tzi * TZ, oy0 = tyi * TY, ox0 = txi * TX;
     const int iz0 = oz0 * SI - 1, iy0 = oy0 * SI - 1, ix0 = ox0 * SI - 1;
-    const float* qb = a.q + (long long)n * a.qsn;
+    const float* qb = QBF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.q) + (long long)n * a.qsn)
+                          : a.q + (long long)n * a.qsn;
     qok = 0u;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -1277,7 +1280,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
       qok |= (ok ? 1u : 0u) << q;
       const unsigned off = (unsigned)min(max(iz, 0), a.Dq - 1) * qsd + (unsigned)min(max(iy, 0), a.Hq - 1) * qsh +
                            (unsigned)min(max(ix, 0), a.Wq - 1) * qsw;
-      raw[q] = *reinterpret_cast<const float4*>(qb + off);
+      if constexpr (QBF) {          // two dwords of the raw register carry the four bf16 channels until they are committed
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(qb) + off);
+        raw[q].x = __uint_as_float(u.x); raw[q].y = __uint_as_float(u.y);
+      } else {
+        raw[q] = *reinterpret_cast<const float4*>(qb + off);
+      }
     }
     const float* pb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.p) + (long long)n * a.psn * (PBF ? 2 : 4));
     pok = 0u;
@@ -1302,6 +1310,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
     for (int q = 0; q < NQ; ++q) {
       if (tid + 256 * q < boxvox) {
         const unsigned okm = ((qok >> q) & 1u) ? 0xffffffffu : 0u;
+        if constexpr (QBF) {
+          const unsigned ux = __float_as_uint(raw[q].x), uy = __float_as_uint(raw[q].y);
+          raw[q] = make_float4(bf16_bits_to_f32(ux & 0xffffu), __uint_as_float(ux & 0xffff0000u),
+                               bf16_bits_to_f32(uy & 0xffffu), __uint_as_float(uy & 0xffff0000u));
+        }
         const float v0 = fmaxf(fmaf(raw[q].x, qsc[0], qsf[0]), qlo);
         const float v1 = a.Cs > 1 ? fmaxf(fmaf(raw[q].y, qsc[1], qsf[1]), qlo) : 0.f;
         const float v2 = a.Cs > 2 ? fmaxf(fmaf(raw[q].z, qsc[2], qsf[2]), qlo) : 0.f;
@@ -1396,7 +1409,11 @@ static void launch_thin_tr_t(const W2Args& a, dim3 grid, hipStream_t s) {
   constexpr int QBYTES = (BZ * BY * BX * 8 + 63) / 64 * 64;
   size_t lds = QBYTES + (size_t)NCB * (4 * TY * 8) * 64;
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);      // the bias-gradient reduction reuses the images
-  hipLaunchKernelGGL((wgrad_thin_tr_kernel<SI, PM, NCB>), grid, dim3(256), lds, s, a);
+  if (a.q_bf) {
+    if constexpr (PM != 2) hipLaunchKernelGGL((wgrad_thin_tr_kernel<SI, PM, NCB, true>), grid, dim3(256), lds, s, a);
+  } else {
+    hipLaunchKernelGGL((wgrad_thin_tr_kernel<SI, PM, NCB>), grid, dim3(256), lds, s, a);
+  }
 }
 
 static void launch_thin_tr(const W2Args& a, int si, int ncb, dim3 grid, hipStream_t s) {
@@ -1718,7 +1735,14 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     // bf16 precision, 27 taps: the transposed-read kernel when the operands admit its staging (Q: fp32 voxels of 16 bytes;
     // P: 16-byte items of 8 channels; 32-bit element offsets inside a batch item)
     w.p_thin = w.pb->c <= 4 && w.si == 1 && g_thin_mfma;
-    w.thin_tr = d->dtype == MMTTA_BF16 && w.ntaps == 27 && g_wgrad_vec && q_ok(w.q) &&
+    // (a bf16-stored Q - the network input of bf16 precision - has 8-byte voxels: this kernel only)
+    auto q_ok16 = [](const mmtta_tensor* t) {
+      const int64_t last = (int64_t)(t->d - 1) * t->sd + (int64_t)(t->h - 1) * t->sh + (int64_t)(t->w - 1) * t->sw + 8;
+      return is_bf16(t) && ((uintptr_t)t->ptr) % 8 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 &&
+             last < ((int64_t)1 << 31);
+    };
+    w.thin_tr = d->dtype == MMTTA_BF16 && w.ntaps == 27 && g_wgrad_vec &&
+                (q_ok(w.q) || (q_ok16(w.q) && !w.p_thin)) &&
                 (w.p_thin ? q_ok(w.pb) : (wtr_ok(w.pb) && w.pb->c % 8 == 0));
     if (!w.thin_tr) w.p_thin = false;
     w.ncb = (w.thin_tr && (w.CDp / 32) % 2 == 0) ? 2 : 1;
@@ -1890,11 +1914,13 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
       return ((((uintptr_t)t->ptr) % 16 == 0) && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0) ? 1 : 0;
     };
     b.qvec4 = al4(w.q); b.pvec4 = al4(w.pb);
-    MMTTA_CHECK(is_f32(w.q), MMTTA_ERR_UNSUPPORTED, "wgrad (thin layer): the <= 4-channel tensor must be fp32-stored");
+    MMTTA_CHECK(is_f32(w.q) || w.thin_tr, MMTTA_ERR_UNSUPPORTED, "wgrad (thin layer): the <= 4-channel tensor must be fp32-stored");
     b.p_bf = is_bf16(w.pb) ? 1 : 0;
     if (b.p_bf) b.pvec4 = (((uintptr_t)w.pb->ptr) % 8 == 0 && w.pb->sw % 4 == 0 && w.pb->sh % 4 == 0 && w.pb->sd % 4 == 0 && w.pb->sn % 4 == 0) ? 1 : 0;
     b.bf = (d->dtype == MMTTA_BF16 && w.ntaps == 27) ? 1 : 0;
     b.p_thin = w.p_thin ? 1 : 0;
+    b.q_bf = is_bf16(w.q) ? 1 : 0;
+    MMTTA_CHECK(!b.q_bf || w.thin_tr, MMTTA_ERR_UNSUPPORTED, "wgrad (thin layer): a bf16-stored <= 4-channel tensor needs the transposed-read kernel");
     const int ext = w.ntaps == 1 ? 0 : 2;
     const int BZ = 3 * w.si + ext + 1, BY = 3 * w.si + ext + 1, BX = 7 * w.si + ext + 1;
     const size_t lds = ((size_t)BZ * BY * BX * 4 + 128 * 32) * sizeof(float);

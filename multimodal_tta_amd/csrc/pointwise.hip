@@ -10,6 +10,7 @@ namespace mmtta {
 
 
 // ------------------------------------------------------------------ strided copy
+template <bool DBF>
 __global__ void copy_strided_kernel(TV s, TV d) {
   const long long total = (long long)d.n * d.c * d.d * d.h * d.w;
   // iterate in the destination's fastest order: if dst is channels-last, c fastest; else x fastest
@@ -29,7 +30,7 @@ __global__ void copy_strided_kernel(TV s, TV d) {
       z = (int)(t % d.d); t /= d.d;
       c = (int)(t % d.c); n = (int)(t / d.c);
     }
-    d.p[vox_addr(d, n, z, y, x) + (long long)c * d.sc] = s.p[vox_addr(s, n, z, y, x) + (long long)c * s.sc];
+    st1_any(d.p, vox_addr(d, n, z, y, x) + (long long)c * d.sc, s.p[vox_addr(s, n, z, y, x) + (long long)c * s.sc], DBF);
   }
 }
 
@@ -840,11 +841,12 @@ using namespace mmtta;
 
 extern "C" int mmtta_copy_strided(const mmtta_tensor* src, const mmtta_tensor* dst, void* stream) {
   MMTTA_CHECK(src == nullptr || src->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_copy_strided: `src` must be fp32-stored");
-  MMTTA_CHECK(dst == nullptr || dst->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_copy_strided: `dst` must be fp32-stored");
   MMTTA_CHECK(src && dst && src->ptr && dst->ptr, MMTTA_ERR_INVALID, "copy: null tensor");
   MMTTA_CHECK(same_shape(src, dst), MMTTA_ERR_INVALID, "copy: shape mismatch");
   const long long total = (long long)dst->n * dst->c * dst->d * dst->h * dst->w;
-  hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, tv(src), tv(dst));
+  // (dst may be bf16-stored: the network input of bf16 precision is rounded once here instead of by every consumer)
+  if (is_bf16(dst)) hipLaunchKernelGGL(copy_strided_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, tv(src), tv(dst));
+  else hipLaunchKernelGGL(copy_strided_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, tv(src), tv(dst));
   return launch_status("copy_strided");
 }
 

@@ -518,9 +518,14 @@ class Runtime:
         n, c, d, h, w = x.shape
         if c != self.in_channels:
             raise ValueError(f"model expects {self.in_channels} input channels, got {c}")
-        x_cl = self.pool.cl("x", n, d, h, w, c, ldc=(c + 3) // 4 * 4, zero=True)
+        x_cl = self.pool.cl("x", n, d, h, w, c, ldc=(c + 3) // 4 * 4, zero=True, dtype=self.input_dtype())
         ops.to_cl(x, out=x_cl)
         return x_cl
+
+    def input_dtype(self) -> torch.dtype:
+        """Storage of the staged network input.  Runtimes whose every reader of the input rounds it to bf16 while staging
+        (models/unet.py in bf16 precision) store it as bf16: the same values from half the bytes."""
+        return torch.float32
 
     def run_forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: NCDHW fp32 on this device -> logits as a channels-last view [N,D,H,W,R]."""

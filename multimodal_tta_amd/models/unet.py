@@ -40,6 +40,9 @@ class UNetRuntime(Runtime):
                          and all(c % 8 == 0 and c >= 32 for c in self.channels)
                          and self.in_channels <= 4 and self.out_channels <= 4)
         self.grad_bf16 = self.act_bf16 and getattr(model, "grad_storage", "bf16") == "bf16"
+        # the staged network input as bf16 too (8-byte voxels): its only readers - the first level's thin-K convolutions and
+        # their weight gradients - round it to bf16 while staging, so the results are the same bit for bit
+        self.input_bf16 = self.act_bf16 and self.channels[0] == 32 and 2 <= self.in_channels <= 4
         L = len(self.strides)
         self.L = L
         self.down: List[Any] = []
@@ -62,6 +65,9 @@ class UNetRuntime(Runtime):
                 self.upru.append(None)
         # the network input needs no gradient
         self.input_shape = None
+
+    def input_dtype(self) -> torch.dtype:
+        return torch.bfloat16 if self.input_bf16 else torch.float32
 
     def _down_block(self, prefix: str, cont: nn.Module):
         if isinstance(cont, ResidualUnit):

@@ -711,6 +711,67 @@ def test_head_input_gradient_into_a_bf16_stored_gradient(r, cout, shape):
     assert (res["bf16"] - want).abs().max().item() <= 3 * 2.0 ** -8 * scale
 
 
+def cl_thin_bf16(x):
+    """NCDHW cpu fp32 (<= 4 channels) -> bf16-stored channels-last cuda view with 8-byte voxels."""
+    from multimodal_tta_amd import ops
+    n, c, d, h, w = x.shape
+    out = ops.new_cl(n, d, h, w, c, "cuda", ldc=4, zero=True, dtype=torch.bfloat16)
+    ops.to_cl(x.cuda().contiguous(), out=out)          # mmtta_copy_strided rounds on the way (round to nearest even)
+    return out
+
+
+@pytest.mark.parametrize("with_norm", [False, True])
+@pytest.mark.parametrize("cin,stride,shape", [(4, 2, (1, 16, 16, 16)), (2, 2, (2, 6, 10, 12)), (3, 1, (1, 5, 7, 11)), (4, 1, (1, 4, 9, 8))])
+def test_bf16_stored_network_input_gives_the_same_bits(cin, stride, shape, with_norm):
+    """The staged network input of bf16 precision is bf16-stored with 8-byte voxels (models/unet.py::input_dtype): the thin-K
+    forward (chan_mfma_kernel) and the thin weight gradient (wgrad_thin_tr_kernel) round their gathered operand to bf16 while
+    staging, so a bf16-representable input gives the SAME BITS from either storage - output, statistics, weight and bias
+    gradient; with a norm-on-load in front the fp32 transform is applied to the same values.  mmtta_copy_strided into a
+    bf16 destination rounds to nearest even."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(40 + cin + stride)
+    n, d, h, w = shape
+    cout = 32
+    mod = ref_module(cin, cout, 3, stride, False)
+    x_raw = torch.randn(n, cin, d, h, w) * 1.5 + 0.25
+    x = x_raw.to(torch.bfloat16).float()
+    x16 = cl_thin_bf16(x_raw)
+    assert torch.equal(x16.float().permute(0, 4, 1, 2, 3).cpu(), x), "copy_strided -> bf16 is round-to-nearest-even"
+    nl = None
+    if with_norm:
+        mu = x.mean(dim=(2, 3, 4))
+        rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+        nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    op = ops.ConvOp(cin, cout, 3, stride, False, "cuda", dtype=ops.BF16)
+    wt = mod.weight.detach().cuda().contiguous()
+    op.pack(wt)
+    gy = None
+    res = {}
+    for name, xin in (("fp32", cl(x)), ("bf16", x16)):
+        y = ops.new_cl(*op.out_shape(xin)[:4], cout, "cuda", ldc=ops.row_pad(cout, torch.bfloat16), dtype=torch.bfloat16)
+        rows = op.stats_rows(xin, y)
+        stats = torch.empty((rows, 2, cout), device="cuda")
+        op.forward(xin, nl, mod.bias.detach().cuda(), y, stats=stats)
+        if gy is None:
+            gy = torch.randn(n, cout, *y.shape[1:4]).to(torch.bfloat16).float()
+        dw = torch.empty_like(wt)
+        db = torch.empty(cout, device="cuda")
+        op.wgrad(xin, nl, cl_bf16(gy), dw, db)
+        torch.cuda.synchronize()
+        res[name] = (y.clone(), stats.clone(), dw.clone(), db.clone())
+    for i, what in enumerate(("output", "statistics rows", "weight gradient", "bias gradient")):
+        assert torch.equal(res["fp32"][i], res["bf16"][i]), f"{what} differs between the fp32- and the bf16-stored input"
+    # and against torch (operand rounding bound of the bf16 kernels)
+    xin_ref = x if nl is None else F.relu((x - mu[:, :, None, None, None]) * rstd[:, :, None, None, None])
+    xin_ref = xin_ref.clone().requires_grad_(True)
+    y_ref = mod(xin_ref)
+    y_ref.backward(gy)
+    got = res["bf16"][0].float().permute(0, 4, 1, 2, 3).cpu()
+    assert (got - y_ref.detach()).abs().max().item() <= 1.5e-2 * y_ref.abs().max().item()
+    assert (res["bf16"][2].cpu() - mod.weight.grad).abs().max().item() <= 1.5e-2 * mod.weight.grad.abs().max().item()
+
+
 THIN_TR_CASES = [
     (4, 32, 3, 2, False, (1, 16, 16, 16)),      # first encoder layer: Q = x (4 channels, norm-on-load), P = dy, bias from P
     (3, 32, 3, 1, False, (1, 5, 7, 11)),        # stride 1, ragged tiles
