@@ -491,7 +491,9 @@ __global__ __launch_bounds__(256) void direct_row_kernel(DArgs a) {
 typedef short cs4 __attribute__((ext_vector_type(4)));
 typedef float cf4v __attribute__((ext_vector_type(4)));
 
-template <bool HAS_T, int TZ>
+// GBF: input, output and the fused-add / accumulate operands are bf16-stored with 8-byte voxels (the input-gradient launch
+// when the thin gradients are bf16-stored, round 3: the operands are rounded to bf16 while staging either way)
+template <bool HAS_T, int TZ, bool GBF = false>
 __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
   // 8 x 8 x 64 tile: the halo box is 1.6x the tile.  The box rows are padded to 68 voxels so that a staging item is a run
   // of 4 voxels along x (one decode, one row address, four 16-byte loads): phase timing of the first version showed 26 of
@@ -527,7 +529,8 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
     for (int k = 0; k < 4; ++k)
       if (k >= a.K) { sc[k] = 0.f; sh[k] = 0.f; }                   // pad lanes of the voxel row may hold anything
     const float relu_lo = (HAS_T && a.tin.relu) ? 0.f : -__builtin_inff();
-    const float* inb = a.in.p + (long long)n * a.in.sn;
+    const float* inb = GBF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.in.p) + (long long)n * a.in.sn)
+                           : a.in.p + (long long)n * a.in.sn;
     const unsigned isw = (unsigned)a.in.sw;
 #pragma unroll 1
     for (int j0 = 0; j0 < NIT; j0 += RND) {
@@ -539,11 +542,17 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
         const int bz = v / (BY * RUNS), rem = v - bz * (BY * RUNS), by = rem / RUNS, run = rem - by * RUNS;
         const int iz = oz0 - 1 + bz, iy = oy0 - 1 + by, ix = ox0 - 1 + 4 * run;
         const bool rok = (unsigned)iz < (unsigned)a.in.d && (unsigned)iy < (unsigned)a.in.h;
-        const float* row = inb + (long long)min(max(iz, 0), a.in.d - 1) * a.in.sd + (long long)min(max(iy, 0), a.in.h - 1) * a.in.sh;
+        const long long rowo = (long long)min(max(iz, 0), a.in.d - 1) * a.in.sd + (long long)min(max(iy, 0), a.in.h - 1) * a.in.sh;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           okm |= ((rok && (unsigned)(ix + q) < (unsigned)a.in.w) ? 1u : 0u) << (4 * j + q);
-          raw[j][q] = *reinterpret_cast<const float4*>(row + (unsigned)min(max(ix + q, 0), a.in.w - 1) * isw);
+          const long long eo = rowo + (unsigned)min(max(ix + q, 0), a.in.w - 1) * isw;
+          if constexpr (GBF) {          // the four bf16 channels travel in two dwords of the raw register
+            const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(inb) + eo);
+            raw[j][q].x = __uint_as_float(u.x); raw[j][q].y = __uint_as_float(u.y);
+          } else {
+            raw[j][q] = *reinterpret_cast<const float4*>(inb + eo);
+          }
         }
       }
 #pragma unroll
@@ -551,6 +560,11 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
         uint2 pk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if constexpr (GBF) {
+            const unsigned ux = __float_as_uint(raw[j][q].x), uy = __float_as_uint(raw[j][q].y);
+            raw[j][q] = make_float4(bf16_bits_to_f32(ux & 0xffffu), __uint_as_float(ux & 0xffff0000u),
+                                    bf16_bits_to_f32(uy & 0xffffu), __uint_as_float(uy & 0xffff0000u));
+          }
           const float xs[4] = {raw[j][q].x, raw[j][q].y, raw[j][q].z, raw[j][q].w};
           float v4[4];
 #pragma unroll
@@ -600,14 +614,14 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { addn[q][r] = 0.f; oldn[q][r] = 0.f; }
       if (a.add) {
-        const float* ap = a.add + (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash;
+        const long long ao = (long long)n * a.asn + (long long)oz * a.asd + (long long)oy * a.ash;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) addn[q][r] = ap[xoff_a[r] + jl];
+        for (int r = 0; r < 4; ++r) addn[q][r] = ld1_t<GBF>(a.add, ao + xoff_a[r] + jl);
       }
       if (a.accumulate) {
-        const float* op = a.out.p + (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh;
+        const long long oo = (long long)n * a.out.sn + (long long)oz * a.out.sd + (long long)oy * a.out.sh;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) oldn[q][r] = op[xoff_o[r] + jl];
+        for (int r = 0; r < 4; ++r) oldn[q][r] = ld1_t<GBF>(a.out.p, oo + xoff_o[r] + jl);
       }
     }
   };
@@ -643,12 +657,25 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
     for (int q = 0; q < 2; ++q) {
       const int oz = oz0 + (r0 + q) / TY, oy = oy0 + (r0 + q) % TY;
       const bool rowok = oz < a.out.d && oy < a.out.h;
-      float* orow = a.out.p + (long long)n * a.out.sn + (long long)min(oz, a.out.d - 1) * a.out.sd + (long long)min(oy, a.out.h - 1) * a.out.sh;
+      const long long orowo = (long long)n * a.out.sn + (long long)min(oz, a.out.d - 1) * a.out.sd + (long long)min(oy, a.out.h - 1) * a.out.sh;
+      float* orow = a.out.p + orowo;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[q][r] + bias;
         if (a.add) v += nl_apply(addc[q][r], asc, ash, a.tadd.relu);
         if (a.accumulate) v += oldc[q][r];
+        if constexpr (GBF) {
+          // 8-byte voxels: channel lanes pair up, the even one stores both as one dword (a 2-byte store per lane is a partial
+          // dword write); channels >= N are stored as zeros (the rows own their pad)
+          v = jc < a.N ? v : 0.f;
+          const float other = __shfl_xor(v, 1, 64);
+          if (rowok && ((xok >> r) & 1u)) {
+            if (!(jc & 1))
+              *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned short*>(a.out.p) + orowo + xoff_o[r] + jc) = f32x2_to_bf16x2(v, other);
+            if (jc < a.N) { ssum += v; ssq += v * v; }
+          }
+          continue;
+        }
         if (rowok && ((xok >> r) & 1u)) {
           if (jc < a.N) {
             orow[xoff_o[r] + jc] = v;
@@ -1167,10 +1194,10 @@ bool chan_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
                       ((uintptr_t)x->ptr) % 4 == 0;
   // the kernels address with 32-bit element offsets inside a batch item (input) / a z-slice (output)
   const bool small = (long long)x->d * x->sd < (1LL << 31) && (long long)(y->h + 4) * y->sh < (1LL << 31);
-  // bf16-stored gathered tensor (8-byte voxels): the matrix-core kernel's 32-column form
+  // bf16-stored gathered tensor (8-byte voxels): the matrix-core kernel
   if (is_bf16(x))
-    return d->dtype == MMTTA_BF16 && K >= 2 && K <= 4 && N == 32 && x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 && x->sd % 4 == 0 &&
-           x->sn % 4 == 0 && ((uintptr_t)x->ptr) % 8 == 0 && small;
+    return d->dtype == MMTTA_BF16 && K <= 4 && ((N == 32 && K >= 2) || N == 64) && x->sc == 1 && x->sw % 4 == 0 && x->sh % 4 == 0 &&
+           x->sd % 4 == 0 && x->sn % 4 == 0 && ((uintptr_t)x->ptr) % 8 == 0 && small;
   return K <= 4 && (N == 32 || (N == 64 && d->dtype == MMTTA_BF16)) && (aligned16(x) || slice1) && x->sw >= 4 && small;
 }
 
@@ -1194,8 +1221,9 @@ static void launch_chan_k(const CArgs& a, int K, int N, int blocks, hipStream_t 
 
 template <int S, int KI, bool HAS_T>
 static void launch_chan_mfma_n(const CArgs& a, int N, int blocks, hipStream_t s) {
-  if (a.in.bf) {                     // bf16-stored gathered tensor: the 32-column forms only (first encoder convolutions)
-    hipLaunchKernelGGL((chan_mfma_kernel<S, KI, 1, HAS_T, true>), dim3(blocks), dim3(256), 0, s, a);
+  if (a.in.bf) {                     // bf16-stored gathered tensor (network input; thin gradients)
+    if (N > 32) hipLaunchKernelGGL((chan_mfma_kernel<S, KI, 2, HAS_T, true>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((chan_mfma_kernel<S, KI, 1, HAS_T, true>), dim3(blocks), dim3(256), 0, s, a);
     return;
   }
   if (N > 32) hipLaunchKernelGGL((chan_mfma_kernel<S, KI, 2, HAS_T>), dim3(blocks), dim3(256), 0, s, a);
@@ -1866,7 +1894,12 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   const int variant = direct_variant(d, x);
   // bf16-stored operands: only the INPUT of the matrix-core up-convolution (the 64 / 32-channel concat buffer); the
   // <= 4-channel results and every other direct variant work on fp32-stored tensors
-  MMTTA_CHECK(is_f32(y) && !(epi && epi->add && is_bf16(epi->add)), MMTTA_ERR_UNSUPPORTED, "direct conv: outputs are fp32-stored");
+  // ... except the 4x4x4 matrix-tile convolution with ALL its thin tensors bf16-stored (8-byte voxels: the input-gradient
+  // launch under bf16-stored thin gradients)
+  const bool thin_bf = variant == 4 && is_bf16(x) && is_bf16(y) && (!(epi && epi->add) || is_bf16(epi->add)) &&
+                       x->sw == 4 && y->sw == 4 && ((y->flags & MMTTA_TENSOR_OWNS_PAD) || y->c == 4) && ((uintptr_t)y->ptr) % 8 == 0 &&
+                       (!(epi && epi->add) || epi->add->sw == 4);
+  MMTTA_CHECK(thin_bf || (is_f32(y) && !(epi && epi->add && is_bf16(epi->add))), MMTTA_ERR_UNSUPPORTED, "direct conv: outputs are fp32-stored");
   if (variant == 5) {
     const int tz = (x->d + 3) / 4, ty = (x->h + 3) / 4, tx = (x->w + 7) / 8;
     if (is_bf16(x)) {
@@ -1878,7 +1911,7 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
     }
     return launch_status("up-convolution (2x2x2 gather GEMM)");
   }
-  MMTTA_CHECK(is_f32(x) || (variant == 3 && d->dtype == MMTTA_BF16) || variant == 1, MMTTA_ERR_UNSUPPORTED,
+  MMTTA_CHECK(is_f32(x) || (variant == 3 && d->dtype == MMTTA_BF16) || variant == 1 || thin_bf, MMTTA_ERR_UNSUPPORTED,
               "direct conv: a bf16-stored input is supported by the matrix-core up-convolution and the lanes-along-K kernel only");
   if (variant == 1) {
     const size_t kl_lds = (size_t)T * a.K * 16 + 32 * sizeof(float);
@@ -1892,6 +1925,19 @@ int direct_conv_run(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta
   }
   if (variant == 4) {
     const dim3 grid(a.blocks_per_n, y->n), block(256);
+    if (thin_bf) {
+      if (g_thin_mfma == 3) {
+        if (has_t) hipLaunchKernelGGL((conv3_mfma4_kernel<true, 2, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((conv3_mfma4_kernel<false, 2, true>), grid, block, 0, stream, a);
+      } else if (g_thin_mfma == 2) {
+        if (has_t) hipLaunchKernelGGL((conv3_mfma4_kernel<true, 4, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((conv3_mfma4_kernel<false, 4, true>), grid, block, 0, stream, a);
+      } else {
+        if (has_t) hipLaunchKernelGGL((conv3_mfma4_kernel<true, 8, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((conv3_mfma4_kernel<false, 8, true>), grid, block, 0, stream, a);
+      }
+      return launch_status("direct conv (4x4x4 matrix tiles, bf16-stored thin tensors)");
+    }
     if (g_thin_mfma == 3) {
       if (has_t) hipLaunchKernelGGL((conv3_mfma4_kernel<true, 2>), grid, block, 0, stream, a);
       else hipLaunchKernelGGL((conv3_mfma4_kernel<false, 2>), grid, block, 0, stream, a);

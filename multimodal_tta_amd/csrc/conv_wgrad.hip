@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(W2Args a) {
 template <int SI, int PM, int NCB, bool QBF = false>
 __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
   extern __shared__ float lds[];
-  constexpr bool PBF = PM == 1, PTHIN = PM == 2;
+  constexpr bool PBF = PM == 1, PTHIN = PM >= 2, PTBF = PM == 3;      // PM 3: the thin P is bf16-stored (8-byte voxels)
   static_assert(!PTHIN || NCB == 1, "a thin P is one column block");
   // stride 1: 4 x 8 x 8 tiles (box 6 x 10 x 10 = 2.3 voxels read per output voxel, 2.8 with 4 x 4 x 8; twice the MFMAs
   // behind one round of loads); stride 2: 4 x 4 x 8 (the 9 x 9 x 17 box is 6 staging passes already)
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
         raw[q] = *reinterpret_cast<const float4*>(qb + off);
       }
     }
-    const float* pb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.p) + (long long)n * a.psn * (PBF ? 2 : 4));
+    const float* pb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.p) + (long long)n * a.psn * ((PBF || PTBF) ? 2 : 4));
     pok = 0u;
 #pragma unroll
     for (int p = 0; p < NI; ++p) {
@@ -1296,8 +1296,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
       const bool ok = pcok && oz < a.Dp && oy < a.Hp && ox < a.Wp;
       pok |= (ok ? 1u : 0u) << p;
       const unsigned off = (unsigned)min(oz, a.Dp - 1) * psd + (unsigned)min(oy, a.Hp - 1) * psh + (unsigned)min(ox, a.Wp - 1) * psw + pcl;
-      if constexpr (PTHIN) pthin = *reinterpret_cast<const float4*>(pb + off);
-      else pit[p] = oct8_ld<PBF>(pb, off, off + 4);
+      if constexpr (PTBF) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(pb) + off);
+        pthin.x = __uint_as_float(u.x); pthin.y = __uint_as_float(u.y);
+      } else if constexpr (PTHIN) {
+        pthin = *reinterpret_cast<const float4*>(pb + off);
+      } else {
+        pit[p] = oct8_ld<PBF>(pb, off, off + 4);
+      }
     }
     if (n != n_coef) {
       nl_coeff_vec<4>(a.tq, n, a.Cs, 0, qsc, qsf);
@@ -1327,6 +1333,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_tr_kernel(W2Args a) {
     if constexpr (PTHIN) {
       if (tid < MT) {
         const unsigned okm = (pok & 1u) ? 0xffffffffu : 0u;
+        if constexpr (PTBF) {
+          const unsigned ux = __float_as_uint(pthin.x), uy = __float_as_uint(pthin.y);
+          pthin = make_float4(bf16_bits_to_f32(ux & 0xffffu), __uint_as_float(ux & 0xffff0000u),
+                              bf16_bits_to_f32(uy & 0xffffu), __uint_as_float(uy & 0xffff0000u));
+        }
         const float raw4[4] = {pthin.x, pthin.y, pthin.z, pthin.w};
         float v[4];
 #pragma unroll
@@ -1410,7 +1421,7 @@ static void launch_thin_tr_t(const W2Args& a, dim3 grid, hipStream_t s) {
   size_t lds = QBYTES + (size_t)NCB * (4 * TY * 8) * 64;
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);      // the bias-gradient reduction reuses the images
   if (a.q_bf) {
-    if constexpr (PM != 2) hipLaunchKernelGGL((wgrad_thin_tr_kernel<SI, PM, NCB, true>), grid, dim3(256), lds, s, a);
+    if constexpr (PM < 2) hipLaunchKernelGGL((wgrad_thin_tr_kernel<SI, PM, NCB, true>), grid, dim3(256), lds, s, a);
   } else {
     hipLaunchKernelGGL((wgrad_thin_tr_kernel<SI, PM, NCB>), grid, dim3(256), lds, s, a);
   }
@@ -1418,7 +1429,7 @@ static void launch_thin_tr_t(const W2Args& a, dim3 grid, hipStream_t s) {
 
 static void launch_thin_tr(const W2Args& a, int si, int ncb, dim3 grid, hipStream_t s) {
   if (a.p_thin) {                                   // both sides thin: stride 1 only (wgeometry)
-    launch_thin_tr_t<1, 2, 1>(a, grid, s);
+    if (a.p_bf) launch_thin_tr_t<1, 3, 1>(a, grid, s); else launch_thin_tr_t<1, 2, 1>(a, grid, s);
   } else if (si == 1) {
     if (a.p_bf) { if (ncb == 2) launch_thin_tr_t<1, 1, 2>(a, grid, s); else launch_thin_tr_t<1, 1, 1>(a, grid, s); }
     else { if (ncb == 2) launch_thin_tr_t<1, 0, 2>(a, grid, s); else launch_thin_tr_t<1, 0, 1>(a, grid, s); }
@@ -1704,10 +1715,15 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     return is_f32(t) && ((uintptr_t)t->ptr) % 16 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 &&
            last < ((int64_t)1 << 31);
   };
+  auto q_ok16 = [](const mmtta_tensor* t) {          // ... or bf16 voxels of 8 bytes
+    const int64_t last = (int64_t)(t->d - 1) * t->sd + (int64_t)(t->h - 1) * t->sh + (int64_t)(t->w - 1) * t->sw + 8;
+    return is_bf16(t) && ((uintptr_t)t->ptr) % 8 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 &&
+           last < ((int64_t)1 << 31);
+  };
   w.tiny = !w.convt && d->cin <= 4 && d->cout <= 4 && d->ksize == 3 && d->stride == 1 && al16(x) && al16(dy);
   // bf16 precision with the thin layers on the matrix cores (MMTTA_OPT_THIN_MFMA, like their forward / input gradient):
   // the transposed-read kernel below instead of the fp32 vector-ALU kernel
-  if (w.tiny && d->dtype == MMTTA_BF16 && g_thin_mfma && g_wgrad_vec && q_ok(x) && q_ok(dy)) w.tiny = false;
+  if (w.tiny && d->dtype == MMTTA_BF16 && g_thin_mfma && g_wgrad_vec && q_ok(x) && (q_ok(dy) || q_ok16(dy))) w.tiny = false;
   if (w.tiny) {
     const long long units = (long long)w.ips * dy->d * ((dy->h + 1) / 2) * ((dy->w + 63) / 64);
     long long blocks = (units + 3) / 4;
@@ -1735,15 +1751,10 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
     // bf16 precision, 27 taps: the transposed-read kernel when the operands admit its staging (Q: fp32 voxels of 16 bytes;
     // P: 16-byte items of 8 channels; 32-bit element offsets inside a batch item)
     w.p_thin = w.pb->c <= 4 && w.si == 1 && g_thin_mfma;
-    // (a bf16-stored Q - the network input of bf16 precision - has 8-byte voxels: this kernel only)
-    auto q_ok16 = [](const mmtta_tensor* t) {
-      const int64_t last = (int64_t)(t->d - 1) * t->sd + (int64_t)(t->h - 1) * t->sh + (int64_t)(t->w - 1) * t->sw + 8;
-      return is_bf16(t) && ((uintptr_t)t->ptr) % 8 == 0 && t->sw % 4 == 0 && t->sh % 4 == 0 && t->sd % 4 == 0 && t->sn % 4 == 0 &&
-             last < ((int64_t)1 << 31);
-    };
+    // (a bf16-stored thin tensor - the network input of bf16 precision, a thin gradient - has 8-byte voxels: this kernel only)
     w.thin_tr = d->dtype == MMTTA_BF16 && w.ntaps == 27 && g_wgrad_vec &&
                 (q_ok(w.q) || (q_ok16(w.q) && !w.p_thin)) &&
-                (w.p_thin ? q_ok(w.pb) : (wtr_ok(w.pb) && w.pb->c % 8 == 0));
+                (w.p_thin ? (q_ok(w.pb) || q_ok16(w.pb)) : (wtr_ok(w.pb) && w.pb->c % 8 == 0));
     if (!w.thin_tr) w.p_thin = false;
     w.ncb = (w.thin_tr && (w.CDp / 32) % 2 == 0) ? 2 : 1;
     w.TZ = 4; w.TY = (w.thin_tr && w.si == 1) ? 8 : 4; w.TX = 8;

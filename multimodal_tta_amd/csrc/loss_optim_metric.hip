@@ -69,10 +69,14 @@ __device__ __forceinline__ void bernoulli_entropy_terms(float t, float& h, float
   h = fmaxf(t, 0.f) + l1p - t * sig;
   g = -t * (e * r * r);            // sig (1 - sig) = sig(|t|) (1 - sig(|t|)) = r * (e r): even in t
 }
+// OBF: the gradient is bf16-stored (8-byte voxels; method.grad_storage - its readers round it to bf16 while staging)
+template <bool OBF>
 __global__ __launch_bounds__(256) void entropy_bernoulli_vec_kernel(TV z, TV dz, double* partial, float inv_count, int per_item) {
   __shared__ double sh[4];
   if (per_item) {      // N independent volumes: this workgroup column works on batch item blockIdx.y alone
-    z.p += (long long)blockIdx.y * z.sn; dz.p += (long long)blockIdx.y * dz.sn;
+    z.p += (long long)blockIdx.y * z.sn;
+    dz.p = OBF ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(dz.p) + (long long)blockIdx.y * dz.sn)
+               : dz.p + (long long)blockIdx.y * dz.sn;
     z.n = 1; dz.n = 1;
     partial += (long long)blockIdx.y * gridDim.x;
   }
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void entropy_bernoulli_vec_kernel(TV z, TV dz,
       }
     }
     acc += (double)h;
-    *reinterpret_cast<float4*>(dz.p + n * dz.sn + v * 4) = make_float4(g[0], g[1], g[2], g[3]);
+    st4_any(dz.p, n * dz.sn + v * 4, make_float4(g[0], g[1], g[2], g[3]), OBF);
   }
   const double t = block_sum_d(acc, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
@@ -430,7 +434,6 @@ extern "C" int64_t mmtta_entropy_partials(const mmtta_tensor* logits) {
 static int entropy_launch(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits, double* partial, float* loss,
                           int per_item, void* stream) {
   MMTTA_CHECK(logits == nullptr || logits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_entropy_loss: `logits` must be fp32-stored");
-  MMTTA_CHECK(dlogits == nullptr || dlogits->dtype == MMTTA_F32, MMTTA_ERR_UNSUPPORTED, "mmtta_entropy_loss: `dlogits` must be fp32-stored");
   MMTTA_CHECK(logits && dlogits && partial && loss && logits->ptr && dlogits->ptr, MMTTA_ERR_INVALID, "entropy: null argument");
   MMTTA_CHECK(logits->n == dlogits->n && logits->c == dlogits->c && logits->d == dlogits->d && logits->h == dlogits->h &&
                   logits->w == dlogits->w, MMTTA_ERR_INVALID, "entropy: shape mismatch");
@@ -450,8 +453,12 @@ static int entropy_launch(const mmtta_tensor* logits, int softmax, const mmtta_t
       return t->sc == 1 && t->sw == 4 && t->sh == (int64_t)t->w * 4 && t->sd == (int64_t)t->h * t->sh && t->sn % 4 == 0 &&
              ((uintptr_t)t->ptr) % 16 == 0;
     };
-    if (logits->c <= 4 && dense16(logits) && dense16(dlogits) && (dlogits->flags & MMTTA_TENSOR_OWNS_PAD))
-      hipLaunchKernelGGL(entropy_bernoulli_vec_kernel, grid, dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt), per_item);
+    const bool vec = logits->c <= 4 && dense16(logits) && dense16(dlogits) && ((dlogits->flags & MMTTA_TENSOR_OWNS_PAD) || dlogits->c == 4);
+    MMTTA_CHECK(is_f32(dlogits) || vec, MMTTA_ERR_UNSUPPORTED, "mmtta_entropy_loss: a bf16-stored `dlogits` needs dense 4-channel voxel rows that own their pad");
+    if (vec && is_bf16(dlogits))
+      hipLaunchKernelGGL(entropy_bernoulli_vec_kernel<true>, grid, dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt), per_item);
+    else if (vec)
+      hipLaunchKernelGGL(entropy_bernoulli_vec_kernel<false>, grid, dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt), per_item);
     else
       hipLaunchKernelGGL(entropy_bernoulli_kernel, grid, dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt), per_item);
     int st = launch_status("entropy bernoulli");
@@ -459,6 +466,7 @@ static int entropy_launch(const mmtta_tensor* logits, int softmax, const mmtta_t
     hipLaunchKernelGGL(entropy_finish_kernel, dim3(items), dim3(64), 0, s, partial, blocks, 1.0 / cnt, loss);
   } else {
     MMTTA_CHECK(logits->c <= ENT_MAX_R, MMTTA_ERR_UNSUPPORTED, "entropy softmax: more than %d classes", ENT_MAX_R);
+    MMTTA_CHECK(is_f32(dlogits), MMTTA_ERR_UNSUPPORTED, "entropy softmax: `dlogits` must be fp32-stored");
     const double cnt = (double)nvox;
     hipLaunchKernelGGL(entropy_categorical_kernel, grid, dim3(256), 0, s, tv(logits), tv(dlogits), partial, (float)(1.0 / cnt), per_item);
     int st = launch_status("entropy categorical");

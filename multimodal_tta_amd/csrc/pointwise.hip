@@ -946,7 +946,9 @@ extern "C" int mmtta_combine(const mmtta_tensor* a, const mmtta_norm_on_load* ta
 extern "C" int mmtta_norm_bwd_reduce(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
                                      float* part, void* stream) {
   MMTTA_CHECK(dout && y && t && part && dout->ptr && y->ptr && t->mean && t->rstd, MMTTA_ERR_INVALID, "norm bwd reduce: null argument");
-  MMTTA_CHECK(!is_bf16(dout) || is_bf16(y), MMTTA_ERR_UNSUPPORTED, "norm bwd reduce: a bf16-stored gradient needs a bf16-stored activation");
+  // (a bf16-stored gradient sits next to a bf16-stored activation - or, <= 4 channels, next to an fp32-stored one: the thin
+  // full-resolution tensors keep their activations fp32, round 3)
+  MMTTA_CHECK(!is_bf16(dout) || is_bf16(y) || y->c <= 4, MMTTA_ERR_UNSUPPORTED, "norm bwd reduce: a bf16-stored gradient needs a bf16-stored activation");
   MMTTA_CHECK(same_shape(dout, y) && is_cl(dout) && is_cl(y), MMTTA_ERR_INVALID, "norm bwd reduce: shape/layout mismatch");
   RedArgs a;
   a.x = tv(y); a.dout = tv(dout); a.t = nl(t); a.part = part;
@@ -954,7 +956,10 @@ extern "C" int mmtta_norm_bwd_reduce(const mmtta_tensor* dout, const mmtta_tenso
   const dim3 grid(y->n * a.rows_per_n);
   hipStream_t s = (hipStream_t)stream;
   const bool v4 = vec4_rd(y) && vec4_rd(dout);
-  if (is_bf16(dout)) {
+  if (is_bf16(dout) && !is_bf16(y)) {
+    if (v4) hipLaunchKernelGGL((channel_reduce_kernel<1, 4, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((channel_reduce_kernel<1, 1, false, true>), grid, dim3(256), 0, s, a);
+  } else if (is_bf16(dout)) {
     if (v4) hipLaunchKernelGGL((channel_reduce_kernel<1, 4, true, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((channel_reduce_kernel<1, 1, true, true>), grid, dim3(256), 0, s, a);
   } else if (is_bf16(y)) {
@@ -993,7 +998,7 @@ extern "C" int mmtta_norm_bwd_finalize(int kind, int groups, const float* part, 
 extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor* y, const mmtta_norm_on_load* t,
                                     const float* m1, const float* m2, const mmtta_tensor* dy, void* stream) {
   MMTTA_CHECK(dout && y && t && dy && m1 && m2 && t->mean && t->rstd, MMTTA_ERR_INVALID, "norm bwd apply: null argument");
-  MMTTA_CHECK(dout->dtype == dy->dtype && (!is_bf16(dout) || is_bf16(y)), MMTTA_ERR_UNSUPPORTED,
+  MMTTA_CHECK(dout->dtype == dy->dtype && (!is_bf16(dout) || is_bf16(y) || y->c <= 4), MMTTA_ERR_UNSUPPORTED,
               "norm bwd apply: `dout` and `dy` share one storage type (bf16 only next to a bf16-stored activation)");
   const bool dbf = is_bf16(dout);
   MMTTA_CHECK(same_shape(dout, y) && same_shape(dy, y), MMTTA_ERR_INVALID, "norm bwd apply: shape mismatch");
@@ -1042,7 +1047,10 @@ extern "C" int mmtta_norm_bwd_apply(const mmtta_tensor* dout, const mmtta_tensor
       return launch_status("norm bwd apply");
     }
   }
-  if (dbf) {
+  if (dbf && !is_bf16(y)) {          // thin tensors: bf16-stored gradients next to an fp32-stored activation
+    if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4, true, false, true>), grid, dim3(256), 0, s, e);
+    else hipLaunchKernelGGL((elementwise_kernel<1, 1, true, false, true>), grid, dim3(256), 0, s, e);
+  } else if (dbf) {
     if (v4) hipLaunchKernelGGL((elementwise_kernel<1, 4, true, true, true>), grid, dim3(256), 0, s, e);
     else hipLaunchKernelGGL((elementwise_kernel<1, 1, true, true, true>), grid, dim3(256), 0, s, e);
   } else if (is_bf16(y)) {

@@ -350,7 +350,7 @@ class ResidualUnitBlock(Block):
             unit = self.units[u]
             if u > 0:
                 inp = unit.saved[0]
-                dprev = pool.cl((self.key, "dprev", u), *inp.shape, dtype=self.rt.grad_dtype(inp.shape[-1]))
+                dprev = pool.cl((self.key, "dprev", u), *inp.shape, dtype=self.rt.grad_dtype(inp.shape[-1], like=d))
                 unit.bwd(d, dprev, accumulate=False, need_dx=True, grad_accumulate=grad_accumulate)
                 d = dprev
             else:
@@ -397,9 +397,18 @@ class Runtime:
         """Storage type of a forward activation with `channels` channels."""
         return torch.bfloat16 if (self.act_bf16 and channels > 4) else torch.float32
 
-    def grad_dtype(self, channels: int) -> torch.dtype:
-        """Storage type of an activation GRADIENT with `channels` channels."""
-        return torch.bfloat16 if (self.grad_bf16 and self.act_bf16 and channels > 4) else torch.float32
+    def grad_dtype(self, channels: int, like: Optional[torch.Tensor] = None) -> torch.dtype:
+        """Storage type of an activation GRADIENT with `channels` channels.  A thin gradient (<= 4 channels: the
+        full-resolution tensors around the head) takes the storage of the gradient it is computed from (`like`): the loss
+        writes bf16 where the runtime says so (`thin_grad_dtype`) and every thin gradient downstream follows."""
+        if channels <= 4:
+            return like.dtype if like is not None else torch.float32
+        return torch.bfloat16 if (self.grad_bf16 and self.act_bf16) else torch.float32
+
+    def thin_grad_dtype(self) -> torch.dtype:
+        """Storage the loss should give d(logits) (<= 4 channels).  bf16 (8-byte voxels) where every consumer of a thin gradient
+        has that form - models/unet.py in bf16 precision; its consumers round the values to bf16 while staging anyway."""
+        return torch.float32
 
     # -- construction helpers
     def make_ref(self, name: str, param: torch.nn.Parameter) -> ParamRef:

@@ -9,6 +9,8 @@ whole network), so ``loss.backward(); optimizer.step()`` of the reference's
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Dict, List, Optional, Sequence
 
 import torch
@@ -68,6 +70,15 @@ class UNetRuntime(Runtime):
 
     def input_dtype(self) -> torch.dtype:
         return torch.bfloat16 if self.input_bf16 else torch.float32
+
+    def thin_grad_dtype(self) -> torch.dtype:
+        # d(logits) and the thin gradients behind it (the top up-convolution's output gradient, before and after its norm
+        # backward): 8-byte voxels.  Their readers - the 3x3x3 matrix-tile input gradient, the thin weight gradients, the
+        # thin-K input gradient of the up-convolution - round them to bf16 while staging either way
+        # (MMTTA_THIN_GRAD_FP32=1: measurement switch for same-box A/B runs)
+        if os.environ.get("MMTTA_THIN_GRAD_FP32", "0") == "1":
+            return torch.float32
+        return torch.bfloat16 if (self.grad_bf16 and self.out_channels <= 4) else torch.float32
 
     def _down_block(self, prefix: str, cont: nn.Module):
         if isinstance(cont, ResidualUnit):
@@ -146,7 +157,7 @@ class UNetRuntime(Runtime):
             dcat = self._cat(i, n, dims, grad=True)
             if self.upru[i] is not None:
                 yt = self.upconv[i].saved[2]
-                dT = self.pool.cl(("dT", i), *yt.shape, dtype=self.grad_dtype(yt.shape[-1]))
+                dT = self.pool.cl(("dT", i), *yt.shape, dtype=self.grad_dtype(yt.shape[-1], like=d))
                 self.upru[i].bwd(d, dT, accumulate=False, need_dx=True)
                 self.upconv[i].bwd(dT, dcat, accumulate=False)
             else:

@@ -174,7 +174,9 @@ class EntropyMinimizationTTA:
             rt.pack_all()
             logits = rt.forward_cl(x_cl) if present is None else rt.forward_cl(x_cl, present=present)
             n, d, h, w, r = logits.shape
-            dlogits = rt.pool.cl("dlogits", n, d, h, w, r, ldc=(r + 3) // 4 * 4)
+            # (the categorical objective writes fp32 only)
+            gdt = rt.thin_grad_dtype() if (not self.softmax and r <= 4) else torch.float32
+            dlogits = rt.pool.cl("dlogits", n, d, h, w, r, ldc=(r + 3) // 4 * 4, dtype=gdt)
             if rt.group > 1:
                 # every volume of the group is its own objective (own mean, own gradient scale): loss [group]
                 partial = rt.pool.flat("ent_partial", ops.entropy_partials_items(logits), dtype=torch.float64)

@@ -772,6 +772,61 @@ def test_bf16_stored_network_input_gives_the_same_bits(cin, stride, shape, with_
     assert (res["bf16"][2].cpu() - mod.weight.grad).abs().max().item() <= 1.5e-2 * mod.weight.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("r,shape", [(3, (1, 5, 7, 70)), (1, (2, 4, 6, 66)), (4, (1, 3, 9, 130)), (2, (1, 8, 8, 8))])
+def test_thin_gradients_bf16_stored_give_the_same_bits(r, shape):
+    """bf16-stored thin gradients (8-byte voxels; models/unet.py::thin_grad_dtype) around the head of the U-Net:
+      * the input gradient of the R -> R convolution (conv3_mfma4_kernel) with d(logits), its identity-residual term and
+        its result all bf16-stored = round_bf16 of the fp32-stored call;
+      * its weight / bias gradient (wgrad_thin_tr_kernel, thin dense operand) from a bf16-stored d(logits): the same bits;
+      * the up-convolution K -> R: input gradient (chan_mfma_kernel, 64-column form) and weight gradient
+        (wgrad_thin_tr_kernel) from a bf16-stored output gradient: the same bits."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(60 + r)
+    n, d, h, w = shape
+    gy = torch.randn(n, r, d, h, w).to(torch.bfloat16).float()
+    g32, g16 = cl(gy), cl_thin_bf16(gy)
+    # R -> R convolution (k3 s1): dx = dgrad(dy) + dy (identity residual term fused into the epilogue)
+    mod = ref_module(r, r, 3, 1, False)
+    op = ops.ConvOp(r, r, 3, 1, False, "cuda", dtype=ops.BF16)
+    wt = mod.weight.detach().cuda().contiguous()
+    op.pack(wt)
+    x = torch.randn(n, r, d, h, w)
+    x_cl = cl(x)
+    res = {}
+    for name, g in (("fp32", g32), ("bf16", g16)):
+        dx = ops.new_cl(n, d, h, w, r, "cuda", ldc=4, zero=True, dtype=g.dtype)
+        op.dgrad(g, dx, add=g)
+        dw = torch.empty_like(wt)
+        db = torch.empty(r, device="cuda")
+        op.wgrad(x_cl, None, g, dw, db)
+        torch.cuda.synchronize()
+        res[name] = (dx.float().clone(), dw.clone(), db.clone())
+    assert torch.equal(res["bf16"][0], res["fp32"][0].to(torch.bfloat16).float()), "R -> R input gradient: not round_bf16 of the fp32-stored call"
+    assert torch.equal(res["bf16"][1], res["fp32"][1]), "R -> R weight gradient differs"
+    assert torch.equal(res["bf16"][2], res["fp32"][2]), "R -> R bias gradient differs"
+    # up-convolution 64 -> R (k3 s2): gradients from the thin output gradient
+    if d % 2 == 0 and h % 2 == 0 and w % 2 == 0:
+        K = 64
+        up = ref_module(K, r, 3, 2, True)
+        opu = ops.ConvOp(K, r, 3, 2, True, "cuda", dtype=ops.BF16)
+        wu = up.weight.detach().cuda().contiguous()
+        opu.pack(wu)
+        xc = (torch.randn(n, K, d // 2, h // 2, w // 2)).to(torch.bfloat16).float()
+        xc16 = cl_bf16(xc)
+        resu = {}
+        for name, g in (("fp32", g32), ("bf16", g16)):
+            dxc = ops.new_cl(n, d // 2, h // 2, w // 2, K, "cuda", ldc=ops.row_pad(K, torch.bfloat16), dtype=torch.bfloat16, zero=True)
+            opu.dgrad(g, dxc)
+            dw = torch.empty_like(wu)
+            db = torch.empty(r, device="cuda")
+            opu.wgrad(xc16, None, g, dw, db)
+            torch.cuda.synchronize()
+            resu[name] = (dxc.float().clone(), dw.clone(), db.clone())
+        for i, what in enumerate(("input gradient", "weight gradient", "bias gradient")):
+            assert torch.equal(resu["fp32"][i], resu["bf16"][i]), f"up-convolution {what} differs between the storages"
+
+
 THIN_TR_CASES = [
     (4, 32, 3, 2, False, (1, 16, 16, 16)),      # first encoder layer: Q = x (4 channels, norm-on-load), P = dy, bias from P
     (3, 32, 3, 1, False, (1, 5, 7, 11)),        # stride 1, ragged tiles

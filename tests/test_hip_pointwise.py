@@ -263,6 +263,72 @@ def test_upsample_backward_with_bf16_stored_gradients(shape):
         ops.upsample2x_bwd(g16, ops.new_cl(n, d, h, w, c, "cuda"))          # mixed storage is refused, loudly
 
 
+def _thin_bf16(t_ncdhw):
+    """NCDHW cpu fp32 (<= 4 channels) -> bf16-stored channels-last cuda view with 8-byte voxels that owns its pad."""
+    from multimodal_tta_amd import ops
+    n, c, d, h, w = t_ncdhw.shape
+    out = ops.new_cl(n, d, h, w, c, "cuda", ldc=4, zero=True, dtype=torch.bfloat16)
+    ops.to_cl(t_ncdhw.cuda().contiguous(), out=out)
+    return out
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 8, 8, 8), (2, 1, 5, 6, 7), (1, 4, 4, 9, 33)])
+def test_thin_norm_backward_with_bf16_stored_gradients(shape):
+    """Thin full-resolution tensors (<= 4 channels): the activation stays fp32-stored, the gradients going into and coming out
+    of the norm backward are bf16-stored with 8-byte voxels.  With a bf16-representable incoming gradient the reduction sees
+    the same values as the fp32-stored call (partials bitwise equal) and the result is round_bf16 of the fp32 result."""
+    from multimodal_tta_amd import ops
+    torch.manual_seed(33)
+    n, c, d, h, w = shape
+    y = torch.randn(shape) * 1.7 + 0.3
+    gout = torch.randn(shape).to(torch.bfloat16).float()
+    y32, g32, g16 = cl(y), cl(gout), _thin_bf16(gout)
+    rows = ops.reduce_rows_per_n(y32)
+    part = torch.empty(n * rows * 2 * c, device="cuda")
+    ops.channel_stats(y32, part)
+    mean, rstd = torch.empty(n * c, device="cuda"), torch.empty(n * c, device="cuda")
+    scratch = torch.empty(n * c * 2, dtype=torch.float64, device="cuda")
+    ops.norm_stats_finalize(ops.NORM_INSTANCE, 1, part, rows, n, c, d * h * w, 1e-5, True, None, None, 0.1, mean, rstd, scratch)
+    nl = ops.NL(mean, rstd, None, None, relu=True)
+    out = {}
+    for name, gg in (("fp32", g32), ("bf16", g16)):
+        bpart = torch.empty(n * rows * 2 * c, device="cuda")
+        m1, m2 = torch.empty(n * c, device="cuda"), torch.empty(n * c, device="cuda")
+        ops.norm_bwd_reduce(gg, y32, nl, bpart)
+        ops.norm_bwd_finalize(ops.NORM_INSTANCE, 1, bpart, rows, n, c, d * h * w, None, True, m1, m2, None, None, False, scratch)
+        dy = ops.new_cl(n, d, h, w, c, "cuda", ldc=4, zero=True, dtype=gg.dtype)
+        ops.norm_bwd_apply(gg, y32, nl, m1, m2, dy)
+        torch.cuda.synchronize()
+        out[name] = (bpart.clone(), dy.float().clone())
+    assert torch.equal(out["fp32"][0], out["bf16"][0]), "reduction partials differ between the storages"
+    assert torch.equal(out["bf16"][1], out["fp32"][1].to(torch.bfloat16).float()), "apply: not round_bf16 of the fp32 result"
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 8, 8, 8), (2, 1, 5, 6, 7), (1, 4, 4, 9, 33)])
+def test_entropy_gradient_into_a_bf16_stored_tensor(shape):
+    """The Bernoulli objective writing d(logits) bf16-stored (8-byte voxels): the same loss, round_bf16 of the fp32 gradient;
+    per-item objectives included.  The categorical objective refuses a bf16 destination."""
+    from multimodal_tta_amd import ops
+    torch.manual_seed(8)
+    n, c, d, h, w = shape
+    z = torch.randn(shape) * 3.0
+    z_cl = cl(z)
+    res = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        g = ops.new_cl(n, d, h, w, c, "cuda", ldc=4, zero=True, dtype=dt)
+        partial = torch.empty(ops.entropy_partials_items(z_cl), dtype=torch.float64, device="cuda")
+        loss = torch.empty(n, device="cuda")
+        ops.entropy_loss_items(z_cl, g, partial, loss, softmax=False)
+        torch.cuda.synchronize()
+        res[name] = (loss.clone(), g.float().clone())
+    assert torch.equal(res["fp32"][0], res["bf16"][0])
+    assert torch.equal(res["bf16"][1], res["fp32"][1].to(torch.bfloat16).float())
+    with pytest.raises(Exception):
+        g = ops.new_cl(n, d, h, w, c, "cuda", ldc=4, zero=True, dtype=torch.bfloat16)
+        partial = torch.empty(ops.entropy_partials(z_cl), dtype=torch.float64, device="cuda")
+        ops.entropy_loss(z_cl, g, partial, torch.empty(1, device="cuda"), softmax=True)
+
+
 def test_lincomb_mean_and_accumulate():
     from multimodal_tta_amd import ops
     torch.manual_seed(4)
