@@ -33,6 +33,11 @@ KNOBS = {
 KNOBS["fine"] = [dict(splitk_below=b, splitk_target=t, wgrad_workgroups=w, wgrad_thin_slabs=th)
                  for (b, t) in ((24, 32), (12, 16)) for (w, th) in ((32, 64), (16, 32), (16, 64), (48, 96))]
 KNOBS["scaled"] = ["scaled"]        # the package's own rule (ops.tune_for_volumes_in_flight)
+# one knob at a time around the scaled rule's values for 24 volumes in flight (3 x 8)
+_V24 = dict(splitk_below=16, splitk_target=22, wgrad_workgroups=22, wgrad_thin_slabs=43, cls_fused_min=22)
+KNOBS["v24"] = [_V24] + [dict(_V24, splitk_below=b, splitk_target=t) for (b, t) in ((8, 11), (32, 43), (1, 1))] + \
+               [dict(_V24, wgrad_workgroups=w) for w in (11, 43)] + [dict(_V24, wgrad_thin_slabs=t) for t in (21, 86)] + \
+               [dict(_V24, cls_fused_min=c) for c in (11, 43)]
 KNOBS["all"] = KNOBS["splitk"] + KNOBS["wgrad"][1:] + [dict(splitk_below=24, splitk_target=32, wgrad_workgroups=32, wgrad_thin_slabs=64),
                                                        dict(splitk_below=48, splitk_target=64, wgrad_workgroups=64, wgrad_thin_slabs=128)]
 
