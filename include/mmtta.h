@@ -405,7 +405,9 @@ int mmtta_entropy_loss_items(const mmtta_tensor* logits, int softmax, const mmtt
  * [0, n_decay) with weight_decay, [n_decay, n) without - the decay / no-decay groups of
  * reference src/core/experiment_manager.py:199-237; hyper-parameters
  * configs/training/default.yaml:30-39.  `step` is a device int32 incremented by this call
- * (t starts at 1), so a captured graph replays correctly.  SURVEY.md Appendix E K8. */
+ * (t starts at 1), so a captured graph replays correctly.  The call that finds *step == 0 starts from ZERO moments whatever
+ * m / v hold (torch creates the state as zeros) and does not read them: resetting the optimizer is `*step = 0`, no buffer
+ * needs clearing.  SURVEY.md Appendix E K8. */
 int mmtta_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int32_t* step, void* stream);
 

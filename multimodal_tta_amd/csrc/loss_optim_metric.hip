@@ -200,9 +200,13 @@ __global__ __launch_bounds__(256) void optim_kernel(float* __restrict__ p, const
     const long long i = q << 2;
     float4 pq = *reinterpret_cast<const float4*>(p + i);
     const float4 gq = *reinterpret_cast<const float4*>(g + i);
+    // step 0 starts from zero moments whatever the buffers hold (torch creates them as zeros): the episodic reset need not
+    // clear them, and the first step does not read them (8 of its 28 bytes per parameter)
     float4 mq = make_float4(0.f, 0.f, 0.f, 0.f), vq = mq;
-    if (KIND != 2 || a.momentum != 0.f) mq = *reinterpret_cast<const float4*>(m + i);
-    if (KIND != 2) vq = *reinterpret_cast<const float4*>(v + i);
+    if (!first) {
+      if (KIND != 2 || a.momentum != 0.f) mq = *reinterpret_cast<const float4*>(m + i);
+      if (KIND != 2) vq = *reinterpret_cast<const float4*>(v + i);
+    }
     const bool decay = wd_on && i < n_decay;          // n_decay is a multiple of 4
     optim_update<KIND>(pq.x, gq.x, mq.x, vq.x, decay, a, step_size, bc2_sqrt, first);
     optim_update<KIND>(pq.y, gq.y, mq.y, vq.y, decay, a, step_size, bc2_sqrt, first);
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void optim_kernel(float* __restrict__ p, const
   // ragged tail (n not a multiple of 4: never the case for the arena, kept for arbitrary callers)
   const long long i = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i < n) {
-    float pi = p[i], mi = m[i], vi = KIND != 2 ? v[i] : 0.f;
+    float pi = p[i], mi = first ? 0.f : m[i], vi = (KIND != 2 && !first) ? v[i] : 0.f;
     optim_update<KIND>(pi, g[i], mi, vi, wd_on && i < n_decay, a, step_size, bc2_sqrt, first);
     p[i] = pi; m[i] = mi;
     if (KIND != 2) v[i] = vi;

@@ -103,8 +103,7 @@ class Arena:
         if self.source is None:
             raise MmttaError("no source snapshot taken")
         self.params_all.copy_(self.source.unsqueeze(0).expand_as(self.params_all))
-        self.exp_avg_all.zero_()
-        self.exp_avg_sq_all.zero_()
+        # (the moments are not cleared: step 0 of mmtta_optim_step starts from zero moments whatever the buffers hold)
         self.step.zero_()
 
     def zero_grad(self) -> None:

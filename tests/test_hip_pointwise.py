@@ -419,7 +419,9 @@ def test_fused_optimizers_match_torch_over_steps(name, kw):
                          momentum=kw.get("momentum", 0.0), dampening=kw.get("dampening", 0.0),
                          nesterov=kw.get("nesterov", False))
     p = p0.clone().cuda()
-    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    # the state buffers hold garbage: the call that finds step == 0 starts from zero moments and does not read them (the
+    # episodic reset clears the step counter only)
+    m, v = torch.full((n,), float("nan"), device="cuda"), torch.full((n,), float("inf"), device="cuda")
     step = torch.zeros(1, dtype=torch.int32, device="cuda")
     for t in range(5):
         g = torch.randn(n) * (10.0 ** (-t))
