@@ -38,6 +38,7 @@ _V24 = dict(splitk_below=16, splitk_target=22, wgrad_workgroups=22, wgrad_thin_s
 KNOBS["v24"] = [_V24] + [dict(_V24, splitk_below=b, splitk_target=t) for (b, t) in ((8, 11), (32, 43), (1, 1))] + \
                [dict(_V24, wgrad_workgroups=w) for w in (11, 43)] + [dict(_V24, wgrad_thin_slabs=t) for t in (21, 86)] + \
                [dict(_V24, cls_fused_min=c) for c in (11, 43)]
+KNOBS["v24w"] = [dict(_V24, wgrad_workgroups=w) for w in (22, 43, 64, 96, 128)]
 KNOBS["all"] = KNOBS["splitk"] + KNOBS["wgrad"][1:] + [dict(splitk_below=24, splitk_target=32, wgrad_workgroups=32, wgrad_thin_slabs=64),
                                                        dict(splitk_below=48, splitk_target=64, wgrad_workgroups=64, wgrad_thin_slabs=128)]
 
