@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
     wtab[tid] = make_uint2(f32x2_to_bf16x2(wk[0], wk[1]), f32x2_to_bf16x2(wk[2], wk[3]));
   }
   {  // ---- stage the halo box: runs of 4 voxels, two runs (8 loads) in flight per thread
-    constexpr int NIT = (NRUN + 255) / 256, RND = 2;
+    constexpr int NIT = (NRUN + 255) / 256, RND = NIT;      // every load of the box in flight at once (RND = 2: two dependent round trips)
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (HAS_T) nl_coeff_vec<4>(a.tin, n, a.K, 0, sc, sh);          // channels >= K: scale = shift = 0
 #pragma unroll
@@ -573,9 +573,14 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
           pk[q].x = f32x2_to_bf16x2(v4[0], v4[1]) & m; pk[q].y = f32x2_to_bf16x2(v4[2], v4[3]) & m;
         }
         if (tid + 256 * (j0 + j) < NRUN) {
-          uint4* dst = reinterpret_cast<uint4*>(box + 4 * (tid + 256 * (j0 + j)));      // run v = voxels 4 v .. 4 v + 3 of the image
-          dst[0] = make_uint4(pk[0].x, pk[0].y, pk[1].x, pk[1].y);
-          dst[1] = make_uint4(pk[2].x, pk[2].y, pk[3].x, pk[3].y);
+          // run v = voxels 4 v .. 4 v + 3 of its box row.  The first 64 voxels of a row are stored PERMUTED, voxel xi at slot
+          // (xi % 16) * 4 + xi / 16: the A operand of lane (blk, arow) is voxel 16 arow + blk (+ tap), and in plain order
+          // arow 0 / 2 and 1 / 3 met in the same banks (SQ_LDS_BANK_CONFLICT: 42 % of the launch's cycles per CU);
+          // permuted, the 64 lanes of a tap read 64 consecutive slots
+          const int v = tid + 256 * (j0 + j), brow = v / RUNS, run = v - brow * RUNS;
+          uint2* drow = box + brow * BX;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) drow[run < 16 ? 16 * (run & 3) + 4 * q + (run >> 2) : 64 + q] = pk[q];
         }
       }
     }
@@ -636,19 +641,23 @@ __global__ __launch_bounds__(256) void conv3_mfma4_kernel(DArgs a) {
       for (int r = 0; r < 4; ++r) { addc[q][r] = addn[q][r]; oldc[q][r] = oldn[q][r]; }
     if (rp + 1 < TZ * TY / 8) fetch(rp + 1);
     cf4v acc[2];
-    const uint2* ab[2];
+    const uint2* ab[2][3];                        // per x tap: the lane's slot of voxel 16 arow + blk + dx in the permuted row
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int zl = (r0 + q) / TY, yl = (r0 + q) % TY;
-      ab[q] = box + (zl * BY + yl) * BX + 16 * arow + blk;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xi = 16 * arow + blk + dx;
+        ab[q][dx] = box + (zl * BY + yl) * BX + (xi < 64 ? ((xi & 15) << 2) | (xi >> 4) : xi);
+      }
       acc[q] = cf4v{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int tp = 0; tp < 27; ++tp) {
-      const int toff = ((tp / 9) * BY + (tp / 3) % 3) * BX + tp % 3;
+      const int toff = ((tp / 9) * BY + (tp / 3) % 3) * BX;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const uint2 av = ab[q][toff];
+        const uint2 av = ab[q][tp % 3][toff];
         acc[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(cs4, av), wb[tp], acc[q], 0, 0, 0);
       }
     }
