@@ -427,6 +427,8 @@ bool direct_applicable(const mmtta_conv_desc* d);
 // bytes of the fragment-ordered bf16 weight image W' of the 2x2x2 gather-GEMM up-convolution (conv_direct.hip,
 // upconv8_kernel), stored behind the fp32 tap image of the packed buffer; 0 for every other layer
 long long upconv8_image_bytes(const mmtta_conv_desc* d);
+// bytes of the thin-K convolution's B-fragment image behind the fp32 tap image (conv_direct.hip: chan_mfma_kernel), 0 if none
+long long chan_frag_bytes(const mmtta_conv_desc* d);
 int direct_blocks_per_n(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y);
 bool pointwise_small_applicable(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y, const float* stats,
                                 const mmtta_conv_epilogue* epi, const mmtta_norm_on_load* x_norm);

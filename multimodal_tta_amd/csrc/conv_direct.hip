@@ -824,6 +824,17 @@ bool direct_applicable(const mmtta_conv_desc* d) {
   return N <= 4 && (size_t)T * K * 16 + (size_t)K * 8 + 128 <= 96 * 1024;
 }
 
+// The thin-K matrix-core convolution (chan_mfma_kernel) multiplies 7 k-steps of 16 = (4 taps x 4 padded channels) by 32-column
+// blocks; its B fragments are part of the PACKED image since round 3 - entry ((s2 * NB + nb) * 64 + lane) = the lane's 8 k
+// values of column nb * 32 + (lane & 31), bf16 - written once per optimizer step by the pack kernels.  Every workgroup
+// rebuilt them before (56 - 112 scalar loads per entry and thread: a quarter of the kernel's vector instructions).
+long long chan_frag_bytes(const mmtta_conv_desc* d) {
+  if (!(d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_DGRAD) || d->ksize != 3 || d->dtype != MMTTA_BF16) return 0;
+  const int K = d->op == MMTTA_CONV_FWD ? d->cin : d->cout, N = d->op == MMTTA_CONV_FWD ? d->cout : d->cin;
+  if (K > 4 || !(N == 32 || N == 64)) return 0;
+  return 7LL * (N / 32) * 64 * 16;
+}
+
 long long upconv8_image_bytes(const mmtta_conv_desc* d) {
   const bool ok = d->op == MMTTA_CONVT_FWD && d->ksize == 3 && d->stride == 2 && (d->cin == 32 || d->cin == 64) && d->cout <= 4 &&
                   d->dtype == MMTTA_BF16;
@@ -984,7 +995,6 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
   constexpr int TZ = 4, TY = 4, TX = 8;
   constexpr int BZ = (TZ - 1) * S + 3, BY = (TY - 1) * S + 3, BX = (TX - 1) * S + 3, BOX = BZ * BY * BX;
   __shared__ uint2 box[BOX];                       // 4 bf16 channels per voxel
-  __shared__ uint4 wlds[7 * NB * 64];              // the B fragments, [s2 * NB + nb][lane]
   __shared__ float red[2][4][32 * NB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1052,34 +1062,16 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
       }
     }
   }
-  // ---- B fragments: k = s*16 + h*8 + e  <->  tap = s*4 + h*2 + (e >> 2), channel = e & 3; column = nb*32 + r.
-  // The 7 x NB x 64 fragments are the same for the four waves: the workgroup builds each ONCE into LDS (<= 8 scalar loads per
-  // entry, two to four entries per thread instead of 56 / 112 loads per lane) and every lane reads its own 16 bytes back.
+  // ---- B fragments: k = s*16 + h*8 + e  <->  tap = s*4 + h*2 + (e >> 2), channel = e & 3; column = nb*32 + r: the
+  // fragment-ordered bf16 image behind the fp32 tap image of this batch item's packed weights (chan_frag_bytes, written by
+  // the pack kernels): one 16-byte load per fragment and lane, issued before the box is staged
+  uint4 wfrag[7][NB];
   {
-    constexpr int NE = (7 * NB * 64 + 255) / 256;
+    const uint4* fr = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)27 * a.Kp * a.Np * 4) + lane;
 #pragma unroll
-    for (int q = 0; q < NE; ++q) {
-      const int fr = (tid >> 6) + 4 * q;                      // fragment s2 * NB + nb (wave-uniform)
-      if (fr < 7 * NB) {
-        const int s2 = fr / NB, nb = fr % NB;
-        const int col = nb * 32 + r;
-        const float* wp = a.w + min(col, a.Np - 1);
-        float wv[8];
+    for (int s2 = 0; s2 < 7; ++s2)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int tap = s2 * 4 + h * 2 + (e >> 2), c = e & 3;
-          const int tapc = tap < 27 ? tap : 26;
-          const float raw = c < KI ? wp[(unsigned)(tapc * a.Kp + c) * (unsigned)a.Np] : 0.f;
-          wv[e] = (tap < 27 && c < KI && col < N) ? raw : 0.f;
-        }
-        uint4 pk;
-        pk.x = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[0], wv[1]}, bf16x2_t));
-        pk.y = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[2], wv[3]}, bf16x2_t));
-        pk.z = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[4], wv[5]}, bf16x2_t));
-        pk.w = __builtin_bit_cast(unsigned int, __builtin_convertvector((float2_t){wv[6], wv[7]}, bf16x2_t));
-        wlds[fr * 64 + lane] = pk;
-      }
-    }
+      for (int nb = 0; nb < NB; ++nb) wfrag[s2][nb] = fr[(s2 * NB + nb) * 64];
   }
   float bias[NB], asc[NB], ash[NB];
 #pragma unroll
@@ -1090,11 +1082,6 @@ __global__ __launch_bounds__(256) void chan_mfma_kernel(CArgs a) {
     if (a.add) nl_coeff(a.tadd, n, N, col, asc[nb], ash[nb]);
   }
   __syncthreads();
-  uint4 wfrag[7][NB];
-#pragma unroll
-  for (int s2 = 0; s2 < 7; ++s2)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) wfrag[s2][nb] = wlds[(s2 * NB + nb) * 64 + lane];
   // ---- A fragments: MFMA row m = r  <->  voxel (zl = wave, yl = m / 8, xl = m % 8)
   ufloat16 acc[NB];
 #pragma unroll

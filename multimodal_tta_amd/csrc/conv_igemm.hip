@@ -1290,6 +1290,7 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, unsigned s
 struct PackEntry {
   const float* w; void* p;
   unsigned short* up8;      // fragment-ordered bf16 image of the gather-GEMM up-convolution (or null)
+  uint4* chfr; int KI, NO;  // B-fragment image of the thin-K matrix-core convolution (or null), its actual K and N
   int A, B, T, Kp, Np, kn_is_ba, bf16, direct;
   long long start;   // first workgroup of this entry
 };
@@ -1398,6 +1399,33 @@ __device__ __forceinline__ void pack_tile(const PackEntry& e, int lb, float* til
       ((float*)e.p)[tp * slab + (long long)(k0 + kk) * e.Np + n0 + nn] = v;
     }
   }
+}
+
+// B fragments of the thin-K matrix-core convolution from the layer's fp32 tap image [27][Kp][Np] (conv_direct.hip:
+// chan_frag_bytes has the layout).  Runs behind the kernel that wrote the tap image.
+__device__ __forceinline__ void chan_frags_write(const float* img, uint4* fr, int Kp, int Np, int KI, int N) {
+  const int NB = N / 32;
+  for (int i = threadIdx.x; i < 7 * NB * 64; i += blockDim.x) {
+    const int lane = i & 63, frn = i >> 6, s2 = frn / NB, nb = frn % NB;
+    const int h = lane >> 5, col = nb * 32 + (lane & 31);
+    float wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int tap = s2 * 4 + h * 2 + (e >> 2), c = e & 3;
+      wv[e] = (tap < 27 && c < KI && col < N) ? img[((long long)tap * Kp + c) * Np + col] : 0.f;
+    }
+    uint4 pk;
+    pk.x = f32x2_to_bf16x2(wv[0], wv[1]); pk.y = f32x2_to_bf16x2(wv[2], wv[3]);
+    pk.z = f32x2_to_bf16x2(wv[4], wv[5]); pk.w = f32x2_to_bf16x2(wv[6], wv[7]);
+    fr[i] = pk;
+  }
+}
+__global__ __launch_bounds__(256) void pack_chan_frags_kernel(const float* img, uint4* fr, int Kp, int Np, int KI, int N) {
+  chan_frags_write(img, fr, Kp, Np, KI, N);
+}
+__global__ __launch_bounds__(256) void pack_chan_frags_batched_kernel(const PackEntry* __restrict__ tab) {
+  const PackEntry e = tab[blockIdx.x];
+  if (e.chfr != nullptr) chan_frags_write((const float*)e.p, e.chfr, e.Kp, e.Np, e.KI, e.NO);
 }
 
 __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __restrict__ tab, int count) {
@@ -1714,7 +1742,7 @@ extern "C" int64_t mmtta_conv_packed_bytes(const mmtta_conv_desc* d) {
   op_dims(d, K, N, si, cl);
   const int T = d->ksize * d->ksize * d->ksize;
   if (direct_applicable(d)) return (int64_t)T * K * 4 * (int64_t)sizeof(float) + upconv8_image_bytes(d);
-  return (int64_t)T * roundup(K, 32) * roundup(N, 32) * (int64_t)(use_bf16(d, K) ? 2 : sizeof(float));
+  return (int64_t)T * roundup(K, 32) * roundup(N, 32) * (int64_t)(use_bf16(d, K) ? 2 : sizeof(float)) + chan_frag_bytes(d);
 }
 
 extern "C" int mmtta_conv_pack_weights(const mmtta_conv_desc* d, const float* w, void* packed, void* stream) {
@@ -1742,6 +1770,9 @@ extern "C" int mmtta_conv_pack_weights(const mmtta_conv_desc* d, const float* w,
   if (direct && upconv8_image_bytes(d) > 0)       // ConvTranspose3d K -> R: + the gather-GEMM image behind the tap image
     hipLaunchKernelGGL(pack_upconv8_kernel, dim3((K * 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
                        (unsigned short*)((char*)packed + (size_t)T * Kp * Np * 4), K, N);
+  if (!direct && chan_frag_bytes(d) > 0)          // thin-K convolution: + its B fragments behind the fp32 tap image
+    hipLaunchKernelGGL(pack_chan_frags_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)packed,
+                       (uint4*)((char*)packed + (size_t)T * Kp * Np * 4), Kp, Np, K, N);
   return launch_status("pack weights");
 }
 
@@ -1760,6 +1791,8 @@ static int fill_pack_entry(const mmtta_conv_desc* d, const float* w, void* packe
   e.kn_is_ba = (d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONVT_DGRAD) ? 1 : 0;
   e.bf16 = use_bf16(d, K) ? 1 : 0; e.direct = direct ? 1 : 0;
   e.up8 = (direct && upconv8_image_bytes(d) > 0) ? (unsigned short*)((char*)packed + (size_t)e.T * e.Kp * e.Np * 4) : nullptr;
+  e.chfr = (!direct && chan_frag_bytes(d) > 0) ? (uint4*)((char*)packed + (size_t)e.T * e.Kp * e.Np * 4) : nullptr;
+  e.KI = K; e.NO = N;
   MMTTA_CHECK(e.T == 1 || e.T == 27, MMTTA_ERR_UNSUPPORTED, "pack: ksize %d", d->ksize);
   e.start = 0;
   return MMTTA_OK;
@@ -1787,7 +1820,11 @@ extern "C" int mmtta_conv_pack_batched(const void* table_dev, int count, int64_t
   MMTTA_CHECK(total < (1LL << 31), MMTTA_ERR_UNSUPPORTED, "pack batched: %lld workgroups", (long long)total);
   hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev,
                      count);
-  return launch_status("pack batched");
+  int st = launch_status("pack batched");
+  if (st) return st;
+  // the thin-K layers' B fragments, from the tap images the launch above wrote (a block per table entry; most return at once)
+  hipLaunchKernelGGL(pack_chan_frags_batched_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev);
+  return launch_status("pack batched (thin-K fragments)");
 }
 
 extern "C" int mmtta_conv_plan(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* y,
