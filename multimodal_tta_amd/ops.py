@@ -151,6 +151,8 @@ def set_option(key: int, value: int) -> int:
 # scales inversely with the volumes in flight (lanes x group): one volume alone wants 384 / 512 / 512 / 1024 (round 1), sixteen
 # want 24 / 32 / 32 / 64 (profiles/r03_tuning_sweep.txt) - the launches of all volumes together should fill the chip about once
 TUNE_AT_4 = {2: 96, 3: 128, 4: 128, 5: 256, 12: 128}      # SPLITK_BELOW, SPLITK_TARGET, WGRAD_WORKGROUPS, WGRAD_THIN_SLABS, CLASS_FUSED_MIN_WORKGROUPS
+if os.environ.get("MMTTA_SPLITK_AT4"):                    # measurement switch: "below,target" at 4 volumes in flight
+    TUNE_AT_4[2], TUNE_AT_4[3] = (int(v) for v in os.environ["MMTTA_SPLITK_AT4"].split(","))
 _TUNED_FOR: Optional[int] = None
 
 
