@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="unet", choices=["unet", "unet_multimodal_deepfusion"])
     ap.add_argument("--task", default="brats", choices=["brats", "hecktor21"])
+    ap.add_argument("--method", default="tta_entmin", choices=["tta_entmin", "tta_moddrop"],
+                    help="tta_moddrop = BASELINE configs[4]: a modality missing for good (t1c) + seeded modality dropout per step "
+                         "(configs/method/tta_moddrop.yaml); its line carries no cpu_baseline / parity block (the oracle "
+                         "comparison of that configuration is tests/test_hip_fullsize.py::test_config5_*)")
     ap.add_argument("--tta-steps", type=int, default=10)
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="D H W (default: 128^3 brats, 48x144x144 hecktor)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
@@ -87,7 +91,7 @@ def parse():
 
 def build_cfg(args):
     from multimodal_tta_amd.config import compose
-    ov = [f"task={args.task}", f"dataset={args.task}", f"model={args.model}", "method=tta_entmin",
+    ov = [f"task={args.task}", f"dataset={args.task}", f"model={args.model}", f"method={getattr(args, 'method', 'tta_entmin')}",
           f"method.steps={args.tta_steps}", f"method.precision={args.precision}"]
     if args.task == "hecktor21" and args.model != "unet":
         ov += ["model.num_modalities=2", "model.num_classes=1"]
@@ -359,7 +363,9 @@ def main():
         "post_tta_dice": post_dice,
         "config": {
             "workload": f"{cfg['model']['name']} {C}x{shape[0]}x{shape[1]}x{shape[2]} {args.task}-shaped volume: "
-                        f"S={args.tta_steps} entropy-min steps (fwd+bwd+Adam, all parameters) + final forward + Dice",
+                        f"S={args.tta_steps} entropy-min steps (fwd+bwd+Adam, all parameters) + final forward + Dice"
+                        + (f"; modalities {list(cfg['method'].get('missing_modalities', []))} missing, modality dropout p = "
+                           f"{cfg['method']['moddrop']['p']} per step (seeded)" if args.method == "tta_moddrop" else ""),
             "tta_steps": args.tta_steps, "volume": [C, *shape], "adapted_params": str(cfg["method"]["params"]),
             "precision": ("bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulate, for forward, input-gradient "
                           "and 27-tap weight-gradient convs; forward activations with >= 32 channels stored as "
@@ -420,7 +426,7 @@ def main():
                 variants[name]["latency_ms"] = 1000.0 * tv / nv
             del pl2, st2
         out["variants"] = variants
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.method == "tta_entmin":
         out["cpu_baseline"], ref = cpu_baseline(cfg, shape, args.tta_steps)
         out["parity_full_size"] = parity_full_size(cfg, ref, device, args.precision)
     if rank == 0:

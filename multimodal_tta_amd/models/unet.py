@@ -100,15 +100,34 @@ class UNetRuntime(Runtime):
             dims.append((d, h, w))
         return dims
 
-    def _run_down(self, blk, x, out):
+    def _run_down(self, blk, x, out, x_nl=None):
         if isinstance(blk, ResidualUnitBlock):
-            blk.fwd(x, None, out)
+            blk.fwd(x, x_nl, out)
         else:  # plain Convolution (num_res_units == 0): materialise norm+ReLU into the concat slice
-            y, nl = blk.fwd(x, None)
+            y, nl = blk.fwd(x, x_nl)
             ops.combine(y, nl, None, None, out)
 
-    def forward_cl(self, x_cl: torch.Tensor) -> torch.Tensor:
+    # the per-step modality mask of the missing-modality / modality-dropout runs (BASELINE configs[4]) is applied by the
+    # first level's kernels WHILE THEY STAGE the input - a per-(item, channel) scale of 1 or 0 through the norm-on-load hook,
+    # x * keep exactly as the oracle's `x * keep.view(1, -1, 1, 1, 1)` - instead of masking and re-staging the volume every step
+    supports_present = True
+    input_mask_on_load = True
+
+    def _input_mask(self, n: int, present) -> ops.NL:
+        key = ("in_keep", tuple(bool(p) for p in present))
+        scale = self.pool.flat(key, n * self.in_channels)
+        if getattr(scale, "_mmtta_filled", None) != n:
+            keep = torch.tensor([1.0 if p else 0.0 for p in present], dtype=torch.float32, device=scale.device)
+            scale.copy_(keep.repeat(n))
+            scale._mmtta_filled = n
+        zero = self.pool.flat("in_keep_shift", n * self.in_channels, zero=True)
+        return ops.NL(zero, zero, None, None, relu=False, scale=scale, shift=zero)
+
+    def forward_cl(self, x_cl: torch.Tensor, present=None) -> torch.Tensor:
         n, D, H, W, _ = x_cl.shape
+        if present is not None and len(present) != self.in_channels:
+            raise ValueError(f"modality mask has {len(present)} entries for {self.in_channels} input channels")
+        x_nl = self._input_mask(n, present) if (present is not None and not all(present)) else None
         f = 2 ** len(self.strides)
         if D % f or H % f or W % f:
             raise ValueError(
@@ -121,7 +140,7 @@ class UNetRuntime(Runtime):
         for i in range(L):
             cat = self._cat(i, n, dims)
             out = cat[..., :c[i]]
-            self._run_down(self.down[i], cur, out)
+            self._run_down(self.down[i], cur, out, x_nl if i == 0 else None)
             cur = out
         cat = self._cat(L - 1, n, dims)
         self._run_down(self.bottom, cur, cat[..., c[L - 1]:])

@@ -267,18 +267,21 @@ class EntropyMinimizationTTA:
         gen = torch.Generator().manual_seed(self.moddrop_seed) if self.moddrop_p > 0.0 else None
         base_present = modality_mask(C, self.missing, 0.0, None)
         x = x.float()
-        x_cl = rt.stage_input(drop_modality(x, base_present) if masked else x)
+        wants_present = masked and getattr(rt, "supports_present", False)
+        # a runtime that applies the mask while its first level stages the input (models/unet.py) reads the volume as it is;
+        # the others get the masked volume re-staged whenever the mask changes
+        restage = masked and not getattr(rt, "input_mask_on_load", False)
+        x_cl = rt.stage_input(drop_modality(x, base_present) if restage else x)
         grouped = rt.group > 1
         loss_hist = rt.pool.flat("loss_hist", max(steps, 1) * (B if grouped else 1))
         loss_buf = rt.pool.flat("ent_loss", rt.group if grouped else 1)
         if grouped:
             loss_hist = loss_hist.view(max(steps, 1), B)
-        wants_present = masked and getattr(rt, "supports_present", False)
         for t in range(steps):
             present = None
             if masked:
                 p = modality_mask(C, self.missing, self.moddrop_p, gen)
-                if self.moddrop_p > 0.0:
+                if self.moddrop_p > 0.0 and restage:
                     rt.stage_input(drop_modality(x, p))
                 present = p if wants_present else None
             self._step(x_cl, present)
@@ -286,7 +289,7 @@ class EntropyMinimizationTTA:
                 loss_hist[t].copy_(loss_buf[:B])
             else:
                 loss_hist[t:t + 1].copy_(loss_buf)
-        if masked and self.moddrop_p > 0.0:
+        if masked and self.moddrop_p > 0.0 and restage:
             rt.stage_input(drop_modality(x, base_present))
         rt.training = False
         ops.Workspace.lane = self.lane

@@ -15,6 +15,10 @@ run hecktor_unet --task hecktor21 --steps 48 --warmup 8
 run deepfusion_brats --model unet_multimodal_deepfusion --steps 24 --warmup 4
 run unet_fp32 --precision fp32 --steps 24 --warmup 4
 run brats_full_160x192x160 --shape 160 192 160 --steps 24 --warmup 4
+# BASELINE configs[4] on one GPU: missing modality + modality dropout (the U-Net with the channel zeroed, the deep-fusion net
+# with its branch masked out of the means)
+run moddrop_unet --method tta_moddrop --steps 48 --warmup 8
+run moddrop_deepfusion --method tta_moddrop --model unet_multimodal_deepfusion --steps 24 --warmup 4
 if [ "$2" != "nopmc" ]; then
   bash scripts/pmc_bench.sh > $out/pmc.log 2>&1 || { tail -20 $out/pmc.log; exit 1; }
   cp gpurun_out/pmc_bench/sq_per_kernel.txt gpurun_out/pmc_bench/mem_per_kernel.txt gpurun_out/pmc_bench/traffic.json $out/
