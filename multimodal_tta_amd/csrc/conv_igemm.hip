@@ -1454,6 +1454,160 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __re
   else pack_tile<1>(e, lb, tile);
 }
 
+
+// ------------------------------------------------------------------ streaming 1x1x1 convolution (bf16 operands, round 3)
+// The 1x1x1 layers of the deep-fusion decoder at full resolution (33 -> 32 shortcut convolutions and their input gradients at
+// 128^3, 96 -> 64 at 64^3) ran on the gather GEMM above: LDS box, barriers and a 27-tap tile shape for what is a [voxels x K] x
+// [K x N] product - 3.3 to 9 times their HBM time.  Without taps there is nothing to share between voxels, so nothing goes
+// through LDS: lane (r, h) of a wave loads the 8 channels k16 * 16 + 8 h .. + 7 of voxel r STRAIGHT into its A fragment (one
+// 16-byte load of bf16, two of fp32), the B fragments of all k steps sit in registers for the whole launch (K <= 128, N <=
+// 64), and a wave owns 32 voxels per trip.  Epilogue as in chan_mfma_kernel: bias, fused add (with its norm-on-load),
+// accumulate, bf16 rows stored as channel-pair dwords.  No statistics, no norm-on-load of the input: those calls stay above.
+struct PWArgs {
+  const float* in; long long isn; unsigned isw; int Ci;       // voxel-dense tensors: element offset of voxel v = v * sw
+  float* out; long long osn; unsigned osw; int Co;
+  const float* add; long long asn; unsigned asw; NL tadd;
+  const float* wp; const float* bias; int Np; PSets ps;
+  int accumulate; long long dhw;
+};
+
+template <int KB, int NB, bool BF>
+__global__ __launch_bounds__(256) void pointwise_mfma_kernel(PWArgs a) {
+  constexpr int TP = NB * 32 + 4;                     // tile row pitch (floats): 16-byte rows, conflict-free column writes
+  __shared__ __attribute__((aligned(16))) float tile[4][32][TP];
+  __shared__ float coef[3][NB * 32];                  // bias | scale, shift of the fused add, per output column
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, r = lane & 31;
+  const float* wpn = pset_packed(a.ps, a.wp, n);
+  const float* biasn = pset_bias(a.ps, a.bias, n);
+  uint4 bfr[KB][NB];
+  {
+    const uint4* wq = reinterpret_cast<const uint4*>(wpn);            // [Kp / 8][Np] entries of 8 bf16
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bfr[ks][nb] = wq[(long long)(ks * 2 + h) * a.Np + nb * 32 + r];
+  }
+  if (tid < NB * 32) {
+    const int col = min(tid, a.Co - 1);
+    float sc = 1.f, sh = 0.f;
+    if (a.add) nl_coeff(a.tadd, n, a.Co, col, sc, sh);
+    coef[0][tid] = (biasn && tid < a.Co) ? biasn[col] : 0.f;
+    coef[1][tid] = sc; coef[2][tid] = sh;
+  }
+  __syncthreads();
+  const float* inn = item_base<BF>(a.in, n, a.isn);
+  float* outn = const_cast<float*>(item_base<BF>(a.out, n, a.osn));
+  const float* addn = a.add == nullptr ? nullptr : item_base<BF>(a.add, n, a.asn);
+  const float relu_lo = a.tadd.relu ? 0.f : -__builtin_inff();
+  // every wave makes the same number of trips (a wave past the end works on clamped voxels and stores nothing): the tile
+  // hand-over below needs no more than the wave's own program order
+  for (long long base = (long long)blockIdx.x * 128; base < a.dhw; base += (long long)gridDim.x * 128) {
+    const long long v0 = base + wave * 32;
+    const unsigned vo = (unsigned)min(v0 + r, a.dhw - 1) * a.isw;
+    uint4 af[KB];
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks) {
+      const unsigned c0 = ks * 16 + h * 8;
+      if (c0 + 8 <= a.isw) {          // (rows are padded to 8 channels; what lies behind the row is not read)
+        if constexpr (BF) {
+          af[ks] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(inn) + vo + c0);
+        } else {
+          const float4 lo = *reinterpret_cast<const float4*>(inn + vo + c0), hi = *reinterpret_cast<const float4*>(inn + vo + c0 + 4);
+          af[ks] = make_uint4(f32x2_to_bf16x2(lo.x, lo.y), f32x2_to_bf16x2(lo.z, lo.w), f32x2_to_bf16x2(hi.x, hi.y), f32x2_to_bf16x2(hi.z, hi.w));
+        }
+      } else if (!BF && c0 + 4 <= a.isw) {          // fp32 rows are padded to 4 channels
+        const float4 lo = *reinterpret_cast<const float4*>(inn + vo + c0);
+        af[ks] = make_uint4(f32x2_to_bf16x2(lo.x, lo.y), f32x2_to_bf16x2(lo.z, lo.w), 0u, 0u);
+      } else {
+        af[ks] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if ((int)c0 + 8 > a.Ci) {          // channels past the tensor's last one (a slice of a wider row, pad lanes): exact zeros
+        auto pm = [&](int c) { return (c < a.Ci ? 0xffffu : 0u) | (c + 1 < a.Ci ? 0xffff0000u : 0u); };
+        af[ks].x &= pm(c0); af[ks].y &= pm(c0 + 2); af[ks].z &= pm(c0 + 4); af[ks].w &= pm(c0 + 6);
+      }
+    }
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks]), __builtin_bit_cast(bf16x8, bfr[ks][nb]), acc[nb], 0, 0, 0);
+    // ---- epilogue through the wave's LDS tile: accumulator i of lane (h, r) = voxel (i & 3) + 8 (i >> 2) + 4 h, column
+    // nb * 32 + r goes in column-wise (conflict-free), comes back as 8 consecutive channels of one voxel per lane: the fused
+    // add and the accumulate operand are one 16-byte load each, the result one 16-byte store
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) tile[wave][(i & 3) + 8 * (i >> 2) + 4 * h][nb * 32 + r] = acc[nb][i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 2 * NB; ++q) {
+      const int item = lane + 64 * q, vl = item / (4 * NB), c8 = item % (4 * NB), c0 = c8 * 8;
+      const long long vv = v0 + vl;
+      if (vv < a.dhw && c0 < a.Co) {
+        const float4 t0 = *reinterpret_cast<const float4*>(&tile[wave][vl][c0]), t1 = *reinterpret_cast<const float4*>(&tile[wave][vl][c0 + 4]);
+        float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        const bool full = c0 + 8 <= a.Co;
+        const unsigned oo = (unsigned)vv * a.osw + c0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += coef[0][c0 + e];
+        if (a.add) {
+          float ad[8];
+          if (full || c0 + 8 <= (int)a.asw) {
+            oct8_f8(oct8_ld<BF>(addn, (unsigned)vv * a.asw + c0, (unsigned)vv * a.asw + c0 + 4), ad);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ad[e] = c0 + e < a.Co ? ld1_t<BF>(addn, (unsigned)vv * a.asw + c0 + e) : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += fmaxf(fmaf(ad[e], coef[1][c0 + e], coef[2][c0 + e]), relu_lo);
+        }
+        if (full) {
+          if (a.accumulate) {
+            float old[8];
+            oct8_f8(oct8_ld<BF>(outn, oo, oo + 4), old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += old[e];
+          }
+          oct8_st<BF>(outn, oo, v);
+        } else {                           // ragged last chunk: element stores, nothing behind the last channel is touched
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (c0 + e < a.Co) st1_t<BF>(outn, oo + e, a.accumulate ? v[e] + ld1_t<BF>(outn, oo + e) : v[e]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int KB, bool BF>
+static void launch_pointwise_mfma_nb(const PWArgs& a, int nb, dim3 grid, hipStream_t s) {
+  if (nb == 1) hipLaunchKernelGGL((pointwise_mfma_kernel<KB, 1, BF>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((pointwise_mfma_kernel<KB, 2, BF>), grid, dim3(256), 0, s, a);
+}
+template <bool BF>
+static void launch_pointwise_mfma(const PWArgs& a, int kb, int nb, dim3 grid, hipStream_t s) {
+  switch (kb) {
+    case 1: launch_pointwise_mfma_nb<1, BF>(a, nb, grid, s); break;
+    case 2: launch_pointwise_mfma_nb<2, BF>(a, nb, grid, s); break;
+    case 3: launch_pointwise_mfma_nb<3, BF>(a, nb, grid, s); break;
+    case 4: launch_pointwise_mfma_nb<4, BF>(a, nb, grid, s); break;
+    case 6: launch_pointwise_mfma_nb<6, BF>(a, nb, grid, s); break;
+    default: launch_pointwise_mfma_nb<8, BF>(a, nb, grid, s); break;
+  }
+}
+
 // ---------------------------------------------------------------- host side
 struct Config { int NB, MB, TZ, TY, TX, KCI; bool bf; };
 
@@ -1887,6 +2041,35 @@ extern "C" int mmtta_conv_run_sets(const mmtta_conv_desc* d, const mmtta_tensor*
     return pointwise_small_run(x, packed, g.Kp, g.Np, bias, y, accumulate, ps, (hipStream_t)stream);
   if (chan_applicable(d, x, y) && !use_bf16(d, g.K))
     return chan_conv_run(d, x, x_norm, packed, g.Kp, g.Np, bias, epi, y, accumulate, stats, ps, (hipStream_t)stream);
+  {  // 1x1x1 over many voxels with bf16 operands, nothing but bias / add / accumulate around it: the streaming kernel
+    static const bool pw_on = !(getenv("MMTTA_POINTWISE_MFMA") && atoi(getenv("MMTTA_POINTWISE_MFMA")) == 0);      // (A/B switch)
+    auto dense = [](const mmtta_tensor* t) { return t->sc == 1 && t->sh == (int64_t)t->w * t->sw && t->sd == (int64_t)t->h * t->sh; };
+    const mmtta_tensor* ad = (epi && epi->add) ? epi->add : nullptr;
+    const bool bfs = is_bf16(x);
+    const long long dhw = (long long)y->d * y->h * y->w;
+    const int kb = (g.K + 15) / 16;
+    auto rows_ok = [&](const mmtta_tensor* t) {
+      return dense(t) && is_bf16(t) == bfs && ((uintptr_t)t->ptr) % 16 == 0 && t->sw % (bfs ? 8 : 4) == 0 && t->sn % (bfs ? 8 : 4) == 0 &&
+             dhw * t->sw < (1LL << 31);
+    };
+    const bool pw = pw_on && d->ksize == 1 && (d->op == MMTTA_CONV_FWD || d->op == MMTTA_CONV_DGRAD) && use_bf16(d, g.K) &&
+                    (kb <= 4 || kb == 6 || kb == 8) && g.Np <= 64 && stats == nullptr && !(x_norm && (x_norm->mean || x_norm->scale)) &&
+                    dhw >= 4096 && rows_ok(x) && rows_ok(y) && (ad == nullptr || (rows_ok(ad) && ad->n == y->n && ad->c == y->c && ad->d == y->d && ad->h == y->h && ad->w == y->w));
+    if (pw) {
+      PWArgs q;
+      q.in = (const float*)x->ptr; q.isn = x->sn; q.isw = (unsigned)x->sw; q.Ci = x->c;
+      q.out = (float*)y->ptr; q.osn = y->sn; q.osw = (unsigned)y->sw; q.Co = y->c;
+      q.add = ad ? (const float*)ad->ptr : nullptr; q.asn = ad ? ad->sn : 0; q.asw = ad ? (unsigned)ad->sw : 0u;
+      q.tadd = ad ? nl(&epi->add_norm) : nl(nullptr);
+      q.wp = (const float*)packed; q.bias = bias; q.Np = g.Np; q.ps = ps; q.accumulate = accumulate; q.dhw = dhw;
+      long long blocks = (dhw + 127) / 128;
+      if (blocks > 2048) blocks = 2048;
+      const dim3 grid((unsigned)blocks, y->n);
+      if (bfs) launch_pointwise_mfma<true>(q, kb, g.Np / 32, grid, (hipStream_t)stream);
+      else launch_pointwise_mfma<false>(q, kb, g.Np / 32, grid, (hipStream_t)stream);
+      return launch_status("1x1 conv (streaming MFMA)");
+    }
+  }
   const int64_t need = g.ksplit > 1 ? (int64_t)g.ksplit * g.tiles * g.cfg.TZ * g.cfg.TY * g.cfg.TX * g.Np * 4 : 0;
   MMTTA_CHECK(need == 0 || (workspace != nullptr && workspace_bytes >= need), MMTTA_ERR_WORKSPACE,
               "conv: workspace %lld bytes, need %lld", (long long)workspace_bytes, (long long)need);

@@ -711,6 +711,43 @@ def test_head_input_gradient_into_a_bf16_stored_gradient(r, cout, shape):
     assert (res["bf16"] - want).abs().max().item() <= 3 * 2.0 ** -8 * scale
 
 
+@pytest.mark.parametrize("stored", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,cout,shape", [(33, 32, (1, 16, 16, 17)), (32, 33, (2, 16, 16, 16)), (96, 64, (1, 8, 16, 33)),
+                                            (64, 64, (1, 16, 16, 16)), (128, 40, (1, 16, 16, 16)), (16, 32, (1, 16, 16, 16))])
+def test_streaming_pointwise_convolution(cin, cout, shape, stored):
+    """1x1x1 convolutions over >= 4096 voxels in bf16 precision take the streaming matrix-core kernel (pointwise_mfma_kernel:
+    A fragments loaded straight from HBM, no LDS): forward with bias and a fused add carrying its own norm-on-load (the
+    shortcut convolution of a residual unit), and the input gradient with the accumulate path - against torch fp32 within the
+    bf16-operand bound, ragged voxel counts, channel counts that are no multiple of 8 / 32, two batch items, both storages."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(23 + cin + cout)
+    n, d, h, w = shape
+    mod = ref_module(cin, cout, 1, 1, False)
+    x = torch.randn(n, cin, d, h, w).to(torch.bfloat16).float().requires_grad_(True)
+    other = (torch.randn(n, cout, d, h, w) * 1.5 + 0.2).to(torch.bfloat16).float()
+    mu = other.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(other.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    y_ref = mod(x) + F.relu((other - mu[:, :, None, None, None]) * rstd[:, :, None, None, None])
+    gy = torch.randn_like(y_ref).to(torch.bfloat16).float()
+    y_ref.backward(gy)
+    nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    conv = cl_bf16 if stored == "bf16" else cl
+    dt = torch.bfloat16 if stored == "bf16" else torch.float32
+    op = ops.ConvOp(cin, cout, 1, 1, False, "cuda", dtype=ops.BF16)
+    op.pack(mod.weight.detach().cuda().contiguous())
+    y = ops.new_cl(n, d, h, w, cout, "cuda", ldc=ops.row_pad(cout, dt), dtype=dt, zero=True)
+    op.forward(conv(x.detach()), None, mod.bias.detach().cuda(), y, add=conv(other), add_nl=nl)
+    dx = ops.new_cl(n, d, h, w, cin, "cuda", ldc=ops.row_pad(cin, dt), dtype=dt, zero=True)
+    op.dgrad(conv(gy), dx)
+    op.dgrad(conv(gy), dx, accumulate=True)
+    torch.cuda.synchronize()
+    got_y = y.float().permute(0, 4, 1, 2, 3).cpu()
+    got_dx = dx.float().permute(0, 4, 1, 2, 3).cpu() / 2
+    assert (got_y - y_ref.detach()).abs().max().item() <= 1.5e-2 * y_ref.abs().max().item()
+    assert (got_dx - x.grad).abs().max().item() <= 2e-2 * x.grad.abs().max().item()
+
+
 def cl_thin_bf16(x):
     """NCDHW cpu fp32 (<= 4 channels) -> bf16-stored channels-last cuda view with 8-byte voxels."""
     from multimodal_tta_amd import ops
