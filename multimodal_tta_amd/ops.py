@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -29,7 +30,20 @@ def _require_cuda() -> None:
 
 
 # ----------------------------------------------------------------------------- workspace
-class Workspace:
+class _WorkspaceSelectors(type):
+    """`Workspace.slot / lane / frozen` select the scratch buffer of the launches that follow; they are per THREAD (a second
+    Python thread driving its own lane does not disturb another thread's selection), with the old class-attribute syntax."""
+    _tls = threading.local()
+
+    def _get(cls, name, default):
+        return getattr(_WorkspaceSelectors._tls, name, default)
+
+    slot = property(lambda cls: cls._get("slot", 0), lambda cls, v: setattr(_WorkspaceSelectors._tls, "slot", int(v)))
+    lane = property(lambda cls: cls._get("lane", 0), lambda cls, v: setattr(_WorkspaceSelectors._tls, "lane", int(v)))
+    frozen = property(lambda cls: cls._get("frozen", False), lambda cls, v: setattr(_WorkspaceSelectors._tls, "frozen", bool(v)))
+
+
+class Workspace(metaclass=_WorkspaceSelectors):
     """One grow-only scratch buffer per device, shared by split-K convs and weight gradients
     (stream ordered).  It must reach its final size before a graph capture starts.
 
@@ -42,9 +56,8 @@ class Workspace:
     _retired: list = []     # superseded buffers, kept alive for the graphs that reference them
     captured: set = set()   # (device index, lane) pairs on which a hipGraph has been captured (the plugin records them)
     min_bytes = 1 << 20     # first allocation of a slot (tests lower it to provoke growth with small shapes)
-    frozen = False
-    slot = 0        # 0: main launch sequence; 1..: the side streams of the weight gradients (engine.ConvLayer.wgrad)
-    lane = 0        # runtimes that run concurrently on different streams (bench.py --lanes) keep separate scratch
+    # frozen / slot / lane: thread-local selectors (metaclass above).  slot 0: main launch sequence, 1..: the side streams of
+    # the weight gradients (engine.ConvLayer.wgrad); lane: runtimes that run concurrently on different streams keep separate scratch
 
     @classmethod
     def get(cls, nbytes: int, device: torch.device) -> torch.Tensor:
