@@ -271,3 +271,27 @@ def test_hardware_queue_dependency_is_loud(monkeypatch):
         monkeypatch.setattr(pkg, "HW_QUEUES_AT_HIP_START", "8")
         ops.lane_streams(4, "cpu")
     assert ops.lanes_effective(4) == 4
+
+
+def test_workspace_selectors_are_per_thread():
+    """`ops.Workspace.lane / slot / frozen` pick the scratch buffer of the launches that follow: a second Python thread driving
+    its own lane starts from the defaults and does not disturb the first one's selection ("smaller")."""
+    import threading
+
+    from multimodal_tta_amd import ops
+    ops.Workspace.lane, ops.Workspace.slot = 3, 1
+    seen = {}
+
+    def other():
+        seen["start"] = (ops.Workspace.lane, ops.Workspace.slot, ops.Workspace.frozen)
+        ops.Workspace.lane, ops.Workspace.frozen = 7, True
+        seen["end"] = (ops.Workspace.lane, ops.Workspace.frozen)
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    try:
+        assert seen == {"start": (0, 0, False), "end": (7, True)}
+        assert (ops.Workspace.lane, ops.Workspace.slot, ops.Workspace.frozen) == (3, 1, False)
+    finally:
+        ops.Workspace.lane, ops.Workspace.slot = 0, 0
