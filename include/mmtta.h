@@ -140,7 +140,8 @@ int mmtta_set_option(int key, int value);
 /* NCDHW fp32 <-> channels-last.  Stands in for nothing in the reference: it is the price of
  * the internal layout, paid once per volume on the way in (reference tensor contract:
  * src/datasets/brats.py:343-347, image float32 [C,D,H,W]) and once on the way out
- * (src/evaluation/seg_eval.py:300, logits [B,R,D,H,W]).  Any strides are accepted. */
+ * (src/evaluation/seg_eval.py:300, logits [B,R,D,H,W]).  Any strides are accepted; `src` is fp32, `dst` fp32 or bf16
+ * (round to nearest even: the staged network input of bf16 precision, 8-byte voxels for <= 4 channels). */
 int mmtta_copy_strided(const mmtta_tensor* src, const mmtta_tensor* dst, void* stream);
 
 /* ------------------------------------------------------------------ convolution ---------- */
@@ -370,7 +371,8 @@ int mmtta_norm_bwd_small(const mmtta_tensor* dout, const mmtta_tensor* y, const 
 
 /* ------------------------------------------------------------------ resampling / glue ---- */
 /* nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True) and its adjoint
- * (reference: src/models/unet_multimodal_midfusion.py:114-120,134 via monai UpSample). */
+ * (reference: src/models/unet_multimodal_midfusion.py:114-120,134 via monai UpSample).  Both tensors of a call share one
+ * storage type (fp32 or bf16: activations under method.storage, gradients under method.grad_storage); fp32 arithmetic. */
 int mmtta_upsample2x_fwd(const mmtta_tensor* x, const mmtta_tensor* y, void* stream);
 int mmtta_upsample2x_bwd(const mmtta_tensor* dy, const mmtta_tensor* dx, int accumulate, void* stream);
 
@@ -386,7 +388,8 @@ int mmtta_lincomb(int count, const mmtta_tensor* const* in, const float* w, cons
  * skeleton of reference src/core/trainers/seg_trainer.py:141-142).
  *   softmax == 0: mean over (n,r,voxel) of H_bern(z) = softplus(z) - z*sigmoid(z)
  *   softmax != 0: mean over (n,voxel)   of H_cat(z)  = logsumexp_r z - sum_r p_r z_r
- *   logits, dlogits  channels-last, same shape; dlogits = dLoss/dlogits
+ *   logits, dlogits  channels-last, same shape; dlogits = dLoss/dlogits.  logits fp32; dlogits fp32, or - softmax == 0, <= 4
+ *            channels in dense 4-channel voxel rows - bf16 (8-byte voxels: the thin gradients of method.grad_storage)
  *   partial  fp64 [mmtta_entropy_partials(...)] scratch; loss  fp32 [1] */
 int64_t mmtta_entropy_partials(const mmtta_tensor* logits);
 int mmtta_entropy_loss(const mmtta_tensor* logits, int softmax, const mmtta_tensor* dlogits,
