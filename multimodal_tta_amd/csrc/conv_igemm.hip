@@ -80,6 +80,7 @@ struct GArgs {
   int ovec;        // 16-byte epilogue stores (out / add rows 16-byte aligned, Co % 4 == 0)
   int coef_off;    // word offset of the coefficient table behind the LDS box image
   int rowload;     // the input admits the row-structured loader (alignment, 24-bit strides, < 2^31 elements)
+  int flip27;      // canonical 27-tap stride-1 stage (rowload): tap t reads weight slab 26 - t (stride-1 input gradient) instead of t
   int ncls;
   ClassInfo cls[8];
   int toff[27];   // box-relative voxel offset of each tap (int32 tables: read with SCALAR loads)
@@ -115,6 +116,10 @@ __device__ __forceinline__ void row_to_local(int v, int& zl, int& yl, int& xl) {
 }
 
 constexpr int LDS_PITCH_BF16 = 12;   // x-row pitch (voxels) of the bf16 LDS image of stride-1 gathers
+
+// Box-relative voxel offset of tap t of the canonical 3x3x3 stride-1 stage (taps in ascending (z, y, x) box order, RBY box
+// rows per z plane): a compile-time constant once the tap loops are unrolled, i.e. an immediate of the ds_read.
+__host__ __device__ constexpr int tap27_off(int t, int rby) { return ((t / 9) * rby + (t / 3) % 3) * LDS_PITCH_BF16 + t % 3; }
 
 // Epilogue with 16-byte stores.  An MFMA accumulator block holds ONE output channel per lane (32 lanes = a 128-byte
 // voxel row) and 16 voxels in its registers, so storing straight from it takes 16 four-byte-per-lane stores per block -
@@ -412,6 +417,22 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
     __syncthreads();      // coefficients visible
   }
 
+  // Weight fragment of (tap t, 16-channel step k2) of the canonical stage: a wave-uniform 64-bit base (scalar registers:
+  // parameter set, stage, slab - the slab walks up for the forward form, down for the mirrored input gradient) plus ONE
+  // 32-bit per-lane byte offset, so a request costs two scalar adds instead of a 64-bit multiply-add per lane
+  // (measured on the 64^3 32-channel layers: 7 scalar + 1 vector instruction per fragment before).
+  // (compiled into the lean 64^3 tile only: beside the table-driven stage it costs the four-block tiles, which sit at the
+  // 256-register limit, 200-450 bytes of spills)
+  constexpr bool CANON_CFG = BF && OCC > 2;
+  const long long wslab16 = (long long)(a.Kp / 8) * a.Np * 16;                    // bytes per tap slab
+  const char* const wuni = reinterpret_cast<const char*>(wpn) + (a.flip27 ? 26 * wslab16 : 0);
+  const long long wstep16 = a.flip27 ? -wslab16 : wslab16;
+  const unsigned wlane16 = (unsigned)(h * a.Np + colbase + r) * 16u;
+  auto wfrag27 = [&](int c0, int t, int k2) {
+    const char* ub = wuni + ((long long)(c0 / 8) * a.Np + (long long)k2 * 2 * a.Np) * 16 + t * wstep16;
+    return *reinterpret_cast<const uint4*>(ub + wlane16);
+  };
+
   for (int ks = ks0; ks < ks1; ++ks) {
     const int stage = ks;
     const int c0 = ks * KCI;
@@ -424,12 +445,19 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
     if constexpr (BF) {
       if (colact && ci.ntaps == 27 && ((min(KCI, a.Ci - c0) + 15) >> 4) == WKS) {   // same test as the MFMA section
         wfirst_ok = true;
-        const uint4* wq0 = reinterpret_cast<const uint4*>(wpn) + (long long)(c0 / 8 + h) * a.Np + colbase + r;
         const long long slabsz8 = (long long)(a.Kp / 8) * a.Np;
+        if (CANON_CFG && fast) {
 #pragma unroll
-        for (int t = 0; t < WG0; ++t)
+          for (int t = 0; t < WG0; ++t)
 #pragma unroll
-          for (int k2 = 0; k2 < WKS; ++k2) wfirst[t][k2] = wq0[(a.slab + ci.tap0)[t] * slabsz8 + k2 * 2 * a.Np];
+            for (int k2 = 0; k2 < WKS; ++k2) wfirst[t][k2] = wfrag27(c0, t, k2);
+        } else {
+          const uint4* wq0 = reinterpret_cast<const uint4*>(wpn) + (long long)(c0 / 8 + h) * a.Np + colbase + r;
+#pragma unroll
+          for (int t = 0; t < WG0; ++t)
+#pragma unroll
+            for (int k2 = 0; k2 < WKS; ++k2) wfirst[t][k2] = wq0[(a.slab + ci.tap0)[t] * slabsz8 + k2 * 2 * a.Np];
+        }
       }
     }
     // ---------------- stage the input box (KCI channels) into LDS ----------------
@@ -623,6 +651,10 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
           constexpr int G = OCC > 2 ? 3 : (KS == 1 ? 9 : 5);
           constexpr int NG = (27 + G - 1) / G;
           static_assert(G == WG0 && KS == WKS, "first-group prefetch must match the group shape");
+          // canonical stage (row loader): tap offsets are immediates, weight requests scalar-based (tap27_off, wfrag27);
+          // otherwise both come from the tap tables
+          auto stage27 = [&](auto fc) {
+          constexpr bool CANON = decltype(fc)::value;
           uint4 wset[2][G][KS];
 #pragma unroll
           for (int t = 0; t < G; ++t)
@@ -630,7 +662,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
             for (int ks = 0; ks < KS; ++ks) wset[0][t][ks] = wfirst[t][ks];     // requested before the staging pass
           uint4 avc[MB];
           {
-            const int ta0 = ttoff[0] * VS;
+            const int ta0 = CANON ? 0 : ttoff[0] * VS;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) avc[mb] = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + ta0);
           }
@@ -641,7 +673,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
               for (int t = 0; t < G; ++t) {
                 if ((g + 1) * G + t < 27) {
 #pragma unroll
-                  for (int ks = 0; ks < KS; ++ks) wset[(g + 1) & 1][t][ks] = wcol[tslab[(g + 1) * G + t] * slabsz8 + ks * np2];
+                  for (int ks = 0; ks < KS; ++ks)
+                    wset[(g + 1) & 1][t][ks] = CANON ? wfrag27(c0, (g + 1) * G + t, ks) : wcol[tslab[(g + 1) * G + t] * slabsz8 + ks * np2];
                 }
               }
             }
@@ -661,7 +694,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
                   const int nidx = ks + 1 < KS ? idx : idx + 1, nks2 = ks + 1 < KS ? ks + 1 : 0;
                   uint4 avn[MB];
                   int tan = 0;
-                  if (more) tan = ttoff[nidx] * VS + nks2 * 16;
+                  if (more) tan = (CANON ? tap27_off(nidx, RBY) : ttoff[nidx]) * VS + nks2 * 16;
 #pragma unroll
                   for (int mb = 0; mb < MB; ++mb) {
                     if (more) avn[mb] = *reinterpret_cast<const uint4*>(lh + rowaddr[mb] + tan);
@@ -680,6 +713,13 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(GArgs a) {
               }
             }
             __builtin_amdgcn_sched_barrier(0);
+          }
+          };
+          if constexpr (CANON_CFG) {
+            if (fast) stage27(std::true_type{});
+            else stage27(std::false_type{});
+          } else {
+            stage27(std::false_type{});
           }
         } else if (nks == KS && ntap >= 4) {
           // A tap is only MB*KS MFMAs of 32 cycles: far less than an L2 round trip, so the weight fragments run
@@ -1775,10 +1815,13 @@ static void build_taps(const mmtta_conv_desc* d, int pz, int py, int px, Taps& t
   if (d->ksize == 1) {
     t.dz[0] = t.dy[0] = t.dx[0] = 0; t.slab[0] = 0; n = 1;
   } else if (!classes) {
-    const int sgn = (d->op == MMTTA_CONV_DGRAD) ? -1 : 1;   // stride-1 input gradient mirrors the taps
-    for (int kz = 0; kz < 3; ++kz) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+    // stride-1 input gradient mirrors the taps; they are enumerated in ascending (z, y, x) order of the voxel they READ in
+    // both forms (kernel tap 26 - m for the mirrored one), the order the canonical stage of igemm_kernel assumes (tap27_off)
+    const int sgn = (d->op == MMTTA_CONV_DGRAD) ? -1 : 1;
+    for (int m = 0; m < 27; ++m) {
+      const int q = sgn < 0 ? 26 - m : m, kz = q / 9, ky = q / 3 % 3, kx = q % 3;
       t.dz[n] = (signed char)(sgn * (kz - 1)); t.dy[n] = (signed char)(sgn * (ky - 1));
-      t.dx[n] = (signed char)(sgn * (kx - 1)); t.slab[n] = (kz * 3 + ky) * 3 + kx; ++n;
+      t.dx[n] = (signed char)(sgn * (kx - 1)); t.slab[n] = q; ++n;
     }
   } else {
     // out index i = 2*o - 1 + k.  parity 0: k=1 reads o=g (d=0); parity 1: k=0 reads g+1, k=2 reads g.
@@ -1819,6 +1862,12 @@ static int launch_cfg_t(const GArgs& a_in, const Taps* ht, int tiles, hipStream_
     a.cls[c].mBXY = (unsigned)(((1ULL << 32) + (unsigned long long)BX * BY - 1) / ((unsigned long long)BX * BY));
     const size_t need = BF ? (size_t)BZ * BY * LP * (KCI + 8) * 2 : (size_t)BZ * BY * BX * (KCI + 1) * sizeof(float);
     if (need > lds) lds = need;
+  }
+  if (BF && a.rowload && a.si == 1 && a.ncls == 1 && a.cls[0].ntaps == 27) {
+    // the canonical stage addresses taps by formula: the tables must agree with it, or the generic loader runs
+    a.flip27 = a.slab[0] == 26 ? 1 : 0;
+    for (int t = 0; t < 27; ++t)
+      if (a.toff[t] != tap27_off(t, TY + 2) || a.slab[t] != (a.flip27 ? 26 - t : t)) a.rowload = 0;
   }
   if (lds < (4 * EPI_TILE_FLOATS + 4 * 2 * 32) * sizeof(float)) lds = (4 * EPI_TILE_FLOATS + 4 * 2 * 32) * sizeof(float);
   lds = (lds + 15) / 16 * 16;
@@ -2114,6 +2163,7 @@ extern "C" int mmtta_conv_run_sets(const mmtta_conv_desc* d, const mmtta_tensor*
   const int am = a.in_bf ? 8 : 4;
   const bool al = (((uintptr_t)x->ptr) % 16 == 0) && x->sw % am == 0 && x->sh % am == 0 && x->sd % am == 0 && x->sn % am == 0;
   a.vec4 = al ? 1 : 0;
+  a.flip27 = 0;
   {  // row-structured loader of the 3x3x3 stride-1 stages: 32-bit element offsets from 24-bit multiply-adds
     const int64_t lim24 = (int64_t)1 << 24;
     const int64_t last = (int64_t)(x->d - 1) * x->sd + (int64_t)(x->h - 1) * x->sh + (int64_t)(x->w - 1) * x->sw + x->c + 16;
