@@ -400,6 +400,7 @@ struct WTGeo {
   static constexpr int NG = BZ * BY * BX, ND = TZ * TY * 8;
   static constexpr int G_BYTES = NG * 64, D_BYTES = ND * 64;
   static constexpr int LDS_BYTES = G_BYTES + D_BYTES + 256;       // + scale / shift of the 32 module-input channels
+  __host__ __device__ static constexpr int lds_bytes(int nb) { return G_BYTES + nb * (D_BYTES + 256); }   // nb dense column blocks
   static constexpr int NK = ND / 16;                  // k steps: two tile rows of 8 voxels each
   // staging: an item = 8 channels (16 bytes of the bf16 image) of one voxel; a thread keeps ONE (x, channel chunk) of the
   // box and walks the box rows RPP at a time, so x, the channel offset and the LDS column are per-thread constants
@@ -439,17 +440,20 @@ typedef __attribute__((address_space(3))) wshort4* wlds4_t;
 // Software pipeline over the tiles of a workgroup: the dense tile and the first PG box passes of tile i+1 are requested
 // right before tile i's MFMA loop (which reads LDS only) and land under it; the remaining passes are requested first
 // thing in tile i+1 and land under the commit of the prefetched ones.
-template <int TZ, int TY, int SI, bool GBF, bool DBF, bool TD>
-__global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
+// NB = 2: ONE workgroup multiplies the gathered box with two 32-channel blocks of the dense operand (14 accumulator blocks:
+// one workgroup per CU).  The stride-2 layers stage a box of 12x the tile's voxels for 28 MFMAs a wave - the staging (vector
+// ALU, L2) is their cost, and every dense column block used to repeat it (conv 32->64 at 64^3: 2x, convT 128->32: 4x).
+template <int TZ, int TY, int SI, bool GBF, bool DBF, bool TD, int NB = 1>
+__global__ __launch_bounds__(256, (NB == 1 && SI == 1) ? 2 : 1) void wgrad_tr_kernel(WArgs a) {
   using G = WTGeo<TZ, TY, SI>;
   static_assert(TY % 2 == 0, "a k step is two rows of one z slice");
   extern __shared__ float lds[];
   unsigned char* gl = reinterpret_cast<unsigned char*>(lds);
-  unsigned char* dl = gl + G::G_BYTES;
+  unsigned char* dl = gl + G::G_BYTES;                  // NB dense images back to back
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, r = lane & 31;
-  const int cg0 = blockIdx.y * 32, cd0 = blockIdx.z * 32;
+  const int cg0 = blockIdx.y * 32, cd0 = blockIdx.z * 32 * NB;
 
   // operand addresses: lane part (group row q, 8-byte column chunk, row half) + tap (A only)
   const int lq = (lane & 15) >> 2, lp = lane & 3, lc = (lane >> 4) & 1;
@@ -460,14 +464,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
     const int tap = min(wave + 4 * j, 26);
     gread[j] = gl + (h * SI * G::BX + lq) * 64 + lc * 32 + lp * 8 + G::tap_off(tap);
   }
-  f32x16 acc[7];
+  f32x16 acc[NB][7];
 #pragma unroll
-  for (int j = 0; j < 7; ++j)
+  for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-  float dbs[8];
+    for (int j = 0; j < 7; ++j)
 #pragma unroll
-  for (int c = 0; c < 8; ++c) dbs[c] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[nb][j][i] = 0.f;
+  float dbs[NB][8];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dbs[nb][c] = 0.f;
   const bool want_db = a.dbpart != nullptr && blockIdx.y == 0;
 
   // ---- staging roles (per-thread constants)
@@ -478,10 +486,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
   const int dvox0 = tid >> 2, d8 = tid & 3;                      // dense item p: voxel dvox0 + 64 p, chunk d8
   unsigned char* dst = dl + dvox0 * 64 + d8 * 16;                // + p * 4096
   const int dzl = dvox0 / (TY * 8), dyl = (dvox0 >> 3) % TY, dxl = dvox0 & 7;     // (pass p adds 64 / (TY * 8) to z)
-  const int gcb = cg0 + 8 * c8, dcb = cd0 + 8 * d8;
+  const int gcb = cg0 + 8 * c8, dcb = cd0 + 8 * d8;               // (dense column block nb: + 32 nb)
   // clamped (always valid) load channels; rows of bf16 tensors are padded to 8 channels, of fp32 tensors to 4
   const unsigned gc_lo = GBF ? min(gcb, (a.Cg - 1) & ~7) : min(gcb, (a.Cg - 1) & ~3), gc_hi = min(gcb + 4, (a.Cg - 1) & ~3);
   const unsigned dc_lo = DBF ? min(dcb, (a.Cd - 1) & ~7) : min(dcb, (a.Cd - 1) & ~3), dc_hi = min(dcb + 4, (a.Cd - 1) & ~3);
+  // (column block 1 of a pair is whole: the host pairs blocks only when CDp / 32 is even and rows are padded to 8 channels)
+  const unsigned dc_lo1 = DBF ? min(dcb + 32, (a.Cd - 1) & ~7) : min(dcb + 32, (a.Cd - 1) & ~3), dc_hi1 = min(dcb + 36, (a.Cd - 1) & ~3);
   const bool gtail = (a.Cg & 7) != 0, dtail = (a.Cd & 7) != 0;  // only then can a chunk hold channels past the last one
   auto pair_mask = [](int c, int C) { return (c < C ? 0xffffu : 0u) | (c + 1 < C ? 0xffff0000u : 0u); };
   const unsigned gsd = (unsigned)a.gsd, gsh = (unsigned)a.gsh, gsw = (unsigned)a.gsw;
@@ -496,15 +506,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
   const int tpn = a.tz * a.ty * a.tx;
   constexpr int GP = G::GP, DP = G::DP;
   constexpr int PREF = (GBF || DBF) ? 40 : 32;                         // registers the cross-loop prefetch may hold
-  constexpr int PGmax = (PREF - DP * (DBF ? 4 : 8)) / (GBF ? 4 : 8);
+  constexpr int PGmax = (PREF - NB * DP * (DBF ? 4 : 8)) / (GBF ? 4 : 8);
   constexpr int PG = PGmax < 0 ? 0 : (PGmax < GP ? PGmax : GP);        // box passes prefetched across the MFMA loop
   Oct8<GBF> gv[GP];
-  Oct8<DBF> dq[DP];
+  Oct8<DBF> dq[NB * DP];
   unsigned pok = 0u;                             // bit p: box item of pass p lies inside the tensor
   unsigned dok = 0u;                             // bit p: dense item p lies inside the tensor
   int pn = -1, poz0 = 0, poy0 = 0, pox0 = 0;     // tile whose loads are in gv[0..PG) / dq
   int cn = -1;                                   // batch item the transform coefficients belong to
-  float* coefl = reinterpret_cast<float*>(dl + G::D_BYTES);     // [2][32]: scale, shift of the module-input channels
+  float* coefl = reinterpret_cast<float*>(dl + NB * G::D_BYTES);     // [NB][2][32]: scale, shift of the module-input channels
   const float relu_lo = (TD ? a.td.relu : a.tg.relu) ? 0.f : -__builtin_inff();
   unsigned gxoff = 0u;                           // per tile: x / channel part of the box offsets, x in bounds
   bool gxok = false;
@@ -570,6 +580,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
       dok |= ((yxok && oz < a.Dd) ? 1u : 0u) << p;
       const unsigned off = __umul24((unsigned)min(oz, a.Dd - 1), dsd) + yxoff;
       dq[p] = oct8_ld<DBF>(dbase, off + dc_lo, off + dc_hi);
+      if constexpr (NB == 2) dq[DP + p] = oct8_ld<DBF>(dbase, off + dc_lo1, off + dc_hi1);
     }
     pok = 0u;
     tile_x(pox0 * SI - 1);
@@ -589,16 +600,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
     static_for<PG, R1>([&](auto pc) { load_g(pc, gbase, iz0, iy0); });
     if (n != cn) {       // per-(n, channel) transform, once per batch item; kept in LDS (16 registers across the MFMA loop
                          // cost more than four LDS reads per tile); every thread of a chunk writes the same values
-      float s8[8], h8[8];
-      if constexpr (TD) nl_coeff_vec<8>(a.td, n, a.Cd, dcb, s8, h8);
-      else nl_coeff_vec<8>(a.tg, n, a.Cg, gcb, s8, h8);
-      const int k8 = TD ? d8 : c8;
+      if constexpr (NB == 1) {
+        float s8[8], h8[8];
+        if constexpr (TD) nl_coeff_vec<8>(a.td, n, a.Cd, dcb, s8, h8);
+        else nl_coeff_vec<8>(a.tg, n, a.Cg, gcb, s8, h8);
+        const int k8 = TD ? d8 : c8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { coefl[8 * k8 + j] = s8[j]; coefl[32 + 8 * k8 + j] = h8[j]; }
+        for (int j = 0; j < 8; ++j) { coefl[8 * k8 + j] = s8[j]; coefl[32 + 8 * k8 + j] = h8[j]; }
+      } else {
+#pragma unroll
+      for (int nb = 0; nb < (TD ? NB : 1); ++nb) {
+        float s8[8], h8[8];
+        if constexpr (TD) nl_coeff_vec<8>(a.td, n, a.Cd, dcb + 32 * nb, s8, h8);
+        else nl_coeff_vec<8>(a.tg, n, a.Cg, gcb, s8, h8);
+        const int k8 = TD ? d8 : c8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { coefl[64 * nb + 8 * k8 + j] = s8[j]; coefl[64 * nb + 32 + 8 * k8 + j] = h8[j]; }
+      }
+      }
       cn = n;
       __syncthreads();
     }
     float sc[8], sh[8];
+    // (the one-block form is kept statement for statement: the register allocation of the two-workgroup kernels is at its
+    // limit, and the paired form's loop nest around the same statements cost them 100 bytes more spills, 206 -> 295 us)
+    if constexpr (NB == 1) {
     {
       const float4* cq = reinterpret_cast<const float4*>(coefl + 8 * (TD ? d8 : c8));
       const float4 s0 = cq[0], s1 = cq[1], h0 = cq[8], h1 = cq[9];
@@ -618,7 +644,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const unsigned cm = (dcb + j < a.Cd) ? okm : 0u;
-          dbs[j] += __uint_as_float(__float_as_uint(v[j]) & cm);
+          dbs[0][j] += __uint_as_float(__float_as_uint(v[j]) & cm);
         }
       }
       uint4 pk;
@@ -628,6 +654,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
         pk.x &= pair_mask(dcb, a.Cd); pk.y &= pair_mask(dcb + 2, a.Cd); pk.z &= pair_mask(dcb + 4, a.Cd); pk.w &= pair_mask(dcb + 6, a.Cd);
       }
       *reinterpret_cast<uint4*>(dst + p * 4096) = pk;
+    }
+    } else {
+#define MMTTA_COEF_REGS(nb)                                                                                            \
+    {                                                                                                                  \
+      const float4* cq = reinterpret_cast<const float4*>(coefl + 64 * (nb) + 8 * (TD ? d8 : c8));                      \
+      const float4 s0 = cq[0], s1 = cq[1], h0 = cq[8], h1 = cq[9];                                                     \
+      sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w; \
+      sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w; \
+    }
+    if constexpr (!TD || NB == 1) MMTTA_COEF_REGS(0)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+    if constexpr (TD && NB > 1) MMTTA_COEF_REGS(nb)
+    const int dcn = dcb + 32 * nb;
+#pragma unroll
+    for (int p = 0; p < DP; ++p) {
+      float v[8];
+      oct8_f8(dq[nb * DP + p], v);
+      if constexpr (TD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), relu_lo);
+      }
+      const unsigned okm = ((dok >> p) & 1u) ? 0xffffffffu : 0u;
+      if (want_db) {                                                  // bias gradient: fp32 sums of what is staged
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned cm = (dcn + j < a.Cd) ? okm : 0u;
+          dbs[nb][j] += __uint_as_float(__float_as_uint(v[j]) & cm);
+        }
+      }
+      uint4 pk;
+      pk.x = wpack2(v[0], v[1]) & okm; pk.y = wpack2(v[2], v[3]) & okm;
+      pk.z = wpack2(v[4], v[5]) & okm; pk.w = wpack2(v[6], v[7]) & okm;
+      if (dtail) {
+        pk.x &= pair_mask(dcn, a.Cd); pk.y &= pair_mask(dcn + 2, a.Cd); pk.z &= pair_mask(dcn + 4, a.Cd); pk.w &= pair_mask(dcn + 6, a.Cd);
+      }
+      *reinterpret_cast<uint4*>(dst + nb * G::D_BYTES + p * 4096) = pk;
+    }
+    }
     }
     static_for<0, R1>([&](auto pc) { commit_g(pc, sc, sh); });
     if constexpr (R1 < GP) {
@@ -644,8 +709,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
     // ---- MFMAs.  Fragment f = (k step, tap slot) is read LA MFMAs before it multiplies (a ring of LA + 1 register sets;
     // a fence per MFMA, or the scheduler sinks every read to one MFMA ahead and the MFMA waits out the LDS latency)
     constexpr int LA = 3, NF = G::NK * 7;
-    wbf16x8 ra[LA + 1], fb[2];
-    fb[0] = MMTTA_TR_FRAG(dread, 0);
+    wbf16x8 ra[LA + 1], fb[2][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) fb[0][nb] = MMTTA_TR_FRAG(dread, nb * G::D_BYTES);
 #pragma unroll
     for (int f = 0; f < LA; ++f) ra[f] = MMTTA_TR_FRAG(gread[f % 7], G::row_off(f / 7));
     __builtin_amdgcn_sched_barrier(0);
@@ -653,50 +719,62 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(WArgs a) {
     for (int f = 0; f < NF; ++f) {
       const int ks = f / 7, j = f % 7;
       if (f + LA < NF) ra[(f + LA) % (LA + 1)] = MMTTA_TR_FRAG(gread[(f + LA) % 7], G::row_off((f + LA) / 7));
-      if (j == 2 && ks + 1 < G::NK) fb[(ks + 1) & 1] = MMTTA_TR_FRAG(dread, (ks + 1) * 1024);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[f % (LA + 1)], fb[ks & 1], acc[j], 0, 0, 0);
+      if (j == 2 && ks + 1 < G::NK) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) fb[(ks + 1) & 1][nb] = MMTTA_TR_FRAG(dread, nb * G::D_BYTES + (ks + 1) * 1024);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[nb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[f % (LA + 1)], fb[ks & 1][nb], acc[nb][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
   const int sl = sx;
 #pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
   for (int j = 0; j < 7; ++j) {
     const int tap = wave + 4 * j;
     if (tap < 27) {
-      float* sb = a.slab + (((long long)sl * 27 + tap) * a.CGp + cg0) * a.CDp + cd0 + r;
+      float* sb = a.slab + (((long long)sl * 27 + tap) * a.CGp + cg0) * a.CDp + cd0 + 32 * nb + r;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        sb[(long long)row * a.CDp] = acc[j][i];
+        sb[(long long)row * a.CDp] = acc[nb][j][i];
       }
     }
   }
   if (want_db) {                                    // thread (voxel slot, chunk d8) holds channels 8 d8 .. 8 d8 + 7
     float* red8 = lds;                              // the images are dead: the loop ended with a barrier
 #pragma unroll
-    for (int c = 0; c < 8; ++c) red8[tid * 8 + c] = dbs[c];
-    __syncthreads();
-    if (tid < 32) {
-      float sacc = 0.f;
+    for (int nb = 0; nb < NB; ++nb) {
+      if (nb) __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 8; ++c) red8[tid * 8 + c] = dbs[nb][c];
+      __syncthreads();
+      if (tid < 32) {
+        float sacc = 0.f;
 #pragma unroll 8
-      for (int q = 0; q < 64; ++q) sacc += red8[((q << 2) | (tid >> 3)) * 8 + (tid & 7)];
-      a.dbpart[(long long)sl * a.CDp + cd0 + tid] = sacc;
+        for (int q = 0; q < 64; ++q) sacc += red8[((q << 2) | (tid >> 3)) * 8 + (tid & 7)];
+        a.dbpart[(long long)sl * a.CDp + cd0 + 32 * nb + tid] = sacc;
+      }
     }
   }
 }
 
-template <int TZ, int TY, int SI, bool GBF, bool DBF, bool TD>
+template <int TZ, int TY, int SI, bool GBF, bool DBF, bool TD, int NB = 1>
 static int launch_wgrad_tr_t(const WArgs& a, int S, hipStream_t s) {
   using G = WTGeo<TZ, TY, SI>;
-  auto kern = wgrad_tr_kernel<TZ, TY, SI, GBF, DBF, TD>;
+  auto kern = wgrad_tr_kernel<TZ, TY, SI, GBF, DBF, TD, NB>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid(S, a.CGp / 32, a.CDp / 32);
-  hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, s, a);
+  MMTTA_CHECK((a.CDp / 32) % NB == 0, MMTTA_ERR_INVALID, "wgrad: %d dense column blocks in groups of %d", a.CDp / 32, NB);
+  dim3 grid(S, a.CGp / 32, a.CDp / 32 / NB);
+  hipLaunchKernelGGL(kern, grid, dim3(256), G::lds_bytes(NB), s, a);
   return launch_status("conv wgrad bf16 (transposed reads)");
 }
 
@@ -876,8 +954,16 @@ static int launch_wgrad_tr1(const WArgs& a, int S, hipStream_t s) {
 // transposed convolution (stride 2 only); the other operand is a gradient: read as is, fp32- or (method.grad_storage: bf16,
 // then next to a bf16-stored module input only) bf16-stored
 template <int TZ, int TY, int SI>
-static int launch_wgrad_tr(const WArgs& a, int S, hipStream_t s) {
+static int launch_wgrad_tr(const WArgs& a, int S, hipStream_t s, int ncb = 1) {
   MMTTA_CHECK(a.gvec4 && a.dvec4, MMTTA_ERR_INVALID, "wgrad: transposed-read kernel selected for unaligned tensors");
+  MMTTA_CHECK(ncb == 1 || (a.g_bf && a.d_bf), MMTTA_ERR_INVALID, "wgrad: paired column blocks exist for the all-bf16 forms");
+  if (ncb == 2) {
+    if constexpr (SI == 2) {
+      if (a.convt) return launch_wgrad_tr_t<TZ, TY, SI, true, true, true, 2>(a, S, s);
+    }
+    MMTTA_CHECK(!a.convt, MMTTA_ERR_UNSUPPORTED, "wgrad: conv_transpose is stride 2 only");
+    return launch_wgrad_tr_t<TZ, TY, SI, true, true, false, 2>(a, S, s);
+  }
   if (a.convt) {
     MMTTA_CHECK(!a.g_bf || a.d_bf, MMTTA_ERR_UNSUPPORTED, "wgrad: a bf16-stored gradient needs a bf16-stored module input");
     if constexpr (SI == 2) {
@@ -1669,6 +1755,8 @@ struct WGeo {
   int ips, nsets; // batch items per parameter set, sets per launch: tiles / S / nsl / *_floats / colsum_blocks are PER SET
 };
 
+static const int g_wgrad_pair = getenv("MMTTA_WGRAD_PAIR") ? atoi(getenv("MMTTA_WGRAD_PAIR")) : 1;      // (A/B switch: 0 off, 2: every stride-1 layer too)
+
 static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtta_tensor* dy, const mmtta_param_sets* sets, WGeo& w) {
   MMTTA_CHECK(d && x && dy && x->ptr && dy->ptr, MMTTA_ERR_INVALID, "wgrad: null argument");
   {
@@ -1801,7 +1889,13 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   w.tiles = w.tz * w.ty * w.tx * w.ips;
   w.CGp = roundup(w.g->c, 32);
   w.CDp = roundup(w.dn->c, 32);
-  const int blocks_cc = (w.CGp / 32) * (w.CDp / 32);
+  // both operands bf16-stored: a workgroup takes two dense column blocks per staged box (wgrad_tr_kernel NB) - every
+  // stride-2 layer, and the stride-1 layers of <= 128 dense channels (per group of 8 volumes: conv 32->64 s2 162 -> 112 us,
+  // convT 128->32 307 -> 210, convT 256->64 200 -> 144, 64->128 s2 102 -> 64; 64->64 s1 120 -> 98, 128->128 83 -> 73; the
+  // 256- and 512-channel stride-1 layers have hundreds of workgroups and want two of them per CU: 512->512 218 -> 224)
+  if (w.tr && g_wgrad_pair && (w.si == 2 || w.CDp <= 128 || g_wgrad_pair >= 2) && is_bf16(w.g) && is_bf16(w.dn) && (w.CDp / 32) % 2 == 0)
+    w.ncb = 2;
+  const int blocks_cc = (w.CGp / 32) * (w.CDp / 32 / w.ncb);
   // workgroups (= slabs x channel blocks) per launch.  One volume in flight: 512 beats 256 by 3 % of the weight-gradient
   // time; two in flight (method.lanes: 2, the default) the other lane fills the CUs and halving the slab traffic wins:
   // 512 / 256 / 128 -> 40.1 / 41.5 / 40.6 volumes/s
@@ -2004,7 +2098,7 @@ static int conv_wgrad_impl(const mmtta_conv_desc* d, const mmtta_tensor* x, cons
   a.dvec4 = wvec_ok(w.dn) ? 1 : 0;
   const int SQ = w.S * Q;                // slabs of the launch
   if (w.tr1) st = launch_wgrad_tr1(a, SQ, s);
-  else if (w.tr) st = (w.si == 1) ? launch_wgrad_tr<4, 8, 1>(a, SQ, s) : launch_wgrad_tr<2, 4, 2>(a, SQ, s);
+  else if (w.tr) st = (w.si == 1) ? launch_wgrad_tr<4, 8, 1>(a, SQ, s, w.ncb) : launch_wgrad_tr<2, 4, 2>(a, SQ, s, w.ncb);
   else if (w.ntaps == 1) st = launch_wgrad<4, 4, 8, 1>(a, SQ, s);
   else st = (w.si == 1) ? launch_wgrad<4, 4, 8, 7>(a, SQ, s) : launch_wgrad<2, 2, 8, 7>(a, SQ, s);
   if (st || g_profile_main_only) return st;
