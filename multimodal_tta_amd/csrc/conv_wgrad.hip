@@ -1895,6 +1895,8 @@ static int wgeometry(const mmtta_conv_desc* d, const mmtta_tensor* x, const mmtt
   // 256- and 512-channel stride-1 layers have hundreds of workgroups and want two of them per CU: 512->512 218 -> 224)
   if (w.tr && g_wgrad_pair && (w.si == 2 || w.CDp <= 128 || g_wgrad_pair >= 2) && is_bf16(w.g) && is_bf16(w.dn) && (w.CDp / 32) % 2 == 0)
     w.ncb = 2;
+  // (a pair counts as one block: the launch keeps its workgroup count and takes twice the slabs - measured against the same
+  // slabs with half the workgroups, three runs each on one box: 96.5 / 96.1 volumes/s, 94.7 without pairs)
   const int blocks_cc = (w.CGp / 32) * (w.CDp / 32 / w.ncb);
   // workgroups (= slabs x channel blocks) per launch.  One volume in flight: 512 beats 256 by 3 % of the weight-gradient
   // time; two in flight (method.lanes: 2, the default) the other lane fills the CUs and halving the slab traffic wins:

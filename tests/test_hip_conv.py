@@ -938,12 +938,54 @@ def test_thin_wgrad_on_transposed_reads(cin, cout, k, stride, transposed, shape,
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", [
+    (32, 64, 3, 2, False, (2, 16, 16, 32)), (64, 128, 3, 2, False, (1, 9, 11, 13)), (128, 32, 3, 2, True, (2, 6, 8, 8)),
+    (256, 64, 3, 2, True, (1, 4, 4, 8)), (64, 64, 3, 1, False, (2, 8, 16, 16)), (128, 128, 3, 1, False, (1, 5, 9, 11)),
+    (40, 72, 3, 2, False, (1, 8, 8, 16))])
+def test_paired_column_blocks_of_the_transposed_read_wgrad(cin, cout, k, stride, transposed, shape):
+    """Both operands bf16-stored (method.storage + method.grad_storage: bf16): the stride-2 layers, and the stride-1 layers of
+    <= 128 dense channels, stage the gathered box once for TWO 32-channel blocks of the dense operand (wgrad_tr_kernel NB =
+    2, one workgroup per CU, twice the slabs).  Several tiles per slab, two batch items, ragged extents, the norm-on-load of
+    the module input on either side (gathered: convolution, dense: transposed convolution), bias gradient, accumulate -
+    against torch fp32 within the bf16-operand bound; (40, 72) has an odd number of column blocks and stays unpaired."""
+    from multimodal_tta_amd import ops
+
+    torch.manual_seed(41 + cin + 3 * cout)
+    n, d, h, w = shape
+    mod = ref_module(cin, cout, k, stride, transposed)
+    x = (torch.randn(n, cin, d, h, w) * 1.5 + 0.25).to(torch.bfloat16).float()
+    mu = x.mean(dim=(2, 3, 4))
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    xin = F.relu((x - mu[:, :, None, None, None]) * rstd[:, :, None, None, None]).requires_grad_(True)
+    y_ref = mod(xin)
+    gy = torch.randn_like(y_ref).to(torch.bfloat16).float()
+    y_ref.backward(gy)
+    nl = ops.NL(mu.reshape(-1).cuda().contiguous(), rstd.reshape(-1).cuda().contiguous(), relu=True)
+    wt = mod.weight.detach().cuda().contiguous()
+    op = ops.ConvOp(cin, cout, k, stride, transposed, "cuda", dtype=ops.BF16)
+    op.pack(wt)
+    import ctypes as C
+    from multimodal_tta_amd import _lib
+    kid = _lib.load().mmtta_conv_wgrad_kernel(C.byref(op.d_fwd), C.byref(ops.desc_cl(cl_bf16(x))), C.byref(ops.desc_cl(cl_bf16(gy))))
+    assert kid in (7, 8), "the transposed-read kernel takes these layers"
+    dw = torch.empty_like(wt)
+    db = torch.empty(cout, device="cuda")
+    op.wgrad(cl_bf16(x), nl, cl_bf16(gy), dw, db)
+    op.wgrad(cl_bf16(x), nl, cl_bf16(gy), dw, db, accumulate=True)
+    torch.cuda.synchronize()
+    ref = mod.weight.grad
+    assert (dw.cpu() / 2 - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item() + 1e-5
+    close("bias gradient", db.cpu() / 2, mod.bias.grad)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", [
     (32, 32, 3, 1, False, (1, 8, 8, 16)), (64, 128, 3, 2, False, (1, 6, 6, 8)), (64, 32, 3, 2, True, (1, 4, 4, 8)),
     (256, 512, 1, 1, False, (1, 4, 4, 4)), (40, 72, 3, 1, False, (2, 5, 9, 11))])
 def test_bf16_stored_gradients_through_the_convolutions(cin, cout, k, stride, transposed, shape):
     """method.grad_storage: bf16 - the output gradient dy arrives bf16-stored and the input gradient dx leaves bf16-stored.
     With a bf16-representable dy the weight / bias gradient equal the fp32-stored call BIT FOR BIT (the kernels round dy to
-    bf16 while staging it anyway: same operands, same order) and dx equals round_bf16(fp32-stored dx) to one bf16 ulp."""
+    bf16 while staging it anyway: same operands, same order - at these sizes also where the all-bf16 call pairs dense column
+    blocks, wgrad_tr_kernel NB = 2: the slab count is capped by the tile count either way) and dx equals
+    round_bf16(fp32-stored dx) to one bf16 ulp."""
     from multimodal_tta_amd import ops
 
     torch.manual_seed(7 + cin)
