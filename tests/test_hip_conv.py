@@ -940,13 +940,15 @@ def test_thin_wgrad_on_transposed_reads(cin, cout, k, stride, transposed, shape,
 @pytest.mark.parametrize("cin,cout,k,stride,transposed,shape", [
     (32, 64, 3, 2, False, (2, 16, 16, 32)), (64, 128, 3, 2, False, (1, 9, 11, 13)), (128, 32, 3, 2, True, (2, 6, 8, 8)),
     (256, 64, 3, 2, True, (1, 4, 4, 8)), (64, 64, 3, 1, False, (2, 8, 16, 16)), (128, 128, 3, 1, False, (1, 5, 9, 11)),
-    (40, 72, 3, 2, False, (1, 8, 8, 16))])
+    (40, 72, 3, 2, False, (1, 8, 8, 16)), (32, 40, 3, 2, False, (2, 8, 8, 16)), (40, 32, 3, 2, True, (1, 4, 6, 8)),
+    (24, 48, 3, 1, False, (1, 8, 8, 8))])
 def test_paired_column_blocks_of_the_transposed_read_wgrad(cin, cout, k, stride, transposed, shape):
     """Both operands bf16-stored (method.storage + method.grad_storage: bf16): the stride-2 layers, and the stride-1 layers of
     <= 128 dense channels, stage the gathered box once for TWO 32-channel blocks of the dense operand (wgrad_tr_kernel NB =
     2, one workgroup per CU, twice the slabs).  Several tiles per slab, two batch items, ragged extents, the norm-on-load of
     the module input on either side (gathered: convolution, dense: transposed convolution), bias gradient, accumulate -
-    against torch fp32 within the bf16-operand bound; (40, 72) has an odd number of column blocks and stays unpaired."""
+    against torch fp32 within the bf16-operand bound; (40, 72) has an odd number of column blocks and stays unpaired, 40 and
+    48 dense channels make the second block of the pair a ragged one (8 / 16 live channels)."""
     from multimodal_tta_amd import ops
 
     torch.manual_seed(41 + cin + 3 * cout)
