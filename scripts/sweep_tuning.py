@@ -39,6 +39,7 @@ KNOBS["v24"] = [_V24] + [dict(_V24, splitk_below=b, splitk_target=t) for (b, t) 
                [dict(_V24, wgrad_workgroups=w) for w in (11, 43)] + [dict(_V24, wgrad_thin_slabs=t) for t in (21, 86)] + \
                [dict(_V24, cls_fused_min=c) for c in (11, 43)]
 KNOBS["v24w"] = [dict(_V24, wgrad_workgroups=w) for w in (22, 43, 64, 96, 128)]
+KNOBS["v24p"] = [dict(_V24, wgrad_workgroups=w) for w in (22, 16, 32, 12)]          # around 22 once the column pairs took a CU each
 KNOBS["all"] = KNOBS["splitk"] + KNOBS["wgrad"][1:] + [dict(splitk_below=24, splitk_target=32, wgrad_workgroups=32, wgrad_thin_slabs=64),
                                                        dict(splitk_below=48, splitk_target=64, wgrad_workgroups=64, wgrad_thin_slabs=128)]
 
